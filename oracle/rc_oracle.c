@@ -185,6 +185,11 @@ int rco_table_get(const rco_table *t, const rco_kmer *km)
     return table_get_canon(t, rco_kmer_canonical(km, t->k));
 }
 
+void rco_table_put_many(rco_table *t, const uint64_t *canon, const int32_t *counts, size_t n)
+{
+    for (size_t i = 0; i < n; ++i) rco_table_put_canon(t, canon[i], counts[i]);
+}
+
 size_t rco_table_size(const rco_table *t) { return t->n; }
 
 size_t rco_table_export(const rco_table *t, uint64_t *codes, int32_t *counts, size_t cap)

@@ -1,0 +1,150 @@
+// rc_common.h -- shared scalar primitives of the MI355X correction path: 2-bit rolling k-mer
+// code with the reference's one-slot invalid tracker, canonical form, bucket hash, table bucket
+// layout, and GetBound in IEEE double.
+//
+// Reference behaviour restated (paths relative to /root/reference):
+//   KmerCode.h:14-27,58-71, KmerCode.cpp:7-42   rolling code / canonical
+//   Store.h:51-66                               Put / GetCount semantics
+//   ErrorCorrection.cpp:139-142                 GetBound
+//
+// This header is compiled by hipcc for gfx950 (product) and by g++ for the lane-serial
+// simulation harness under tests/hostsim (a test-only aid: there is no GPU in the build
+// container, so the wave-uniform control flow of the search kernel is first checked against the
+// oracle on the CPU).  RC_HD is the only portability hook.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define RC_HD __host__ __device__ __forceinline__
+#else
+#define RC_HD inline
+#endif
+
+#define RC_MAX_READ_LENGTH 1024  // utils.h:7 (reads hold <=1023 bases)
+#define RC_MAX_TRIAL 1025        // ErrorCorrection.cpp:7
+#define RC_INF 1000000000        // utils.h:10
+#define RC_INT_MIN (-2147483647 - 1)
+
+// ---- table bucket: 64 B = 5 x {key_lo,key_hi,count} + 1 meta dword -------------------------
+// count == 0 marks an empty slot (stored counts are >= 2 by construction, main.cpp:299).
+// meta bit0 = "some key whose home is <= this bucket lives in a later bucket" (probe goes on).
+#define RC_BUCKET_SLOTS 5
+#define RC_BUCKET_DWORDS 16
+#define RC_BUCKET_BYTES 64
+
+struct rc_table_view {
+    const uint32_t *buckets;  // nbuckets_alloc * 16 dwords, 64-B aligned
+    uint32_t home_mask;       // nbuckets_home - 1 (power of two)
+    uint32_t nbuckets_alloc;  // home buckets + slack (no wrap-around)
+};
+
+RC_HD uint64_t rc_kmer_mask(int k) { return k >= 32 ? ~0ull : ((1ull << (2 * k)) - 1ull); }
+
+RC_HD uint64_t rc_brev64(uint64_t x)
+{
+#if defined(__clang__)
+    return __builtin_bitreverse64(x);
+#else
+    x = ((x >> 1) & 0x5555555555555555ull) | ((x & 0x5555555555555555ull) << 1);
+    x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
+    x = ((x >> 8) & 0x00FF00FF00FF00FFull) | ((x & 0x00FF00FF00FF00FFull) << 8);
+    x = ((x >> 16) & 0x0000FFFF0000FFFFull) | ((x & 0x0000FFFF0000FFFFull) << 16);
+    return (x >> 32) | (x << 32);
+#endif
+}
+
+// reverse complement of a k-mer code (first base in the most significant 2 bits, as the
+// reference's KmerCode): reverse the 2-bit groups, complement, drop the unused low bits.
+RC_HD uint64_t rc_revcomp(uint64_t code, int k)
+{
+    uint64_t x = rc_brev64(code);
+    x = ((x & 0x5555555555555555ull) << 1) | ((x >> 1) & 0x5555555555555555ull);
+    return (~x) >> (64 - 2 * k);
+}
+
+// KmerCode::GetCanonicalKmerCode, KmerCode.h:58-71
+RC_HD uint64_t rc_canonical(uint64_t code, int k)
+{
+    uint64_t rc = rc_revcomp(code, k);
+    return rc < code ? rc : code;
+}
+
+// 32-bit bucket hash of a canonical code (free choice: results do not depend on it)
+RC_HD uint32_t rc_hash(uint64_t key)
+{
+    uint32_t h = (uint32_t)key * 0x9E3779B1u + (uint32_t)(key >> 32) * 0x85EBCA77u;
+    h ^= h >> 15;
+    h *= 0x2C1B3C6Du;
+    h ^= h >> 12;
+    h *= 0x297A2D39u;
+    h ^= h >> 15;
+    return h;
+}
+
+// ---- rolling code with invalid tracker (KmerCode.cpp:7-42) ---------------------------------
+// base codes: 0..3 = A,C,G,T; >= 4 = not ACGT (contributes bits 11 and sets the tracker)
+struct rc_kmer {
+    uint64_t code;
+    int inv;
+};
+
+RC_HD rc_kmer rc_append(rc_kmer km, int k, int b)
+{
+    rc_kmer r;
+    int inv = km.inv;
+    if (inv != -1) ++inv;
+    r.code = ((km.code << 2) & rc_kmer_mask(k)) | (uint64_t)(b >= 4 ? 3 : b);
+    if (b >= 4) inv = 0;
+    if (inv >= k) inv = -1;
+    r.inv = inv;
+    return r;
+}
+
+RC_HD rc_kmer rc_prepend(rc_kmer km, int k, int b)
+{
+    rc_kmer r;
+    int inv = km.inv;
+    if (inv != -1) inv -= 1;
+    if (inv < 0) inv = -1;
+    if (b >= 4) inv = k - 1;
+    r.code = ((km.code >> 2) | ((uint64_t)(b >= 4 ? 3 : b) << (2 * (k - 1)))) & rc_kmer_mask(k);
+    r.inv = inv;
+    return r;
+}
+
+// ---- GetBound, ErrorCorrection.cpp:139-142 -------------------------------------------------
+// c*E + 6*sqrt(c*E) + 1 in IEEE double with separately rounded mul/add/sqrt (the reference is
+// x86-64 SSE2: no FMA contraction, correctly rounded sqrtsd).  On the device the explicit
+// round-to-nearest intrinsics are used so hipcc cannot contract a*b+c into an FMA.
+RC_HD double rc_bound_d(int c, double e)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    double ce = __dmul_rn((double)c, e);
+    double s = __dmul_rn(6.0, __dsqrt_rn(ce));
+    return __dadd_rn(__dadd_rn(ce, s), 1.0);
+#else
+    volatile double ce = (double)c * e;
+    volatile double s = 6.0 * __builtin_sqrt(ce);
+    volatile double r = ce + s;
+    return r + 1.0;
+#endif
+}
+
+// the implicit double->int conversions at ErrorCorrection.cpp:164,798,815,821,1282 are
+// cvttsd2si on the reference's platform: INT_MIN for NaN / out of range, truncation otherwise
+RC_HD int rc_bound_i(int c, double e)
+{
+    if (c < 0) return RC_INT_MIN;  // sqrt(negative) = NaN
+    double x = rc_bound_d(c, e);
+    if (!(x < 2147483648.0)) return RC_INT_MIN;
+    return (int)x;
+}
+
+// `b < GetBound(c)` as the double comparison at ErrorCorrection.cpp:1195 (NaN compares false)
+RC_HD bool rc_less_than_bound(int b, int c, double e)
+{
+    if (c < 0) return false;
+    return (double)b < rc_bound_d(c, e);
+}

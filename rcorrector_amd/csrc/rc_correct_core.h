@@ -1,0 +1,833 @@
+// rc_correct_core.h -- per-read error correction as ONE WAVEFRONT PER READ.
+//
+// All 64 lanes of a wave walk the same control flow ("wave-uniform" scalars); lanes split the
+// data-parallel parts (array fills, window scans, sort, the table probes of a search node).
+// The per-read state lives in LDS (rc_read_state), the table in HBM.
+//
+// Reference behaviour restated (paths relative to /root/reference, v1.0.7):
+//   GetStrongTrustedThreshold  ErrorCorrection.cpp:1482-1565   -> rc_front_end()
+//   ErrorCorrection            ErrorCorrection.cpp:682-1480    -> rc_correct_read()
+//   SearchPaths_Right/_Left    ErrorCorrection.cpp:201-678     -> rc_search() (explicit stack)
+//   InferPosThreshold          ErrorCorrection.cpp:144-173     -> rc_pos_threshold()
+//   GetKmerInformation         ErrorCorrection.cpp:1567-1602   -> rc_kmer_info()
+//
+// The template parameter W is the wave back end:
+//   W::lane, W::STRIDE          lane id and lane count (64 on the device)
+//   w.sync()                    orders LDS traffic between lanes of the wave
+//   w.probe4(km, dir, cnt)      counts of the four one-base extensions of km (lanes 0..3 probe)
+//   w.probe1(km)                count of one k-mer
+//   w.sort(a, n)                ascending in-LDS sort
+//   w.qual(i)                   quality character i of the read (HBM)
+//   w.stack_push/pop/top        search stack frames (HBM scratch)
+// The device back end is in rc_correct.hip; tests/hostsim has a lane-serial one (STRIDE = 1)
+// that lets the CPU test-suite diff this exact control flow against the oracle.
+#pragma once
+#include "rc_common.h"
+
+struct rc_run_params {
+    int k;
+    int max_fix_per_k;
+    double error_rate;
+    int bad_qual;  // badQualityThreshold as a signed char value
+};
+
+struct rc_island {
+    short from, to;
+};
+struct rc_segment {
+    short from, to, lanchor, ranchor;
+    int top2[2];
+};
+
+// search-stack frame: a node whose substitution alternatives are still pending
+struct rc_frame {
+    uint64_t code;
+    int inv;
+    int pos;
+    int t;
+    int threshold;
+    int fix_cnt;
+    int bottleneck;
+    int cnt[4];
+    int mask;  // pending substitution candidates, bit c
+};
+
+// per-wave LDS state; arrays sized for `cap` bases (cap >= read length, multiple of 64) and
+// `cap2` = cap rounded up to a power of two (sort buffer)
+struct rc_read_state {
+    unsigned char *base;    // [cap]   0..3 ACGT, 4 'N', 5 any other letter
+    int *counts;            // [cap]   k-mer counts of the uncorrected read (K1 output)
+    int *v;                 // [cap2]  sort buffer / fix positions
+    signed char *path;      // [cap]   scratch path of the search (the reference's iBuffer)
+    signed char *best;      // [cap]   accepted fixes (the reference's fix[])
+    unsigned char *strongb; // [cap]   isStrongTrusted per base
+    unsigned char *polya;   // [cap]   bit0 IsPolyA(.,k,2), bit1 IsPolyA(.,k,max(7,k/2))
+    rc_island *isl;         // [cap/2+2]
+    rc_segment *seg;        // [cap/2+2]
+    int len, kcnt;
+};
+
+RC_HD int rc_min(int a, int b) { return a < b ? a : b; }
+
+// ---- front end ---------------------------------------------------------------------------------
+// screens of ErrorCorrection.cpp:735-755 (=:1507-1527); returns 1 if the read is rejected
+template <class W>
+RC_HD int rc_screened(W &w, const rc_read_state &S, int k)
+{
+    int n = 0, a = 0, t = 0;
+    for (int i = w.lane; i < S.len; i += W::STRIDE) {
+        int b = S.base[i];
+        n += (b == 4);
+        a += (b == 0);
+        t += (b == 3);
+    }
+    n = w.reduce_add(n);
+    a = w.reduce_add(a);
+    t = w.reduce_add(t);
+    return n > 5 || a > S.len - k || t > S.len - k;
+}
+
+// IsPolyA for every k-mer window, thresholds 2 and max(7,k/2) (ErrorCorrection.cpp:53-71,
+// :776-779, :826)
+template <class W>
+RC_HD void rc_polya_flags(W &w, rc_read_state &S, int k)
+{
+    int thr7 = 7;
+    if (k / 2 > thr7) thr7 = k / 2;
+    for (int i = w.lane; i < S.kcnt; i += W::STRIDE) {
+        int a = 0, t = 0;
+        for (int j = 0; j < k; ++j) {
+            int b = S.base[i + j];
+            a += (b == 0);
+            t += (b == 3);
+        }
+        int f = 0;
+        if (a >= k - 2 || t >= k - 2) f |= 1;
+        if (a >= k - thr7 || t >= k - thr7) f |= 2;
+        S.polya[i] = (unsigned char)f;
+    }
+    w.sync();
+}
+
+// v[] = poly-A masked counts, sorted ascending (ErrorCorrection.cpp:774-784, :1247-1257)
+template <class W>
+RC_HD void rc_masked_sorted(W &w, rc_read_state &S)
+{
+    for (int i = w.lane; i < S.kcnt; i += W::STRIDE) S.v[i] = (S.polya[i] & 2) ? -1 : S.counts[i];
+    w.sync();
+    w.sort(S.v, S.kcnt);
+}
+
+// the "drop" scan of ErrorCorrection.cpp:787-816 / :1543-1563 on sorted v[].
+// returns strong; *found = 1 if a drop was found, *prev = v[i-1] at the drop
+template <class W>
+RC_HD int rc_initial_strong(W &w, const rc_read_state &S, int *found, int *prev)
+{
+    (void)w;
+    int i;
+    const int kcnt = S.kcnt;
+    for (i = kcnt - 1; i >= 1; --i)
+        if (S.v[i] > 2 * S.v[i - 1] && S.v[i] > 10) break;
+    if (i >= 1) {
+        *found = 1;
+        *prev = S.v[i - 1];
+        return S.v[i];
+    }
+    *found = 0;
+    *prev = 0;
+    for (i = 0; i < kcnt; ++i)
+        if (S.v[i] > 0) break;
+    return S.v[(i + kcnt - 1) / 2];
+}
+
+// GetStrongTrustedThreshold (ErrorCorrection.cpp:1482-1565).  Requires base[], counts[],
+// len, kcnt loaded.  info bit0 = drop found, bit1 = v[i-1]==2 at the drop, bit2 = screened.
+template <class W>
+RC_HD int rc_front_end(W &w, rc_read_state &S, const rc_run_params &P, int *info)
+{
+    *info = 4;
+    if (S.len < P.k) return -1;
+    if (rc_screened(w, S, P.k)) return -1;
+    rc_polya_flags(w, S, P.k);
+    rc_masked_sorted(w, S);
+    int found, prev;
+    int strong = rc_initial_strong(w, S, &found, &prev);
+    *info = (found ? 1 : 0) | ((found && prev == 2) ? 2 : 0);
+    return strong;
+}
+
+// ---- search ------------------------------------------------------------------------------------
+struct rc_search_ctx {
+    int dir;  // +1 right, -1 left
+    int start, to;
+    int max_fix_cnt;
+    int best_fix_cnt;
+    int best_bottleneck;
+    int trial_cnt;
+    int top2a, top2b;  // top2FixBottleNeck[0], [1] of the segment being searched
+};
+
+// cnt[idx] for a wave-uniform runtime idx without spilling the 4-array to scratch
+RC_HD int rc_sel4(const int c[4], int idx)
+{
+    int r = c[0];
+    r = idx == 1 ? c[1] : r;
+    r = idx == 2 ? c[2] : r;
+    r = idx == 3 ? c[3] : r;
+    return r;
+}
+
+// InferPosThreshold (ErrorCorrection.cpp:144-173) given the four extension counts
+RC_HD int rc_pos_threshold(const int cnt[4], int upper, double e)
+{
+    int mx = 0;
+    for (int i = 0; i < 4; ++i)
+        if (cnt[i] > mx) mx = cnt[i];
+    int ret = rc_bound_i(mx, e);
+    if (ret < 1) ret = 1;
+    if (upper > ret || upper <= 0) return ret;
+    return upper;
+}
+
+RC_HD rc_kmer rc_extend(rc_kmer km, int k, int dir, int b)
+{
+    return dir > 0 ? rc_append(km, k, b) : rc_prepend(km, k, b);
+}
+
+// terminal bookkeeping, ErrorCorrection.cpp:243-284 / :483-523
+template <class W>
+RC_HD void rc_search_terminal(W &w, rc_read_state &S, rc_search_ctx &C, int pos, int t, int fix_cnt,
+                              int bottleneck)
+{
+    if (bottleneck < t) ++fix_cnt;
+    if (fix_cnt < C.max_fix_cnt) {
+        C.top2a = bottleneck;
+        C.top2b = -1;
+    } else if (fix_cnt == C.max_fix_cnt) {
+        if (bottleneck > C.top2a) {
+            C.top2b = C.top2a;
+            C.top2a = bottleneck;
+        } else if (bottleneck > C.top2b) {
+            C.top2b = bottleneck;
+        }
+    }
+    if (fix_cnt < C.max_fix_cnt || (fix_cnt == C.max_fix_cnt && bottleneck > C.best_bottleneck)) {
+        if (fix_cnt < C.max_fix_cnt) C.trial_cnt = -(C.max_fix_cnt - fix_cnt + 1) * RC_MAX_TRIAL;
+        int lo, hi;  // copy path -> best over [lo, hi)
+        if (C.dir > 0) {
+            lo = C.start;
+            hi = pos;
+        } else {
+            lo = pos + 1;
+            hi = C.start + 1;
+        }
+        w.sync();
+        for (int i = lo + w.lane; i < hi; i += W::STRIDE) S.best[i] = S.path[i];
+        w.sync();
+        C.max_fix_cnt = fix_cnt;
+        C.best_bottleneck = bottleneck;
+        C.best_fix_cnt = 1;
+    } else if (fix_cnt == C.max_fix_cnt && bottleneck == C.best_bottleneck) {
+        C.best_fix_cnt += 1;
+    }
+}
+
+// one SearchPaths_Right/_Left call tree (ErrorCorrection.cpp:201-442 / :444-678), depth-first
+// in the reference's visiting order, with an explicit stack that only holds nodes whose
+// substitution alternatives are still pending.
+template <class W>
+RC_HD void rc_search(W &w, rc_read_state &S, const rc_run_params &P, rc_search_ctx &C, rc_kmer kc0,
+                     int t0)
+{
+    const int k = P.k;
+    const int dir = C.dir;
+    int sp = 0;
+    // current node
+    rc_kmer kc = kc0;
+    int pos = C.start, t = t0, fix_cnt = 0, bottleneck = 1000000000;
+    bool have = true;
+
+    for (;;) {
+        if (!have) {
+            if (sp == 0) break;
+            rc_frame f;
+            w.stack_top(sp - 1, f);
+            int c = 0;
+            while (!((f.mask >> c) & 1)) ++c;
+            f.mask &= ~(1 << c);
+            if (f.mask == 0)
+                --sp;
+            else
+                w.stack_set_mask(sp - 1, f.mask);
+            // substitution child c of node f (ErrorCorrection.cpp:345-371 / :579-607)
+            rc_kmer fk;
+            fk.code = f.code;
+            fk.inv = f.inv;
+            S.path[f.pos] = (signed char)c;
+            w.sync();
+            ++C.trial_cnt;
+            kc = rc_extend(fk, k, dir, c);
+            pos = f.pos + dir;
+            t = dir > 0 ? f.t : f.threshold;
+            fix_cnt = f.fix_cnt + (S.base[f.pos] < 4 ? 1 : 0);
+            bottleneck = rc_min(f.bottleneck, rc_sel4(f.cnt, c));
+            have = true;
+        }
+
+        // entry gate, ErrorCorrection.cpp:211-224 / :453-467
+        if (C.trial_cnt > RC_MAX_TRIAL) {
+            if (C.max_fix_cnt > 2) {
+                --C.max_fix_cnt;
+                C.best_fix_cnt = 0;
+                C.best_bottleneck = -1;
+                C.trial_cnt = 0;
+            } else {
+                have = false;
+                continue;
+            }
+        }
+        if (fix_cnt > C.max_fix_cnt) {
+            have = false;
+            continue;
+        }
+        if (dir > 0 ? (pos >= C.to) : (pos < C.to)) {
+            rc_search_terminal(w, S, C, pos, t, fix_cnt, bottleneck);
+            have = false;
+            continue;
+        }
+
+        int cnt[4];
+        w.probe4(kc, dir, cnt);
+        int threshold = rc_pos_threshold(cnt, t, P.error_rate);  // :287 / :525
+        const int b = S.base[pos];
+        const bool bvalid = b < 4;
+
+        int mask = 0;  // substitution candidates, :343-352 / :577-588
+        {
+            const int pa = dir > 0 ? S.polya[pos - k + 1] : S.polya[pos];
+            if (!S.strongb[pos] && !(pa & 1)) {
+                for (int c = 0; c < 4; ++c)
+                    if (c != b && cnt[c] >= threshold) mask |= 1 << c;
+            }
+        }
+
+        bool first = false;
+        rc_kmer nkc = kc;
+        int npos = pos, nt = t, nfix = fix_cnt, nbott = bottleneck;
+        if (bvalid) {
+            int c0 = rc_sel4(cnt, b);
+            if (c0 >= threshold) {  // keep the base, :302-312 / :539-549
+                S.path[pos] = -1;
+                nkc = rc_extend(kc, k, dir, b);
+                npos = pos + dir;
+                nt = dir > 0 ? t : threshold;
+                nbott = rc_min(bottleneck, c0);
+                first = true;
+            } else if (threshold == 1 && t <= 2) {  // accidental gap, :313-338 / :550-573
+                rc_kmer tmp = rc_extend(kc, k, dir, b);
+                int steps = 0, i = pos, c1 = c0;
+                for (; c1 < threshold && steps < k; ++steps) {
+                    i += dir;
+                    if (dir > 0 ? (i >= C.to) : (i < C.to)) break;
+                    tmp = rc_extend(tmp, k, dir, S.base[i]);
+                    c1 = w.probe1(tmp);
+                }
+                if (steps < k && (dir > 0 ? (i < C.to) : (i >= C.to))) {
+                    int lo = dir > 0 ? pos : i, hi = dir > 0 ? i : pos;
+                    for (int j = lo + w.lane; j <= hi; j += W::STRIDE) S.path[j] = -1;
+                    nkc = tmp;
+                    npos = i + dir;
+                    nt = dir > 0 ? t : threshold;
+                    nfix = fix_cnt + 1;
+                    first = true;
+                }
+            }
+        }
+
+        if (!first && mask) {  // first child is a substitution
+            int c = 0;
+            while (!((mask >> c) & 1)) ++c;
+            mask &= ~(1 << c);
+            S.path[pos] = (signed char)c;
+            ++C.trial_cnt;
+            nkc = rc_extend(kc, k, dir, c);
+            npos = pos + dir;
+            nt = dir > 0 ? t : threshold;
+            nfix = fix_cnt + (bvalid ? 1 : 0);
+            nbott = rc_min(bottleneck, rc_sel4(cnt, c));
+            first = true;
+        }
+
+        if (first) {
+            if (mask) {
+                rc_frame f;
+                f.code = kc.code;
+                f.inv = kc.inv;
+                f.pos = pos;
+                f.t = t;
+                f.threshold = threshold;
+                f.fix_cnt = fix_cnt;
+                f.bottleneck = bottleneck;
+                for (int c = 0; c < 4; ++c) f.cnt[c] = cnt[c];
+                f.mask = mask;
+                w.stack_push(sp, f);
+                ++sp;
+            }
+        } else {
+            // jump over an unfixable stretch, :393-441 / :629-677
+            rc_kmer tmp = kc;
+            int i, c1 = 0;
+            int thr = threshold;
+            if (dir > 0) {
+                for (i = pos; i < C.to; ++i) {
+                    int cn[4];
+                    if (i == pos) {
+                        for (int c = 0; c < 4; ++c) cn[c] = cnt[c];
+                    } else
+                        w.probe4(tmp, dir, cn);
+                    thr = rc_pos_threshold(cn, t, P.error_rate);
+                    int bb = S.base[i];
+                    tmp = rc_append(tmp, k, bb);
+                    c1 = (bb < 4) ? rc_sel4(cn, bb) : 0;
+                    S.path[i] = -1;
+                    if (c1 >= thr) break;
+                }
+                int pen = (i < S.len) ? (i - pos - k + 1) : ((i - pos) / 2);
+                if (pen <= 0) pen = 1;
+                nfix = fix_cnt + pen;
+                if (i >= C.to) i -= 1;
+                npos = i + 1;
+                nt = t;
+            } else {
+                for (i = pos; i >= C.to; --i) {
+                    int cn[4];
+                    if (i == pos) {
+                        for (int c = 0; c < 4; ++c) cn[c] = cnt[c];
+                    } else
+                        w.probe4(tmp, dir, cn);
+                    thr = rc_pos_threshold(cn, t, P.error_rate);
+                    int bb = S.base[i];
+                    tmp = rc_prepend(tmp, k, bb);
+                    c1 = (bb < 4) ? rc_sel4(cn, bb) : 0;
+                    S.path[i] = -1;
+                    if (c1 >= thr) break;
+                }
+                int pen = (i >= 0) ? (pos - i - k + 1) : (pos - 1);
+                if (pen <= 0) pen = 1;
+                nfix = fix_cnt + pen;
+                if (i <= C.to) ++i;  // :672
+                npos = i - 1;
+                nt = thr;
+            }
+            nkc = tmp;
+            nbott = bottleneck;
+        }
+        w.sync();
+        kc = nkc;
+        pos = npos;
+        t = nt;
+        fix_cnt = nfix;
+        bottleneck = nbott;
+        have = true;
+    }
+}
+
+// original k-mer of the read starting at base `a`, built as the reference does for an anchor
+// (Restart + k Appends, ErrorCorrection.cpp:1140-1142 / :1152-1154)
+template <class W>
+RC_HD rc_kmer rc_anchor(W &w, const rc_read_state &S, int k, int a)
+{
+    (void)w;
+    rc_kmer kc;
+    kc.code = 0;
+    kc.inv = -1;
+    for (int i = a; i < a + k; ++i) kc = rc_append(kc, k, S.base[i]);
+    return kc;
+}
+
+// ErrorCorrection (ErrorCorrection.cpp:682-1480).  On entry base[], counts[], polya[] are
+// loaded; strong0/info0 are this read's rc_front_end() results (from the threshold kernel) and
+// pair_t is min(strong of both mates) or -1.  Returns the reference's return value; best[]
+// holds the fixes to apply when the return value is > 0.
+template <class W>
+RC_HD int rc_correct_read(W &w, rc_read_state &S, const rc_run_params &P, int pair_t, int strong0,
+                          int info0)
+{
+    const int k = P.k;
+    const int len = S.len, kcnt = S.kcnt;
+    if (len < k) return -1;   // :713
+    if (info0 & 4) return -1; // screens, :735-755
+
+    // initial thresholds, :793-842
+    int strong = strong0, trust;
+    bool flag = false;
+    trust = rc_bound_i(strong, P.error_rate);
+    if (info0 & 1) {
+        if (strong >= 20 && (info0 & 2) && trust < 3) {
+            flag = true;
+            trust = 3;
+        }
+    }
+    if (pair_t >= 1 && strong > pair_t) {
+        if (!flag || pair_t < 20) trust = rc_bound_i(pair_t, P.error_rate);
+        strong = pair_t;
+    }
+    if (trust < 2) trust = 2;
+
+    int iter = 0, total_fix = 0, bad_segment_cnt = 0;
+    int tstart = 0, tend = 0;
+    for (;;) {  // :854-1291
+        const int allowed_fix = len;
+        total_fix = 0;
+        bool unfixable = false, force_next = false;
+        int isl_cnt = 0, longest = -1, j = 0, i;
+
+        for (i = w.lane; i < len; i += W::STRIDE) {
+            S.strongb[i] = 0;
+            S.path[i] = -1;
+        }
+        w.sync();
+
+        // trusted k-mer islands, :870-931
+        for (i = 0; i < kcnt; ++i) {
+            if (S.counts[i] >= strong && !(S.polya[i] & 1)) {
+                ++j;
+            } else {
+                if (j > longest) {
+                    longest = j;
+                    tstart = i - longest;
+                    tend = i - 1;
+                }
+                if (j >= 2) {
+                    S.isl[isl_cnt].from = (short)(i - j);
+                    S.isl[isl_cnt].to = (short)(i - 1);
+                    ++isl_cnt;
+                }
+                j = 0;
+            }
+        }
+        if (j > longest) {
+            longest = j;
+            tstart = i - longest;
+            tend = i - 1;
+        }
+        if (j >= 2) {
+            S.isl[isl_cnt].from = (short)(i - j);
+            S.isl[isl_cnt].to = (short)(i - 1);
+            ++isl_cnt;
+        }
+        w.sync();
+
+        // boundary adjustment, :934-965
+        for (i = 1; i < isl_cnt; ++i) {
+            int pf = S.isl[i - 1].from, pt = S.isl[i - 1].to, cf = S.isl[i].from, ct = S.isl[i].to;
+            if (cf <= pt + k) {
+                int len1 = pt - pf, len2 = ct - cf, overlap = pt + k - cf;
+                for (j = pt + 1; j < cf; ++j)
+                    if (S.counts[j] <= 2 && S.counts[j] < trust) break;
+                if (j >= cf) continue;
+                if (overlap > 3) continue;
+                if (len1 < len2)
+                    S.isl[i - 1].to = (short)(pt - (overlap + 1));
+                else
+                    S.isl[i].from = (short)(cf + (overlap + 1));
+                w.sync();
+            }
+        }
+
+        // to base space, :968-1007
+        for (i = 0; i < isl_cnt; ++i) {
+            int f = S.isl[i].from, tt = S.isl[i].to;
+            if (f > tt) continue;
+            for (j = f + w.lane; j <= tt + k - 1; j += W::STRIDE) S.strongb[j] = 1;
+        }
+        w.sync();
+        isl_cnt = 0;
+        j = -1;
+        for (i = 0; i < len; ++i) {
+            int sb = S.strongb[i];
+            if (j == -1 && sb) j = i;
+            if (j != -1 && !sb && S.strongb[i - 1]) {
+                S.isl[isl_cnt].from = (short)j;
+                S.isl[isl_cnt].to = (short)(i - 1);
+                ++isl_cnt;
+                j = -1;
+            }
+        }
+        if (j != -1) {
+            S.isl[isl_cnt].from = (short)j;
+            S.isl[isl_cnt].to = (short)(i - 1);
+            ++isl_cnt;
+        }
+        if (isl_cnt == 0) {
+            S.isl[0].from = (short)tstart;
+            S.isl[0].to = (short)(tend + k - 1);
+            isl_cnt = 1;
+        }
+        w.sync();
+
+        // segments, :1009-1046
+        int seg_cnt = 0;
+        {
+            int f0 = S.isl[0].from, t0 = S.isl[0].to;
+            if (f0 > 0) {
+                S.seg[seg_cnt].from = 0;
+                S.seg[seg_cnt].to = (short)(f0 - 1);
+                S.seg[seg_cnt].lanchor = 0;
+                S.seg[seg_cnt].ranchor = (short)(t0 - f0 + 1);
+                ++seg_cnt;
+            }
+            for (i = 0; i < isl_cnt - 1; ++i) {
+                int af = S.isl[i].from, at = S.isl[i].to, bf = S.isl[i + 1].from, bt = S.isl[i + 1].to;
+                S.seg[seg_cnt].from = (short)(at + 1);
+                S.seg[seg_cnt].to = (short)(bf - 1);
+                S.seg[seg_cnt].lanchor = (short)(at - af + 1);
+                S.seg[seg_cnt].ranchor = (short)(bt - bf + 1);
+                ++seg_cnt;
+            }
+            int lf = S.isl[i].from, lt = S.isl[i].to;
+            if (lt < len - 1) {
+                S.seg[seg_cnt].from = (short)(lt + 1);
+                S.seg[seg_cnt].to = (short)len;
+                S.seg[seg_cnt].lanchor = (short)(lt - lf + 1);
+                S.seg[seg_cnt].ranchor = 0;
+                ++seg_cnt;
+            }
+            for (i = 0; i < seg_cnt; ++i) S.seg[i].top2[0] = S.seg[i].top2[1] = -1;
+        }
+        w.sync();
+
+        if (longest == -1) return -1;  // :1107
+        if (longest == kcnt) return 0; // :1110
+
+        for (i = w.lane; i < len; i += W::STRIDE) S.best[i] = -1;
+        w.sync();
+        bad_segment_cnt = 0;
+        if (seg_cnt > 0) {  // :1118-1230
+            rc_search_ctx C;
+            int best_bottleneck = RC_INF;
+            C.best_fix_cnt = -1;
+            C.trial_cnt = 0;
+            C.max_fix_cnt = allowed_fix;
+            for (int si = 0; si < seg_cnt; ++si) {
+                const int sf = S.seg[si].from, st = S.seg[si].to;
+                C.top2a = C.top2b = -1;
+                C.trial_cnt = 0;
+                C.max_fix_cnt = (st - sf + 1) * P.max_fix_per_k / k * 2 + 1;
+                if (C.max_fix_cnt < P.max_fix_per_k) C.max_fix_cnt = P.max_fix_per_k;
+                C.best_bottleneck = -1;
+                if (S.seg[si].lanchor >= S.seg[si].ranchor) {
+                    int extend = (st == len) ? 0 : (k - 1);
+                    int a = sf - k;
+                    if (a < 0) return -1;  // the reference reads seq[-1] here (undefined)
+                    C.dir = 1;
+                    C.start = a + k;
+                    C.to = st + extend;
+                    rc_search(w, S, P, C, rc_anchor(w, S, k, a), trust);
+                } else {
+                    int extend = (sf == 0) ? 0 : (k - 1);
+                    int a = st + 1;
+                    if (a + k > len) return -1;  // undefined in the reference
+                    C.dir = -1;
+                    C.start = a - 1;
+                    C.to = sf - extend;
+                    rc_search(w, S, P, C, rc_anchor(w, S, k, a), trust);
+                }
+                S.seg[si].top2[0] = C.top2a;
+                S.seg[si].top2[1] = C.top2b;
+                w.sync();
+                if (C.best_bottleneck == -1) {
+                    ++bad_segment_cnt;
+                    continue;
+                }
+                if (C.best_bottleneck < best_bottleneck) best_bottleneck = C.best_bottleneck;
+                if (best_bottleneck == -1) break;
+                if (C.trial_cnt > RC_MAX_TRIAL) return -1;
+                total_fix += C.max_fix_cnt;
+            }
+            int best_fix_cnt = C.best_fix_cnt;
+            if (best_bottleneck != -1) {  // :1178-1192
+                best_fix_cnt = 1;
+                for (i = 0; i < seg_cnt; ++i)
+                    if (S.seg[i].top2[1] >= best_bottleneck) best_fix_cnt *= 2;
+            }
+            if (best_bottleneck != -1 && iter == 0 &&
+                rc_less_than_bound(best_bottleneck, strong, P.error_rate))  // :1195
+                force_next = true;
+            if (best_fix_cnt >= 2)
+                return -1;
+            else if (best_fix_cnt <= 0)
+                unfixable = true;
+        }
+        if (total_fix == 0 && force_next) return 0;  // :1231
+        if (total_fix > allowed_fix) unfixable = true;
+        if (!unfixable && !force_next) break;
+        if (trust < 10 && !force_next) return -1;  // :1241
+
+        // lower the thresholds, :1247-1289
+        rc_masked_sorted(w, S);
+        bool has_drop = false;
+        for (i = kcnt - 1; i >= 1; --i) {
+            int vi = S.v[i], vp = S.v[i - 1];
+            if (vi > strong) continue;
+            if (vi > 2 * vp && vi > 10) {
+                has_drop = true;
+                if (vi < strong) break;
+            } else if (vp == 0 && vi >= 5) {
+                has_drop = true;
+                if (vi < strong) break;
+            }
+        }
+        if (has_drop) {
+            ++iter;
+            int vi = S.v[i];
+            trust = rc_bound_i(vi, P.error_rate);
+            strong = vi;
+        } else
+            break;
+    }
+
+    // ---- post filters (positions list in v[]) ----
+    int cnt = 0;
+    for (int i = 0; i < len; ++i) {  // :1296-1303
+        if (S.base[i] == 4 || S.best[i] == -1) continue;
+        S.v[cnt++] = i;
+    }
+    w.sync();
+    const int badq = P.bad_qual;
+    const int q0 = w.qual(0);
+    for (int i = 1; i < cnt; ++i) {  // pairwise veto, :1314-1398
+        const int pi = S.v[i], pp = S.v[i - 1];
+        if (q0 != 0 && (w.qual(pi) <= badq && w.qual(pp) <= badq)) continue;
+        if (pi - pp + 1 <= k) {
+            int min_single = RC_INF, min_double = RC_INF, taga = -1, tagb = -1;
+            const int pprev = i >= 2 ? S.v[i - 2] : -1;
+            const int pnext = i < cnt - 1 ? S.v[i + 1] : -1;
+            int j = pp - k + 1;
+            if (j < 0) j = 0;
+            for (; j < kcnt; ++j) {
+                if (i >= 2 && j <= pprev) continue;
+                if (i < cnt - 1 && j + k - 1 >= pnext) break;
+                if (j + k - 1 >= pi) break;
+                int cj = S.counts[j];
+                if (cj < min_single) {
+                    min_single = cj;
+                    taga = j;
+                }
+            }
+            for (; j < kcnt; ++j) {
+                if (i < cnt - 1 && j + k - 1 >= pnext) break;
+                if (j > pp) break;
+                int cj = S.counts[j];
+                if (cj < min_double) {
+                    min_double = cj;
+                    tagb = j;
+                }
+            }
+            for (; j < kcnt; ++j) {
+                if (i < cnt - 1 && j + k - 1 >= pnext) break;
+                if (j > pi) break;
+                int cj = S.counts[j];
+                if (cj < min_single) {
+                    min_single = cj;
+                    taga = j;
+                }
+            }
+            (void)taga;
+            (void)tagb;
+            if (min_single != RC_INF && min_double != RC_INF && min_single > 1 && min_double > 1 &&
+                min_single > min_double / 2 && min_single < 2 * min_double) {
+                S.best[pi] = -1;
+                S.best[pp] = -1;
+                int jj = i - 2;
+                while (jj >= 0 && S.v[jj + 1] - S.v[jj] + 1 <= k) {
+                    S.best[S.v[jj]] = -1;
+                    --jj;
+                }
+                while (i + 1 < cnt && S.v[i + 1] - S.v[i] + 1 <= k) {
+                    S.best[S.v[i + 1]] = -1;
+                    ++i;
+                }
+                w.sync();
+            }
+        }
+    }
+
+    if (total_fix > 3 && len > 10) {  // end-of-read veto, :1407-1430
+        int tmp = 0;
+        for (int i = 0; i < 10; ++i)
+            if (S.best[i] != -1 && S.base[i] != 4 && w.qual(i) > badq) ++tmp;
+        if (tmp >= 2)
+            for (int i = 0; i < 10; ++i)
+                if (S.base[i] != 4) S.best[i] = -1;
+        w.sync();
+        tmp = 0;
+        for (int i = len - 10; i < len; ++i)
+            if (S.best[i] != -1 && S.base[i] != 4 && w.qual(i) > badq) ++tmp;
+        if (tmp >= 3)
+            for (int i = len - 10; i < len; ++i)
+                if (S.base[i] != 4) S.best[i] = -1;
+        w.sync();
+    }
+
+    if (total_fix >= P.max_fix_per_k) {  // density veto, :1432-1466, weights x2
+        // prefix weights in v[0..len]
+        int acc = 0;
+        S.v[0] = 0;
+        for (int i = 0; i < len; ++i) {
+            if (S.base[i] != 4 && S.best[i] != -1) acc += (w.qual(i) > badq) ? 2 : 1;
+            S.v[i + 1] = acc;
+        }
+        w.sync();
+        int bad = 0;
+        for (int i = w.lane; i < kcnt; i += W::STRIDE)
+            if (S.v[i + k] - S.v[i] > 2 * P.max_fix_per_k) bad = 1;
+        if (w.reduce_add(bad)) return -1;
+    }
+
+    int ret = 0;  // :1468-1479
+    for (int i = w.lane; i < len; i += W::STRIDE)
+        if (S.best[i] != -1) ++ret;
+    ret = w.reduce_add(ret);
+    if (ret == 0 && bad_segment_cnt > 0) return -1;
+    return ret;
+}
+
+// GetKmerInformation (ErrorCorrection.cpp:1567-1602) on the read after `ret` fixes were
+// applied to base[] (so base[i] already holds the corrected base where best[i] != -1).
+// counts[] still holds the pre-correction counts; only windows touching a fix are re-probed.
+template <class W>
+RC_HD void rc_kmer_info(W &w, rc_read_state &S, const rc_run_params &P, int ret, int *l, int *m,
+                        int *h)
+{
+    const int k = P.k;
+    *l = *m = *h = 0;
+    if (S.kcnt <= 0) return;
+    int nvalid = 0;
+    for (int i = w.lane; i < S.kcnt; i += W::STRIDE) {
+        bool valid = true, touched = false;
+        rc_kmer kc;
+        kc.code = 0;
+        kc.inv = -1;
+        for (int j = 0; j < k; ++j) {
+            int b = S.base[i + j];
+            if (b >= 4) valid = false;
+            if (ret > 0 && S.best[i + j] != -1) touched = true;
+            kc.code = (kc.code << 2) | (uint64_t)(b & 3);
+        }
+        int c = 2147483647;
+        if (valid) {
+            c = touched ? w.lookup(kc.code) : S.counts[i];
+            if (c == 0) c = 1;
+            ++nvalid;
+        }
+        S.v[i] = c;
+    }
+    nvalid = w.reduce_add(nvalid);
+    w.sync();
+    if (nvalid == 0) return;
+    w.sort(S.v, S.kcnt);
+    *l = S.v[0];
+    *m = S.v[nvalid / 2];
+    *h = S.v[nvalid - 1];
+}

@@ -1,0 +1,184 @@
+// hostsim.cpp -- lane-serial back end for rc_correct_core.h (TEST HARNESS, CPU only).
+//
+// The build container has no GPU, so the wave-uniform control flow of the correction kernel
+// (rcorrector_amd/csrc/rc_correct_core.h) is instantiated here with STRIDE = 1 and the oracle's
+// table as the probe target, and diffed against the oracle by tests/test_hostsim.py.  Nothing in
+// the product path links this file.
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "../../oracle/rc_oracle.h"
+#include "../../rcorrector_amd/csrc/rc_correct_core.h"
+
+namespace {
+
+struct HostWave {
+    static const int STRIDE = 1;
+    int lane = 0;
+    const rco_table *tab;
+    int k;
+    const char *qualp;
+    std::vector<rc_frame> stack;
+    long probes4 = 0, probes1 = 0, max_sp = 0;
+
+    void sync() {}
+    int reduce_add(int x) { return x; }
+    int get(rc_kmer km)
+    {
+        rco_kmer q;
+        q.code = km.code;
+        q.inv = km.inv;
+        return rco_table_get(tab, &q);
+    }
+    void probe4(rc_kmer km, int dir, int cnt[4])
+    {
+        ++probes4;
+        for (int c = 0; c < 4; ++c) cnt[c] = get(rc_extend(km, k, dir, c));
+    }
+    int probe1(rc_kmer km)
+    {
+        ++probes1;
+        return get(km);
+    }
+    int lookup(uint64_t code)
+    {
+        rc_kmer km;
+        km.code = code;
+        km.inv = -1;
+        return get(km);
+    }
+    void sort(int *a, int n) { std::sort(a, a + n); }
+    int qual(int i) { return (int)(signed char)qualp[i]; }
+    void stack_push(int sp, const rc_frame &f)
+    {
+        if ((int)stack.size() <= sp) stack.resize(sp + 1);
+        stack[sp] = f;
+        if (sp + 1 > max_sp) max_sp = sp + 1;
+    }
+    void stack_top(int idx, rc_frame &f) { f = stack[idx]; }
+    void stack_set_mask(int idx, int mask) { stack[idx].mask = mask; }
+};
+
+struct Buffers {
+    std::vector<unsigned char> base, strongb, polya;
+    std::vector<int> counts, v;
+    std::vector<signed char> path, best;
+    std::vector<rc_island> isl;
+    std::vector<rc_segment> seg;
+    rc_read_state S;
+    explicit Buffers(int cap)
+    {
+        int cap2 = 1;
+        while (cap2 < cap) cap2 <<= 1;
+        base.resize(cap);
+        strongb.resize(cap);
+        polya.resize(cap);
+        counts.resize(cap);
+        v.resize(cap2);
+        path.resize(cap);
+        best.resize(cap);
+        isl.resize(cap / 2 + 2);
+        seg.resize(cap / 2 + 2);
+        S.base = base.data();
+        S.strongb = strongb.data();
+        S.polya = polya.data();
+        S.counts = counts.data();
+        S.v = v.data();
+        S.path = path.data();
+        S.best = best.data();
+        S.isl = isl.data();
+        S.seg = seg.data();
+    }
+};
+
+int base_code(char c)
+{
+    switch (c) {
+    case 'A': return 0;
+    case 'C': return 1;
+    case 'G': return 2;
+    case 'T': return 3;
+    case 'N': return 4;
+    default: return 5;
+    }
+}
+
+void load_read(Buffers &B, const rco_params *p, const rco_table *t, const char *seq)
+{
+    int len = (int)strlen(seq);
+    B.S.len = len;
+    B.S.kcnt = len >= p->k ? len - p->k + 1 : 0;
+    for (int i = 0; i < len; ++i) B.S.base[i] = (unsigned char)base_code(seq[i]);
+    if (B.S.kcnt > 0) rco_kmer_counts(p, t, seq, B.S.counts);  // stands in for the probe kernel
+}
+
+}  // namespace
+
+extern "C" {
+
+struct hostsim_stats {
+    long probes4, probes1, max_stack, reads;
+};
+
+// same contract as rco_correct_batch (oracle/rc_oracle.h)
+void hostsim_correct_batch(const rco_params *p, const rco_table *t, rco_batch *b, hostsim_stats *st)
+{
+    rc_run_params P;
+    P.k = p->k;
+    P.max_fix_per_k = p->max_fix_per_k;
+    P.error_rate = p->error_rate;
+    P.bad_qual = (int)(signed char)p->bad_qual;
+    Buffers B(RC_MAX_READ_LENGTH + 64);
+    HostWave w;
+    w.tab = t;
+    w.k = p->k;
+    const size_t total = b->mode == 1 ? 2 * b->n : b->n;
+    std::vector<int> strong(total), info(total);
+    auto seq_of = [&](size_t r) -> char * { return r < b->n ? b->seq + b->off[r] : b->seq2 + b->off2[r - b->n]; };
+    auto qual_of = [&](size_t r) -> const char * {
+        return r < b->n ? b->qual + b->off[r] : b->qual2 + b->off2[r - b->n];
+    };
+    // threshold kernel
+    for (size_t r = 0; r < total; ++r) {
+        load_read(B, p, t, seq_of(r));
+        int inf;
+        strong[r] = rc_front_end(w, B.S, P, &inf);
+        info[r] = inf;
+    }
+    // correction kernel
+    for (size_t r = 0; r < total; ++r) {
+        char *seq = seq_of(r);
+        load_read(B, p, t, seq);
+        w.qualp = qual_of(r);
+        int pair_t = -1;
+        if (b->mode == 1) {
+            size_t mate = r < b->n ? r + b->n : r - b->n;
+            pair_t = std::min(strong[r], strong[mate]);
+        } else if (b->mode == 2) {
+            pair_t = std::min(strong[r], strong[r ^ 1]);
+        }
+        if (B.S.kcnt > 0 && !(info[r] & 4)) rc_polya_flags(w, B.S, P.k);
+        int ret = rc_correct_read(w, B.S, P, pair_t, strong[r], info[r]);
+        if (ret > 0) {
+            for (int i = 0; i < B.S.len; ++i)
+                if (B.S.best[i] != -1) {
+                    seq[i] = "ACGT"[B.S.best[i]];
+                    B.S.base[i] = (unsigned char)B.S.best[i];
+                }
+        }
+        int l, m, h;
+        rc_kmer_info(w, B.S, P, ret, &l, &m, &h);
+        b->ret[r] = ret;
+        b->l[r] = l;
+        b->m[r] = m;
+        b->h[r] = h;
+    }
+    if (st) {
+        st->probes4 = w.probes4;
+        st->probes1 = w.probes1;
+        st->max_stack = w.max_sp;
+        st->reads = (long)total;
+    }
+}
+}
