@@ -1,0 +1,138 @@
+/*
+ * rcorrector_amd.h -- C ABI of librcorrector_amd.so: the MI355X-native drop-in for Rcorrector's
+ * per-read correction path (stage 3 of run_rcorrector.pl).
+ *
+ * Plain pointers and sizes only; no C++/torch types.  Each entry point names the reference
+ * interface (/root/reference, v1.0.7) it replaces.  INTEGRATION.md shows the binding a maintainer
+ * of the reference would add in main.cpp.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative rc_status; rc_last_error() has the text.
+ *     The library never calls exit() (the reference exits on I/O errors, File.h:69-73).
+ *   - k-mer codes are the reference's KmerCode::GetCode() values (KmerCode.h:39): 2 bits per base,
+ *     A0 C1 G2 T3, first base in the most significant position, k <= 32.
+ *   - a context owns one GPU, its stream, the k-mer table in HBM and all scratch memory.  One
+ *     context per GPU / per host thread; reads shard across contexts with no communication
+ *     (the table is replicated), SURVEY.md §8(e).
+ *   - there is NO CPU fallback: without a usable HIP device rc_create() fails.
+ */
+#ifndef RCORRECTOR_AMD_H
+#define RCORRECTOR_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rc_ctx rc_ctx;
+
+typedef enum {
+    RC_STATUS_OK = 0,
+    RC_STATUS_ARG = -1,   /* bad argument */
+    RC_STATUS_HIP = -2,   /* HIP runtime error */
+    RC_STATUS_IO = -3,    /* file could not be read */
+    RC_STATUS_STATE = -4, /* call sequence error (no table, no run parameters, ...) */
+    RC_STATUS_NOMEM = -5
+} rc_status;
+
+typedef struct {
+    int device;        /* HIP device ordinal */
+    int k;             /* kmerLength, main.cpp:133,200-204 (1..32) */
+    int max_fix_per_k; /* MAX_FIX_PER_K / -maxcorK, main.cpp:159,215-219 */
+} rc_config;
+
+/* replaces: KmerCode kcode(kmerLength); Store kmers;  (main.cpp:140,270) */
+rc_ctx *rc_create(const rc_config *cfg, char *errbuf, size_t errbuf_len);
+void rc_destroy(rc_ctx *ctx);
+const char *rc_last_error(const rc_ctx *ctx);
+
+/* ---- k-mer table (Store.h:17-88) ------------------------------------------------------------ */
+/* replaces the load loop main.cpp:294-308 when the caller has already parsed the dump:
+ * n x Store::Put(code, count) in index order (a later duplicate overrides an earlier one,
+ * Store.h:55).  codes may be forward or canonical; counts <= 1 must already be filtered. */
+int rc_table_build(rc_ctx *ctx, const uint64_t *codes, const int32_t *counts, size_t n);
+/* same with the arrays already in HBM (d_codes is canonicalised in place) */
+int rc_table_build_device(rc_ctx *ctx, uint64_t *d_codes, const int32_t *d_counts, size_t n);
+/* replaces main.cpp:294-308 including the parse: reads a `jellyfish dump` text file
+ * (">COUNT\nKMER\n"), drops count <= 1, builds the table.  *stored = the "Stored %d kmers" value. */
+int rc_table_load_jfdump(rc_ctx *ctx, const char *path, int64_t *stored);
+/* replaces stages 0-2 (run_rcorrector.pl:262-281: jellyfish bc / count / dump -L 2) when the reads
+ * are already in HBM: exact canonical k-mer counts of every read in the arena (reads separated by
+ * NUL bytes), entries with count >= min_count kept. */
+int rc_table_count_reads_device(rc_ctx *ctx, const uint8_t *d_seq, size_t nbytes, int min_count,
+                                int64_t *n_kmers);
+/* Store::GetCount (Store.h:59-66) for n valid k-mer codes (host arrays) */
+int rc_table_lookup(rc_ctx *ctx, const uint64_t *codes, size_t n, int32_t *counts_out);
+/* bytes of HBM held by the table, number of buckets, number of stored entries */
+int rc_table_stats(const rc_ctx *ctx, uint64_t *bytes, uint64_t *buckets, uint64_t *entries);
+
+/* ---- run parameters (globals of main.cpp:17-30) ----------------------------------------------- */
+/* replaces main.cpp:310-358 (ERROR_RATE estimation).  Uses the entries parsed by the last
+ * rc_table_load_jfdump() in file order; the probes run on the GPU, the <=100000 divisions and
+ * the sort on the host in IEEE double exactly as the reference does. */
+int rc_estimate_error_rate(rc_ctx *ctx, double wk, double *rate_out);
+/* replaces GetBadQuality's arithmetic (main.cpp:108-127) given the two histograms gathered over
+ * the first <= 1,000,000 records (first_hist[q] = #reads whose first quality char is q,
+ * last_hist likewise for the last base) */
+char rc_bad_quality_from_hist(const int32_t first_hist[300], const int32_t last_hist[300], int32_t total);
+/* sets ERROR_RATE and badQualityThreshold for subsequent corrections */
+int rc_set_run_params(rc_ctx *ctx, double error_rate, char bad_quality);
+
+/* ---- correction (ErrorCorrection.h:12-28) ------------------------------------------------------ */
+/* Batch in host memory.  Replaces struct _ErrorCorrectionThreadArg + the pthread fan-out of
+ * main.cpp:439-523 / the inline loop main.cpp:368-438: one call = one batch through
+ * ErrorCorrection_Thread (ErrorCorrection.cpp:73-136).
+ *   read i of an arena is the NUL-terminated string at seq + off[i]; off has n+1 entries and
+ *   off[i+1]-off[i] = strlen+1; qual uses the same offsets.
+ *   mode 0: single-end.  mode 1: paired, mate i of arena 1 pairs with mate i of arena 2
+ *   (readBatch/readBatch2).  mode 2: interleaved, reads 2j and 2j+1 are mates.
+ *   Outputs: seq/seq2 corrected in place; ret = ErrorCorrection()'s return value
+ *   (_Read::correction), l/m/h = GetKmerInformation().  In mode 1 entries [n, 2n) of
+ *   ret/l/m/h belong to arena 2. */
+typedef struct {
+    int mode;
+    size_t n;
+    char *seq;
+    const char *qual;
+    const uint32_t *off;
+    char *seq2;
+    const char *qual2;
+    const uint32_t *off2;
+    int32_t *ret, *l, *m, *h;
+} rc_batch;
+int rc_correct_batch(rc_ctx *ctx, rc_batch *b);
+
+/* Batch already resident in HBM (asynchronous on the context's stream; rc_sync() to wait).
+ * In mode 1 the arena holds the n/2 first mates followed by the n/2 second mates. */
+typedef struct {
+    int mode;
+    uint32_t n_reads;
+    uint64_t nbytes;        /* bytes of the arena (sum of strlen+1) */
+    int32_t max_read_len;   /* longest read, bases */
+    uint8_t *d_seq;         /* corrected in place */
+    const uint8_t *d_qual;
+    const uint32_t *d_off;  /* n_reads + 1 */
+    int32_t *d_ret, *d_l, *d_m, *d_h;
+} rc_device_batch;
+int rc_correct_device(rc_ctx *ctx, const rc_device_batch *b);
+/* the hash-probe kernel alone: d_counts[a] = count of the k-mer starting at arena byte a
+ * (ErrorCorrection.cpp:716-723 for every read of the arena) */
+int rc_probe_device(rc_ctx *ctx, const uint8_t *d_seq, uint64_t nbytes, int32_t *d_counts);
+int rc_sync(rc_ctx *ctx);
+
+/* ---- measurement ----------------------------------------------------------------------------- */
+/* with profiling on, every kernel launch is bracketed by HIP events on the context's stream */
+int rc_profile_enable(rc_ctx *ctx, int on);
+/* kernel 0 = probe, 1 = threshold, 2 = correct; accumulated since the last reset */
+int rc_profile_get(rc_ctx *ctx, int kernel, double *total_ms, uint64_t *launches);
+int rc_profile_reset(rc_ctx *ctx);
+
+/* summary counters, struct _summary main.cpp:32-36,73-79 */
+int rc_summary(const rc_ctx *ctx, uint64_t *total_reads, uint64_t *total_corrections);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

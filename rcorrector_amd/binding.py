@@ -1,0 +1,253 @@
+"""ctypes binding of include/rcorrector_amd.h.  No algorithm lives here."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+
+# every function include/rcorrector_amd.h declares (tests check the .so exports all of them)
+ABI_SYMBOLS = [
+    "rc_create", "rc_destroy", "rc_last_error",
+    "rc_table_build", "rc_table_build_device", "rc_table_load_jfdump",
+    "rc_table_count_reads_device", "rc_table_lookup", "rc_table_stats",
+    "rc_estimate_error_rate", "rc_bad_quality_from_hist", "rc_set_run_params",
+    "rc_correct_batch", "rc_correct_device", "rc_probe_device", "rc_sync",
+    "rc_profile_enable", "rc_profile_get", "rc_profile_reset", "rc_summary",
+]
+
+
+class RcorrectorError(RuntimeError):
+    pass
+
+
+def library_path():
+    return os.path.join(HERE, "librcorrector_amd.so")
+
+
+def build_library(quiet=True):
+    """Compile the HIP sources for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    subprocess.run(["make", "-C", CSRC, "-j4", "all"], check=True,
+                   stdout=subprocess.DEVNULL if quiet else None)
+    return library_path()
+
+
+class _Config(C.Structure):
+    _fields_ = [("device", C.c_int), ("k", C.c_int), ("max_fix_per_k", C.c_int)]
+
+
+class _Batch(C.Structure):
+    _fields_ = [("mode", C.c_int), ("n", C.c_size_t),
+                ("seq", C.c_void_p), ("qual", C.c_void_p), ("off", C.c_void_p),
+                ("seq2", C.c_void_p), ("qual2", C.c_void_p), ("off2", C.c_void_p),
+                ("ret", C.c_void_p), ("l", C.c_void_p), ("m", C.c_void_p), ("h", C.c_void_p)]
+
+
+class _DeviceBatch(C.Structure):
+    _fields_ = [("mode", C.c_int), ("n_reads", C.c_uint32), ("nbytes", C.c_uint64),
+                ("max_read_len", C.c_int32),
+                ("d_seq", C.c_void_p), ("d_qual", C.c_void_p), ("d_off", C.c_void_p),
+                ("d_ret", C.c_void_p), ("d_l", C.c_void_p), ("d_m", C.c_void_p), ("d_h", C.c_void_p)]
+
+
+_lib = None
+
+
+def load_library():
+    """Loads librcorrector_amd.so; raises RcorrectorError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise RcorrectorError(
+            "%s not found: build the HIP extension first (python -c 'import __graft_entry__ as g; "
+            "g.build()' or make -C rcorrector_amd/csrc).  There is no CPU fallback." % path)
+    # torch wheels bundle their own copy of the HIP runtime (same soname).  If torch is going to be
+    # used in this process (bench.py / tests use it for device tensors and torch.distributed) it
+    # has to be loaded FIRST so that exactly one HIP runtime is live; a C/C++ host links ROCm's.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is optional for the binding
+        pass
+    try:
+        L = C.CDLL(path)
+    except OSError as e:  # pragma: no cover
+        raise RcorrectorError("cannot load %s: %s" % (path, e))
+    vp, sz = C.c_void_p, C.c_size_t
+    L.rc_create.restype = vp
+    L.rc_create.argtypes = [C.POINTER(_Config), C.c_char_p, sz]
+    L.rc_destroy.argtypes = [vp]
+    L.rc_last_error.restype = C.c_char_p
+    L.rc_last_error.argtypes = [vp]
+    L.rc_table_build.argtypes = [vp, vp, vp, sz]
+    L.rc_table_build_device.argtypes = [vp, vp, vp, sz]
+    L.rc_table_load_jfdump.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64)]
+    L.rc_table_count_reads_device.argtypes = [vp, vp, sz, C.c_int, C.POINTER(C.c_int64)]
+    L.rc_table_lookup.argtypes = [vp, vp, sz, vp]
+    L.rc_table_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.rc_estimate_error_rate.argtypes = [vp, C.c_double, C.POINTER(C.c_double)]
+    L.rc_bad_quality_from_hist.restype = C.c_char
+    L.rc_bad_quality_from_hist.argtypes = [vp, vp, C.c_int32]
+    L.rc_set_run_params.argtypes = [vp, C.c_double, C.c_char]
+    L.rc_correct_batch.argtypes = [vp, C.POINTER(_Batch)]
+    L.rc_correct_device.argtypes = [vp, C.POINTER(_DeviceBatch)]
+    L.rc_probe_device.argtypes = [vp, vp, C.c_uint64, vp]
+    L.rc_sync.argtypes = [vp]
+    L.rc_profile_enable.argtypes = [vp, C.c_int]
+    L.rc_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    L.rc_profile_reset.argtypes = [vp]
+    L.rc_summary.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    _lib = L
+    return L
+
+
+def pack_reads(seqs):
+    """list of bytes -> (uint8 arena with a NUL after every read, uint32 offsets[n+1])."""
+    lens = np.fromiter((len(s) for s in seqs), dtype=np.int64, count=len(seqs))
+    off = np.zeros(len(seqs) + 1, dtype=np.uint32)
+    np.cumsum(lens + 1, out=off[1:])
+    if seqs:
+        arena = np.frombuffer(b"\0".join(seqs) + b"\0", dtype=np.uint8).copy()
+    else:
+        arena = np.zeros(0, np.uint8)
+    return arena, off
+
+
+def unpack_reads(arena, off):
+    b = arena.tobytes()
+    return [b[off[i]:off[i + 1] - 1] for i in range(len(off) - 1)]
+
+
+def _ptr(x):
+    """device/host pointer of a numpy array, a torch tensor or a raw integer address."""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return x
+    if isinstance(x, np.ndarray):
+        return x.ctypes.data
+    if hasattr(x, "data_ptr"):
+        return x.data_ptr()
+    raise TypeError("cannot take a pointer of %r" % type(x))
+
+
+class Context:
+    """One GPU: stream, k-mer table in HBM, scratch.  Mirrors the objects main.cpp sets up
+    (KmerCode kcode / Store kmers / globals, main.cpp:17-30,140,270)."""
+
+    def __init__(self, k=23, max_fix_per_k=4, device=0):
+        self._L = load_library()
+        cfg = _Config(device, k, max_fix_per_k)
+        err = C.create_string_buffer(512)
+        self._h = self._L.rc_create(C.byref(cfg), err, 512)
+        if not self._h:
+            raise RcorrectorError(err.value.decode() or "rc_create failed")
+        self.k = k
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.rc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise RcorrectorError("rc=%d: %s" % (rc, self._L.rc_last_error(self._h).decode()))
+
+    # ---- table ----
+    def table_build(self, codes, counts):
+        codes = np.ascontiguousarray(codes, dtype=np.uint64)
+        counts = np.ascontiguousarray(counts, dtype=np.int32)
+        self._ck(self._L.rc_table_build(self._h, codes.ctypes.data, counts.ctypes.data, len(codes)))
+
+    def table_build_device(self, d_codes, d_counts, n):
+        self._ck(self._L.rc_table_build_device(self._h, _ptr(d_codes), _ptr(d_counts), n))
+
+    def load_jfdump(self, path):
+        stored = C.c_int64(0)
+        self._ck(self._L.rc_table_load_jfdump(self._h, os.fsencode(path), C.byref(stored)))
+        return stored.value
+
+    def count_reads_device(self, d_seq, nbytes, min_count=2):
+        n = C.c_int64(0)
+        self._ck(self._L.rc_table_count_reads_device(self._h, _ptr(d_seq), nbytes, min_count, C.byref(n)))
+        return n.value
+
+    def lookup(self, codes):
+        codes = np.ascontiguousarray(codes, dtype=np.uint64)
+        out = np.zeros(len(codes), dtype=np.int32)
+        self._ck(self._L.rc_table_lookup(self._h, codes.ctypes.data, len(codes), out.ctypes.data))
+        return out
+
+    def table_stats(self):
+        b, n, e = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        self._ck(self._L.rc_table_stats(self._h, C.byref(b), C.byref(n), C.byref(e)))
+        return {"bytes": b.value, "buckets": n.value, "entries": e.value}
+
+    # ---- run parameters ----
+    def estimate_error_rate(self, wk=0.95):
+        r = C.c_double(0)
+        self._ck(self._L.rc_estimate_error_rate(self._h, wk, C.byref(r)))
+        return r.value
+
+    def bad_quality_from_hist(self, first_hist, last_hist, total):
+        fh = np.ascontiguousarray(first_hist, dtype=np.int32)
+        lh = np.ascontiguousarray(last_hist, dtype=np.int32)
+        return self._L.rc_bad_quality_from_hist(fh.ctypes.data, lh.ctypes.data, int(total))
+
+    def set_run_params(self, error_rate, bad_quality):
+        if isinstance(bad_quality, int):
+            bad_quality = bytes([bad_quality & 0xFF])
+        self._ck(self._L.rc_set_run_params(self._h, error_rate, bad_quality))
+
+    # ---- correction ----
+    def correct_batch(self, mode, seq, qual, off, seq2=None, qual2=None, off2=None):
+        """Host-buffer batch (rc_correct_batch).  seq arenas are corrected IN PLACE.
+        Returns (ret, l, m, h)."""
+        n = len(off) - 1
+        total = 2 * n if mode == 1 else n
+        res = [np.zeros(total, dtype=np.int32) for _ in range(4)]
+        b = _Batch()
+        b.mode, b.n = mode, n
+        b.seq, b.qual, b.off = seq.ctypes.data, qual.ctypes.data, off.ctypes.data
+        if mode == 1:
+            b.seq2, b.qual2, b.off2 = seq2.ctypes.data, qual2.ctypes.data, off2.ctypes.data
+        b.ret, b.l, b.m, b.h = (r.ctypes.data for r in res)
+        self._ck(self._L.rc_correct_batch(self._h, C.byref(b)))
+        return tuple(res)
+
+    def correct_device(self, mode, n_reads, nbytes, max_read_len, d_seq, d_qual, d_off, d_ret, d_l, d_m, d_h):
+        b = _DeviceBatch(mode, n_reads, nbytes, max_read_len, _ptr(d_seq), _ptr(d_qual), _ptr(d_off),
+                         _ptr(d_ret), _ptr(d_l), _ptr(d_m), _ptr(d_h))
+        self._ck(self._L.rc_correct_device(self._h, C.byref(b)))
+
+    def probe_device(self, d_seq, nbytes, d_counts):
+        self._ck(self._L.rc_probe_device(self._h, _ptr(d_seq), nbytes, _ptr(d_counts)))
+
+    def sync(self):
+        self._ck(self._L.rc_sync(self._h))
+
+    # ---- measurement ----
+    def profile(self, on=True):
+        self._ck(self._L.rc_profile_enable(self._h, 1 if on else 0))
+
+    def profile_reset(self):
+        self._ck(self._L.rc_profile_reset(self._h))
+
+    def profile_get(self, kernel):
+        ms, n = C.c_double(0), C.c_uint64(0)
+        self._ck(self._L.rc_profile_get(self._h, kernel, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def summary(self):
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self._ck(self._L.rc_summary(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value

@@ -1,0 +1,524 @@
+// rc_api.hip -- the C ABI of librcorrector_amd.so (include/rcorrector_amd.h): context, table
+// load, run-parameter estimation and the batch entry points.  Host code only drives HIP; every
+// per-read computation happens in the kernels of rc_table.hip / rc_correct.hip.  There is no CPU
+// fallback anywhere in this library.
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/rcorrector_amd.h"
+#include "rc_internal.h"
+
+// parsed dump kept between rc_table_load_jfdump() and rc_estimate_error_rate()
+struct rc_dump_cache {
+    std::vector<uint64_t> codes;  // forward code of every entry (file order), main.cpp:326-328
+    std::vector<int8_t> inv_mid;  // 1 if the entry holds a non-ACGT letter before its last base
+    int load_state_invalid = 0;   // validity of the KmerCode object the load pass leaves behind
+    bool valid = false;
+};
+
+struct rc_ctx_full : rc_ctx {
+    rc_dump_cache dump;
+    uint64_t total_reads = 0, total_corrections = 0;
+};
+
+static thread_local char g_create_err[512];
+
+void rc_set_error(rc_ctx *ctx, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(ctx ? ctx->err : g_create_err, 512, fmt, ap);
+    va_end(ap);
+}
+
+int rc_dbuf_reserve(rc_ctx *ctx, rc_dbuf *b, size_t bytes)
+{
+    if (bytes <= b->bytes) return RC_OK;
+    if (b->p) {
+        RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(b->p);
+        b->p = nullptr;
+        b->bytes = 0;
+    }
+    size_t want = bytes + bytes / 8 + 256;
+    RC_CHECK_HIP(ctx, hipMalloc(&b->p, want));
+    b->bytes = want;
+    return RC_OK;
+}
+
+rc_table_view rc_view(const rc_ctx *ctx)
+{
+    rc_table_view v;
+    v.buckets = ctx->d_buckets;
+    v.home_mask = ctx->home_mask;
+    v.nbuckets_alloc = ctx->nb_alloc;
+    return v;
+}
+
+void rc_timer_begin(rc_ctx *ctx)
+{
+    if (ctx->profile) (void)hipEventRecord(ctx->ev0, ctx->stream);
+}
+
+void rc_timer_end(rc_ctx *ctx, int which)
+{
+    if (!ctx->profile) return;
+    (void)hipEventRecord(ctx->ev1, ctx->stream);
+    (void)hipEventSynchronize(ctx->ev1);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+    ctx->timers[which].ms += ms;
+    ctx->timers[which].launches += 1;
+}
+
+extern "C" {
+
+rc_ctx *rc_create(const rc_config *cfg, char *errbuf, size_t errbuf_len)
+{
+    auto fail = [&](const char *msg) -> rc_ctx * {
+        if (errbuf && errbuf_len) snprintf(errbuf, errbuf_len, "%s", msg);
+        return nullptr;
+    };
+    if (!cfg) return fail("rc_create: null config");
+    if (cfg->k < 1 || cfg->k > 32) return fail("rc_create: k must be in 1..32 (run_rcorrector.pl:225-228)");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) return fail("rc_create: no HIP device available (this library has no CPU fallback)");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail("rc_create: device ordinal out of range");
+    if (hipSetDevice(cfg->device) != hipSuccess) return fail("rc_create: hipSetDevice failed");
+    rc_ctx_full *ctx = new (std::nothrow) rc_ctx_full();
+    if (!ctx) return fail("rc_create: out of memory");
+    ctx->err[0] = 0;
+    ctx->device = cfg->device;
+    ctx->k = cfg->k;
+    ctx->P.k = cfg->k;
+    ctx->P.max_fix_per_k = cfg->max_fix_per_k > 0 ? cfg->max_fix_per_k : 4;
+    ctx->P.error_rate = 0.01;
+    ctx->P.bad_qual = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
+        hipMalloc(&ctx->work.p, 256) != hipSuccess) {
+        delete ctx;
+        return fail("rc_create: could not create stream/events");
+    }
+    ctx->work.bytes = 256;
+    return ctx;
+}
+
+void rc_destroy(rc_ctx *c)
+{
+    if (!c) return;
+    rc_ctx_full *ctx = static_cast<rc_ctx_full *>(c);
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    rc_dbuf *bufs[] = {&ctx->counts, &ctx->strong, &ctx->info, &ctx->stack, &ctx->work,
+                       &ctx->h_seq, &ctx->h_qual, &ctx->h_off, &ctx->h_res};
+    for (rc_dbuf *b : bufs)
+        if (b->p) (void)hipFree(b->p);
+    if (ctx->d_buckets) (void)hipFree(ctx->d_buckets);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *rc_last_error(const rc_ctx *ctx) { return ctx ? ctx->err : g_create_err; }
+
+// ---- table ---------------------------------------------------------------------------------
+int rc_table_build_device(rc_ctx *ctx, uint64_t *d_codes, const int32_t *d_counts, size_t n)
+{
+    if (!ctx) return RC_ERR_ARG;
+    RC_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = rc_launch_canonicalize(ctx, d_codes, n);
+    if (rc) return rc;
+    return rc_build_table_from_device_pairs(ctx, d_codes, d_counts, n);
+}
+
+int rc_table_build(rc_ctx *ctx, const uint64_t *codes, const int32_t *counts, size_t n)
+{
+    if (!ctx || (n && (!codes || !counts))) return RC_ERR_ARG;
+    RC_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    uint64_t *d_codes = nullptr;
+    int32_t *d_counts = nullptr;
+    if (n) {
+        RC_CHECK_HIP(ctx, hipMalloc(&d_codes, n * 8));
+        RC_CHECK_HIP(ctx, hipMalloc(&d_counts, n * 4));
+        RC_CHECK_HIP(ctx, hipMemcpyAsync(d_codes, codes, n * 8, hipMemcpyHostToDevice, ctx->stream));
+        RC_CHECK_HIP(ctx, hipMemcpyAsync(d_counts, counts, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    int rc = rc_table_build_device(ctx, d_codes, d_counts, n);
+    if (d_codes) (void)hipFree(d_codes);
+    if (d_counts) (void)hipFree(d_counts);
+    return rc;
+}
+
+// main.cpp:294-308.  Tokens are whitespace separated (fscanf "%s"); the first of a pair is
+// ">COUNT" (atoi of the text after the first character), the second the k-mer, pushed through
+// KmerCode::Append character by character (only the last k characters survive the mask).
+int rc_table_load_jfdump(rc_ctx *c, const char *path, int64_t *stored)
+{
+    if (!c || !path) return RC_ERR_ARG;
+    rc_ctx_full *ctx = static_cast<rc_ctx_full *>(c);
+    RC_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    FILE *fp = fopen(path, "rb");
+    if (!fp) {
+        rc_set_error(ctx, "Could not open file %s", path);
+        return RC_ERR_IO;
+    }
+    fseek(fp, 0, SEEK_END);
+    long sz = ftell(fp);
+    fseek(fp, 0, SEEK_SET);
+    std::vector<char> buf((size_t)sz + 1);
+    if (sz > 0 && fread(buf.data(), 1, (size_t)sz, fp) != (size_t)sz) {
+        fclose(fp);
+        rc_set_error(ctx, "short read on %s", path);
+        return RC_ERR_IO;
+    }
+    fclose(fp);
+    buf[(size_t)sz] = 0;
+
+    const int k = ctx->k;
+    const uint64_t mask = rc_kmer_mask(k);
+    rc_dump_cache &D = ctx->dump;
+    D.codes.clear();
+    D.inv_mid.clear();
+    D.load_state_invalid = 0;
+    std::vector<uint64_t> put_codes;
+    std::vector<int32_t> put_counts;
+    const char *p = buf.data(), *end = buf.data() + sz;
+    auto is_ws = [](char ch) { return ch == ' ' || ch == '\n' || ch == '\t' || ch == '\r' || ch == '\f' || ch == '\v'; };
+    int64_t accepted = 0;
+    while (true) {
+        while (p < end && is_ws(*p)) ++p;
+        if (p >= end) break;
+        const char *t0 = p;
+        while (p < end && !is_ws(*p)) ++p;
+        // atoi(&token[1])
+        long long cnt = 0;
+        {
+            const char *q = t0 + 1;
+            bool neg = false;
+            if (q < p && (*q == '-' || *q == '+')) {
+                neg = *q == '-';
+                ++q;
+            }
+            while (q < p && *q >= '0' && *q <= '9') {
+                cnt = cnt * 10 + (*q - '0');
+                if (cnt > 0x7fffffffLL) cnt = 0x7fffffffLL;
+                ++q;
+            }
+            if (neg) cnt = -cnt;
+        }
+        while (p < end && is_ws(*p)) ++p;
+        const char *k0 = p;
+        while (p < end && !is_ws(*p)) ++p;
+        uint64_t code = 0;
+        int inv = -1;
+        for (const char *q = k0; q < p; ++q) {
+            int b;
+            switch (*q) {
+            case 'A': b = 0; break;
+            case 'C': b = 1; break;
+            case 'G': b = 2; break;
+            case 'T': b = 3; break;
+            default: b = -1;
+            }
+            if (inv != -1) ++inv;
+            code = ((code << 2) & mask) | (uint64_t)(b & 3);
+            if (b == -1) inv = 0;
+            if (inv >= k) inv = -1;
+        }
+        D.codes.push_back(code);
+        D.inv_mid.push_back(inv > 0 ? 1 : 0);
+        if (cnt <= 1) continue;
+        D.load_state_invalid = (inv != -1);
+        ++accepted;
+        if (inv == -1) {  // Store::Put ignores invalid k-mers, Store.h:53-54
+            put_codes.push_back(code);
+            put_counts.push_back((int32_t)cnt);
+        }
+    }
+    D.valid = true;
+    if (stored) *stored = accepted;
+    return rc_table_build(ctx, put_codes.data(), put_counts.data(), put_codes.size());
+}
+
+int rc_table_count_reads_device(rc_ctx *ctx, const uint8_t *d_seq, size_t nbytes, int min_count, int64_t *n_kmers)
+{
+    if (!ctx || !d_seq) return RC_ERR_ARG;
+    RC_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    return rc_count_reads(ctx, d_seq, nbytes, min_count, n_kmers);
+}
+
+int rc_table_lookup(rc_ctx *ctx, const uint64_t *codes, size_t n, int32_t *out)
+{
+    if (!ctx || (n && (!codes || !out))) return RC_ERR_ARG;
+    if (!ctx->d_buckets) {
+        rc_set_error(ctx, "lookup: no k-mer table loaded");
+        return RC_ERR_STATE;
+    }
+    if (n == 0) return RC_OK;
+    RC_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    uint64_t *d_codes = nullptr;
+    int32_t *d_out = nullptr;
+    RC_CHECK_HIP(ctx, hipMalloc(&d_codes, n * 8));
+    RC_CHECK_HIP(ctx, hipMalloc(&d_out, n * 4));
+    RC_CHECK_HIP(ctx, hipMemcpyAsync(d_codes, codes, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    int rc = rc_launch_lookup(ctx, d_codes, n, d_out);
+    if (rc == RC_OK) {
+        RC_CHECK_HIP(ctx, hipMemcpyAsync(out, d_out, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    (void)hipFree(d_codes);
+    (void)hipFree(d_out);
+    return rc;
+}
+
+int rc_table_stats(const rc_ctx *ctx, uint64_t *bytes, uint64_t *buckets, uint64_t *entries)
+{
+    if (!ctx) return RC_ERR_ARG;
+    if (bytes) *bytes = ctx->table_bytes;
+    if (buckets) *buckets = ctx->nb_alloc;
+    if (entries) *entries = ctx->n_entries;
+    return RC_OK;
+}
+
+// ---- run parameters --------------------------------------------------------------------------
+static int cmp_double(const void *a, const void *b)
+{
+    double d = *(const double *)a - *(const double *)b;  // CompDouble, main.cpp:39-48
+    return d > 0 ? 1 : (d < 0 ? -1 : 0);
+}
+
+// main.cpp:310-358
+int rc_estimate_error_rate(rc_ctx *c, double wk, double *rate_out)
+{
+    if (!c || !rate_out) return RC_ERR_ARG;
+    rc_ctx_full *ctx = static_cast<rc_ctx_full *>(c);
+    if (!ctx->dump.valid || !ctx->d_buckets) {
+        rc_set_error(ctx, "estimate_error_rate: call rc_table_load_jfdump first");
+        return RC_ERR_STATE;
+    }
+    RC_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    const rc_dump_cache &D = ctx->dump;
+    const size_t n = D.codes.size();
+    std::vector<int32_t> mx2(2 * n);
+    if (n) {
+        uint64_t *d_codes = nullptr;
+        int32_t *d_out = nullptr;
+        RC_CHECK_HIP(ctx, hipMalloc(&d_codes, n * 8));
+        RC_CHECK_HIP(ctx, hipMalloc(&d_out, n * 8));
+        RC_CHECK_HIP(ctx, hipMemcpyAsync(d_codes, D.codes.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
+        int rc = rc_launch_last_base_variants(ctx, d_codes, n, d_out);
+        if (rc) return rc;
+        RC_CHECK_HIP(ctx, hipMemcpyAsync(mx2.data(), d_out, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(d_codes);
+        (void)hipFree(d_out);
+    }
+    const int rate_size = 100000;
+    std::vector<double> store((size_t)rate_size + 2, 0.0);
+    double *r = store.data() + 1;  // r[-1] readable, as in the reference when k == 0
+    int cnt = 0;
+    bool state_invalid = D.load_state_invalid != 0;  // the IsValid() test at main.cpp:323
+    for (size_t i = 0; i < n && cnt < rate_size; ++i) {
+        if (state_invalid) continue;
+        if (D.inv_mid[i]) {  // this entry leaves an invalid KmerCode behind: everything after is skipped
+            state_invalid = true;
+            continue;
+        }
+        const int mx = mx2[2 * i], second = mx2[2 * i + 1];
+        if (mx < 1000) continue;
+        r[cnt++] = (double)second / (double)mx;
+    }
+    qsort(r, (size_t)cnt, sizeof(double), cmp_double);
+    r[cnt] = r[cnt - 1];
+    double rate = r[(int)(cnt * wk)];
+    if (rate == 0 || cnt < 100) rate = 0.01;
+    *rate_out = rate;
+    return RC_OK;
+}
+
+char rc_bad_quality_from_hist(const int32_t first_hist[300], const int32_t last_hist[300], int32_t total)
+{
+    int i, cnt = 0, t1, t2;  // main.cpp:108-127
+    for (i = 0; i < 300; ++i) {
+        cnt += first_hist[i];
+        if (cnt > total * 0.05) break;
+    }
+    t1 = i - 1;
+    cnt = 0;
+    for (i = 0; i < 300; ++i) {
+        cnt += last_hist[i];
+        if (cnt > total * 0.05) break;
+    }
+    t2 = i;
+    return (char)(t2 < t1 ? t2 : t1);
+}
+
+int rc_set_run_params(rc_ctx *ctx, double error_rate, char bad_quality)
+{
+    if (!ctx) return RC_ERR_ARG;
+    ctx->P.error_rate = error_rate;
+    ctx->P.bad_qual = (int)(signed char)bad_quality;
+    ctx->params_set = true;
+    return RC_OK;
+}
+
+// ---- correction ------------------------------------------------------------------------------
+int rc_probe_device(rc_ctx *ctx, const uint8_t *d_seq, uint64_t nbytes, int32_t *d_counts)
+{
+    if (!ctx || !d_seq || !d_counts) return RC_ERR_ARG;
+    RC_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    return rc_launch_probe(ctx, d_seq, (size_t)nbytes, d_counts);
+}
+
+int rc_correct_device(rc_ctx *ctx, const rc_device_batch *b)
+{
+    if (!ctx || !b) return RC_ERR_ARG;
+    if (b->n_reads == 0) return RC_OK;
+    if (b->mode < 0 || b->mode > 2 || !b->d_seq || !b->d_qual || !b->d_off || !b->d_ret || !b->d_l || !b->d_m || !b->d_h) {
+        rc_set_error(ctx, "correct_device: bad batch descriptor");
+        return RC_ERR_ARG;
+    }
+    if (b->nbytes >= (1ull << 32)) {
+        rc_set_error(ctx, "correct_device: arena of %llu bytes exceeds the 4 GiB batch limit", (unsigned long long)b->nbytes);
+        return RC_ERR_ARG;
+    }
+    RC_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = rc_dbuf_reserve(ctx, &ctx->counts, (size_t)b->nbytes * 4 + 256))) return rc;
+    if ((rc = rc_dbuf_reserve(ctx, &ctx->strong, (size_t)b->n_reads * 4 + 256))) return rc;
+    if ((rc = rc_dbuf_reserve(ctx, &ctx->info, (size_t)b->n_reads * 4 + 256))) return rc;
+    rc_device_batch_args a;
+    a.mode = b->mode;
+    a.n = b->n_reads;
+    a.seq = b->d_seq;
+    a.qual = b->d_qual;
+    a.off = b->d_off;
+    a.ret = b->d_ret;
+    a.l = b->d_l;
+    a.m = b->d_m;
+    a.h = b->d_h;
+    a.max_len = b->max_read_len;
+    if ((rc = rc_launch_probe(ctx, b->d_seq, (size_t)b->nbytes, (int32_t *)ctx->counts.p))) return rc;
+    if ((rc = rc_launch_threshold(ctx, a))) return rc;
+    if ((rc = rc_launch_correct(ctx, a))) return rc;
+    return RC_OK;
+}
+
+int rc_sync(rc_ctx *ctx)
+{
+    if (!ctx) return RC_ERR_ARG;
+    RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RC_OK;
+}
+
+int rc_correct_batch(rc_ctx *c, rc_batch *b)
+{
+    if (!c || !b) return RC_ERR_ARG;
+    rc_ctx_full *ctx = static_cast<rc_ctx_full *>(c);
+    if (b->n == 0) return RC_OK;
+    if (b->mode < 0 || b->mode > 2 || !b->seq || !b->qual || !b->off || !b->ret || !b->l || !b->m || !b->h ||
+        (b->mode == 1 && (!b->seq2 || !b->qual2 || !b->off2))) {
+        rc_set_error(ctx, "correct_batch: bad batch descriptor");
+        return RC_ERR_ARG;
+    }
+    RC_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t n1 = b->n;
+    const size_t bytes1 = b->off[n1], bytes2 = b->mode == 1 ? b->off2[n1] : 0;
+    const size_t total_reads = b->mode == 1 ? 2 * n1 : n1;
+    const size_t nbytes = bytes1 + bytes2;
+    if (nbytes >= (1ull << 32) || total_reads >= (1ull << 32)) {
+        rc_set_error(ctx, "correct_batch: batch too large (split it)");
+        return RC_ERR_ARG;
+    }
+    std::vector<uint32_t> off(total_reads + 1);
+    int max_len = 0;
+    for (size_t i = 0; i <= n1; ++i) off[i] = b->off[i];
+    for (size_t i = 0; i < n1; ++i) max_len = std::max(max_len, (int)(b->off[i + 1] - b->off[i]) - 1);
+    if (b->mode == 1) {
+        for (size_t i = 0; i <= n1; ++i) off[n1 + i] = (uint32_t)bytes1 + b->off2[i];
+        for (size_t i = 0; i < n1; ++i) max_len = std::max(max_len, (int)(b->off2[i + 1] - b->off2[i]) - 1);
+    }
+    int rc;
+    if ((rc = rc_dbuf_reserve(ctx, &ctx->h_seq, nbytes + 64))) return rc;
+    if ((rc = rc_dbuf_reserve(ctx, &ctx->h_qual, nbytes + 64))) return rc;
+    if ((rc = rc_dbuf_reserve(ctx, &ctx->h_off, (total_reads + 1) * 4))) return rc;
+    if ((rc = rc_dbuf_reserve(ctx, &ctx->h_res, total_reads * 16))) return rc;
+    uint8_t *d_seq = (uint8_t *)ctx->h_seq.p, *d_qual = (uint8_t *)ctx->h_qual.p;
+    RC_CHECK_HIP(ctx, hipMemcpyAsync(d_seq, b->seq, bytes1, hipMemcpyHostToDevice, ctx->stream));
+    RC_CHECK_HIP(ctx, hipMemcpyAsync(d_qual, b->qual, bytes1, hipMemcpyHostToDevice, ctx->stream));
+    if (b->mode == 1) {
+        RC_CHECK_HIP(ctx, hipMemcpyAsync(d_seq + bytes1, b->seq2, bytes2, hipMemcpyHostToDevice, ctx->stream));
+        RC_CHECK_HIP(ctx, hipMemcpyAsync(d_qual + bytes1, b->qual2, bytes2, hipMemcpyHostToDevice, ctx->stream));
+    }
+    RC_CHECK_HIP(ctx, hipMemcpyAsync(ctx->h_off.p, off.data(), (total_reads + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    int32_t *d_res = (int32_t *)ctx->h_res.p;
+    rc_device_batch db;
+    db.mode = b->mode;
+    db.n_reads = (uint32_t)total_reads;
+    db.nbytes = nbytes;
+    db.max_read_len = max_len;
+    db.d_seq = d_seq;
+    db.d_qual = d_qual;
+    db.d_off = (const uint32_t *)ctx->h_off.p;
+    db.d_ret = d_res;
+    db.d_l = d_res + total_reads;
+    db.d_m = d_res + 2 * total_reads;
+    db.d_h = d_res + 3 * total_reads;
+    if ((rc = rc_correct_device(ctx, &db))) return rc;
+    RC_CHECK_HIP(ctx, hipMemcpyAsync(b->seq, d_seq, bytes1, hipMemcpyDeviceToHost, ctx->stream));
+    if (b->mode == 1) RC_CHECK_HIP(ctx, hipMemcpyAsync(b->seq2, d_seq + bytes1, bytes2, hipMemcpyDeviceToHost, ctx->stream));
+    RC_CHECK_HIP(ctx, hipMemcpyAsync(b->ret, db.d_ret, total_reads * 4, hipMemcpyDeviceToHost, ctx->stream));
+    RC_CHECK_HIP(ctx, hipMemcpyAsync(b->l, db.d_l, total_reads * 4, hipMemcpyDeviceToHost, ctx->stream));
+    RC_CHECK_HIP(ctx, hipMemcpyAsync(b->m, db.d_m, total_reads * 4, hipMemcpyDeviceToHost, ctx->stream));
+    RC_CHECK_HIP(ctx, hipMemcpyAsync(b->h, db.d_h, total_reads * 4, hipMemcpyDeviceToHost, ctx->stream));
+    RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < total_reads; ++i) {  // UpdateSummary, main.cpp:73-79
+        ++ctx->total_reads;
+        if (b->ret[i] > 0) ctx->total_corrections += (uint64_t)b->ret[i];
+    }
+    return RC_OK;
+}
+
+// ---- measurement -----------------------------------------------------------------------------
+int rc_profile_enable(rc_ctx *ctx, int on)
+{
+    if (!ctx) return RC_ERR_ARG;
+    ctx->profile = on != 0;
+    return RC_OK;
+}
+
+int rc_profile_get(rc_ctx *ctx, int kernel, double *total_ms, uint64_t *launches)
+{
+    if (!ctx || kernel < 0 || kernel >= RC_T_COUNT) return RC_ERR_ARG;
+    if (total_ms) *total_ms = ctx->timers[kernel].ms;
+    if (launches) *launches = ctx->timers[kernel].launches;
+    return RC_OK;
+}
+
+int rc_profile_reset(rc_ctx *ctx)
+{
+    if (!ctx) return RC_ERR_ARG;
+    for (auto &t : ctx->timers) t = rc_kernel_timer();
+    return RC_OK;
+}
+
+int rc_summary(const rc_ctx *c, uint64_t *total_reads, uint64_t *total_corrections)
+{
+    if (!c) return RC_ERR_ARG;
+    const rc_ctx_full *ctx = static_cast<const rc_ctx_full *>(c);
+    if (total_reads) *total_reads = ctx->total_reads;
+    if (total_corrections) *total_corrections = ctx->total_corrections;
+    return RC_OK;
+}
+
+}  // extern "C"

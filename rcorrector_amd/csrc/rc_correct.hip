@@ -1,0 +1,359 @@
+// rc_correct.hip -- device back end of rc_correct_core.h and the two per-read kernels:
+//   k_threshold (K2): GetStrongTrustedThreshold for every read   (ErrorCorrection.cpp:1482-1565)
+//   k_correct   (K3): ErrorCorrection + GetKmerInformation        (ErrorCorrection.cpp:682-1480,
+//                     :1567-1602), i.e. the body of ErrorCorrection_Thread (:73-136)
+// One 64-lane wavefront (= one workgroup) per read; persistent waves pull read indices from an
+// atomic counter, which is the reference's mutex-protected batchUsed counter (:87-90) and
+// absorbs the heavy tail of the search.  Per-read state is carved out of dynamic LDS.
+#include "rc_internal.h"
+#include "rc_device.h"
+
+struct DevWave {
+    static const int STRIDE = 64;
+    int lane;
+    rc_table_view T;
+    int k;
+    const uint8_t *qualp;
+    rc_frame *stack;  // this wave's frames in HBM scratch
+
+    __device__ __forceinline__ void sync() { __syncthreads(); }  // 1-wave workgroup: LDS ordering only
+
+    __device__ __forceinline__ int reduce_add(int x)
+    {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+        return x;
+    }
+
+    __device__ __forceinline__ int get(rc_kmer km)
+    {
+        return km.inv == -1 ? rc_table_lookup(T, rc_canonical(km.code, k)) : 0;
+    }
+
+    // the four one-base extensions of km: lane c (c < 4) probes extension c
+    __device__ __forceinline__ void probe4(rc_kmer km, int dir, int cnt[4])
+    {
+        int mine = 0;
+        if (lane < 4) mine = get(rc_extend(km, k, dir, lane));
+        cnt[0] = __builtin_amdgcn_readlane(mine, 0);
+        cnt[1] = __builtin_amdgcn_readlane(mine, 1);
+        cnt[2] = __builtin_amdgcn_readlane(mine, 2);
+        cnt[3] = __builtin_amdgcn_readlane(mine, 3);
+    }
+
+    __device__ __forceinline__ int probe1(rc_kmer km)
+    {
+        int mine = 0;
+        if (lane == 0) mine = get(km);
+        return __builtin_amdgcn_readlane(mine, 0);
+    }
+
+    __device__ __forceinline__ int lookup(uint64_t code) { return rc_table_lookup(T, rc_canonical(code, k)); }
+
+    // ascending bitonic sort of a[0..n) in LDS; a[] has room for the next power of two
+    __device__ __forceinline__ void sort(int *a, int n)
+    {
+        int n2 = 1;
+        while (n2 < n) n2 <<= 1;
+        for (int i = n + lane; i < n2; i += 64) a[i] = 2147483647;
+        __syncthreads();
+        for (int size = 2; size <= n2; size <<= 1) {
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                for (int t = lane; t < (n2 >> 1); t += 64) {
+                    const int pos = 2 * t - (t & (stride - 1));
+                    const int par = pos + stride;
+                    const bool up = (pos & size) == 0;
+                    const int x = a[pos], y = a[par];
+                    if ((x > y) == up) {
+                        a[pos] = y;
+                        a[par] = x;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+
+    __device__ __forceinline__ int qual(int i) { return (int)(signed char)qualp[i]; }
+
+    __device__ __forceinline__ void stack_push(int sp, const rc_frame &f)
+    {
+        if (lane == 0) stack[sp] = f;
+        __threadfence_block();
+    }
+    __device__ __forceinline__ void stack_top(int idx, rc_frame &f)
+    {
+        const volatile rc_frame *p = stack + idx;
+        f.code = p->code;
+        f.inv = p->inv;
+        f.pos = p->pos;
+        f.t = p->t;
+        f.threshold = p->threshold;
+        f.fix_cnt = p->fix_cnt;
+        f.bottleneck = p->bottleneck;
+        f.cnt[0] = p->cnt[0];
+        f.cnt[1] = p->cnt[1];
+        f.cnt[2] = p->cnt[2];
+        f.cnt[3] = p->cnt[3];
+        f.mask = p->mask;
+    }
+    __device__ __forceinline__ void stack_set_mask(int idx, int mask)
+    {
+        if (lane == 0) stack[idx].mask = mask;
+        __threadfence_block();
+    }
+};
+
+struct rc_lds_layout {
+    int cap, cap2;
+    size_t o_counts, o_v, o_isl, o_seg, o_base, o_path, o_best, o_strongb, o_polya, total;
+};
+
+static __host__ __device__ inline rc_lds_layout rc_layout(int cap)
+{
+    rc_lds_layout L;
+    L.cap = cap;
+    int c2 = 64;
+    while (c2 < cap) c2 <<= 1;
+    L.cap2 = c2;
+    const int nseg = cap / 2 + 2;
+    size_t o = 0;
+    L.o_counts = o;
+    o += (size_t)cap * 4;
+    L.o_v = o;
+    o += (size_t)c2 * 4;
+    L.o_seg = o;
+    o += (size_t)nseg * sizeof(rc_segment);
+    L.o_isl = o;
+    o += (size_t)nseg * sizeof(rc_island);
+    L.o_base = o;
+    o += cap;
+    L.o_path = o;
+    o += cap;
+    L.o_best = o;
+    o += cap;
+    L.o_strongb = o;
+    o += cap;
+    L.o_polya = o;
+    o += cap;
+    L.total = (o + 15) & ~(size_t)15;
+    return L;
+}
+
+__device__ __forceinline__ void rc_carve(uint8_t *lds, const rc_lds_layout &L, rc_read_state &S)
+{
+    S.counts = reinterpret_cast<int *>(lds + L.o_counts);
+    S.v = reinterpret_cast<int *>(lds + L.o_v);
+    S.seg = reinterpret_cast<rc_segment *>(lds + L.o_seg);
+    S.isl = reinterpret_cast<rc_island *>(lds + L.o_isl);
+    S.base = lds + L.o_base;
+    S.path = reinterpret_cast<signed char *>(lds + L.o_path);
+    S.best = reinterpret_cast<signed char *>(lds + L.o_best);
+    S.strongb = lds + L.o_strongb;
+    S.polya = lds + L.o_polya;
+}
+
+__device__ __forceinline__ int rc_base_code(uint32_t c)
+{
+    int b = 5;
+    b = c == 'A' ? 0 : b;
+    b = c == 'C' ? 1 : b;
+    b = c == 'G' ? 2 : b;
+    b = c == 'T' ? 3 : b;
+    b = c == 'N' ? 4 : b;
+    return b;
+}
+
+struct rc_kernel_args {
+    rc_table_view T;
+    rc_run_params P;
+    int mode;
+    uint32_t n;
+    uint8_t *seq;
+    const uint8_t *qual;
+    const uint32_t *off;
+    const int32_t *counts;  // K1 output, indexed like seq
+    int32_t *strong, *info;
+    int32_t *ret, *l, *m, *h;
+    rc_frame *stack;
+    int stack_frames;  // per wave
+    uint32_t *work;
+    int cap;
+};
+
+__device__ __forceinline__ void rc_load_read(const rc_kernel_args &A, rc_read_state &S, uint32_t r, int lane)
+{
+    const uint32_t o = A.off[r];
+    const int len = (int)(A.off[r + 1] - o) - 1;
+    S.len = len;
+    S.kcnt = len >= A.P.k ? len - A.P.k + 1 : 0;
+    for (int i = lane; i < len; i += 64) {
+        S.base[i] = (unsigned char)rc_base_code(A.seq[o + i]);
+        S.counts[i] = i < S.kcnt ? A.counts[o + i] : 0;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(64) void k_threshold(rc_kernel_args A)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const rc_lds_layout L = rc_layout(A.cap);
+    rc_read_state S;
+    rc_carve(lds, L, S);
+    DevWave w;
+    w.lane = threadIdx.x;
+    w.T = A.T;
+    w.k = A.P.k;
+    w.qualp = nullptr;
+    w.stack = nullptr;
+    for (uint32_t r = blockIdx.x; r < A.n; r += gridDim.x) {
+        rc_load_read(A, S, r, w.lane);
+        int info;
+        const int strong = rc_front_end(w, S, A.P, &info);
+        if (w.lane == 0) {
+            A.strong[r] = strong;
+            A.info[r] = info;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(64) void k_correct(rc_kernel_args A)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const rc_lds_layout L = rc_layout(A.cap);
+    rc_read_state S;
+    rc_carve(lds, L, S);
+    DevWave w;
+    w.lane = threadIdx.x;
+    w.T = A.T;
+    w.k = A.P.k;
+    w.stack = A.stack + (size_t)blockIdx.x * A.stack_frames;
+    for (;;) {
+        uint32_t r = 0;
+        if (w.lane == 0) r = atomicAdd(A.work, 1u);
+        r = (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
+        if (r >= A.n) break;
+        rc_load_read(A, S, r, w.lane);
+        const uint32_t o = A.off[r];
+        w.qualp = A.qual + o;
+        const int strong0 = A.strong[r], info0 = A.info[r];
+        int pair_t = -1;
+        if (A.mode == 1) {
+            const uint32_t half = A.n >> 1;
+            const uint32_t mate = r < half ? r + half : r - half;
+            pair_t = rc_min(strong0, A.strong[mate]);
+        } else if (A.mode == 2) {
+            pair_t = rc_min(strong0, A.strong[r ^ 1u]);
+        }
+        if (S.kcnt > 0 && !(info0 & 4)) rc_polya_flags(w, S, A.P.k);
+        const int ret = rc_correct_read(w, S, A.P, pair_t, strong0, info0);
+        __syncthreads();
+        if (ret > 0) {
+            for (int i = w.lane; i < S.len; i += 64) {
+                const int f = S.best[i];
+                if (f != -1) {
+                    A.seq[o + i] = (uint8_t)("ACGT"[f]);
+                    S.base[i] = (unsigned char)f;
+                }
+            }
+            __syncthreads();
+        }
+        int l, m, h;
+        rc_kmer_info(w, S, A.P, ret, &l, &m, &h);
+        if (w.lane == 0) {
+            A.ret[r] = ret;
+            A.l[r] = l;
+            A.m[r] = m;
+            A.h[r] = h;
+        }
+        __syncthreads();
+    }
+}
+
+static int rc_cap_for(int max_len)
+{
+    int cap = ((max_len + 1 + 63) / 64) * 64;
+    if (cap < 64) cap = 64;
+    return cap;
+}
+
+static int fill_args(rc_ctx *ctx, const rc_device_batch_args &a, rc_kernel_args &A)
+{
+    if (!ctx->d_buckets) {
+        rc_set_error(ctx, "correct: no k-mer table loaded");
+        return RC_ERR_STATE;
+    }
+    if (!ctx->params_set) {
+        rc_set_error(ctx, "correct: run parameters not set (rc_set_run_params)");
+        return RC_ERR_STATE;
+    }
+    if (a.max_len >= RC_MAX_READ_LENGTH) {
+        rc_set_error(ctx, "correct: read of %d bases exceeds the %d-base limit (utils.h:7)", a.max_len, RC_MAX_READ_LENGTH - 1);
+        return RC_ERR_ARG;
+    }
+    if (a.mode == 1 && (a.n & 1)) {
+        rc_set_error(ctx, "correct: paired mode needs an even number of reads");
+        return RC_ERR_ARG;
+    }
+    if (a.mode == 2 && (a.n & 1)) {
+        rc_set_error(ctx, "correct: interleaved mode needs an even number of reads");
+        return RC_ERR_ARG;
+    }
+    A.T = rc_view(ctx);
+    A.P = ctx->P;
+    A.mode = a.mode;
+    A.n = a.n;
+    A.seq = a.seq;
+    A.qual = a.qual;
+    A.off = a.off;
+    A.counts = (const int32_t *)ctx->counts.p;
+    A.strong = (int32_t *)ctx->strong.p;
+    A.info = (int32_t *)ctx->info.p;
+    A.ret = a.ret;
+    A.l = a.l;
+    A.m = a.m;
+    A.h = a.h;
+    A.stack = nullptr;
+    A.stack_frames = 0;
+    A.work = (uint32_t *)ctx->work.p;
+    A.cap = rc_cap_for(a.max_len);
+    return RC_OK;
+}
+
+int rc_launch_threshold(rc_ctx *ctx, const rc_device_batch_args &a)
+{
+    if (a.n == 0) return RC_OK;
+    rc_kernel_args A;
+    int rc = fill_args(ctx, a, A);
+    if (rc) return rc;
+    const rc_lds_layout L = rc_layout(A.cap);
+    unsigned grid = (unsigned)ctx->n_cu * 32u;
+    if (grid > a.n) grid = a.n;
+    rc_timer_begin(ctx);
+    hipLaunchKernelGGL(k_threshold, dim3(grid), dim3(64), L.total, ctx->stream, A);
+    rc_timer_end(ctx, RC_T_THRESH);
+    RC_CHECK_HIP(ctx, hipGetLastError());
+    return RC_OK;
+}
+
+int rc_launch_correct(rc_ctx *ctx, const rc_device_batch_args &a)
+{
+    if (a.n == 0) return RC_OK;
+    rc_kernel_args A;
+    int rc = fill_args(ctx, a, A);
+    if (rc) return rc;
+    const rc_lds_layout L = rc_layout(A.cap);
+    unsigned grid = (unsigned)ctx->n_cu * 16u;
+    if (grid > a.n) grid = a.n;
+    A.stack_frames = A.cap + 64;
+    rc = rc_dbuf_reserve(ctx, &ctx->stack, (size_t)grid * A.stack_frames * sizeof(rc_frame));
+    if (rc) return rc;
+    A.stack = (rc_frame *)ctx->stack.p;
+    RC_CHECK_HIP(ctx, hipMemsetAsync(ctx->work.p, 0, 64, ctx->stream));
+    rc_timer_begin(ctx);
+    hipLaunchKernelGGL(k_correct, dim3(grid), dim3(64), L.total, ctx->stream, A);
+    rc_timer_end(ctx, RC_T_CORRECT);
+    RC_CHECK_HIP(ctx, hipGetLastError());
+    return RC_OK;
+}

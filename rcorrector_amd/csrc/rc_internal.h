@@ -1,0 +1,90 @@
+// rc_internal.h -- context object and cross-TU declarations of librcorrector_amd.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "rc_correct_core.h"
+
+#define RC_CHECK_HIP(ctx, expr)                                                                  \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess) {                                                                  \
+            rc_set_error((ctx), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                         __LINE__);                                                              \
+            return RC_ERR_HIP;                                                                   \
+        }                                                                                        \
+    } while (0)
+
+enum { RC_OK = 0, RC_ERR_ARG = -1, RC_ERR_HIP = -2, RC_ERR_IO = -3, RC_ERR_STATE = -4, RC_ERR_NOMEM = -5 };
+
+// grow-only device buffer
+struct rc_dbuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+struct rc_kernel_timer {
+    double ms = 0;       // accumulated
+    uint64_t launches = 0;
+};
+
+enum { RC_T_PROBE = 0, RC_T_THRESH = 1, RC_T_CORRECT = 2, RC_T_COUNT };
+
+struct rc_ctx {
+    int device = 0;
+    int k = 23;
+    int n_cu = 256;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool profile = false;
+    rc_kernel_timer timers[RC_T_COUNT];
+
+    rc_run_params P;
+    bool params_set = false;
+
+    // k-mer table in HBM
+    uint32_t *d_buckets = nullptr;
+    uint32_t home_mask = 0;
+    uint32_t nb_alloc = 0;
+    size_t n_entries = 0;   // accepted entries (duplicates included)
+    size_t table_bytes = 0;
+
+    // batch scratch
+    rc_dbuf counts;   // int32 per arena byte
+    rc_dbuf strong;   // int32 per read
+    rc_dbuf info;     // int32 per read
+    rc_dbuf stack;    // search stack frames
+    rc_dbuf work;     // work counters
+    rc_dbuf h_seq, h_qual, h_off, h_res;  // device staging for the host-buffer entry point
+
+    char err[512];
+};
+
+void rc_set_error(rc_ctx *ctx, const char *fmt, ...);
+int rc_dbuf_reserve(rc_ctx *ctx, rc_dbuf *b, size_t bytes);
+rc_table_view rc_view(const rc_ctx *ctx);
+void rc_timer_begin(rc_ctx *ctx);
+void rc_timer_end(rc_ctx *ctx, int which);
+
+// rc_table.hip
+int rc_build_table_from_device_pairs(rc_ctx *ctx, const uint64_t *d_canon, const int32_t *d_counts,
+                                     size_t n);
+int rc_launch_canonicalize(rc_ctx *ctx, uint64_t *d_codes, size_t n);
+int rc_launch_lookup(rc_ctx *ctx, const uint64_t *d_codes, size_t n, int32_t *d_out);
+int rc_launch_probe(rc_ctx *ctx, const uint8_t *d_seq, size_t nbytes, int32_t *d_counts);
+int rc_count_reads(rc_ctx *ctx, const uint8_t *d_seq, size_t nbytes, int min_count, int64_t *n_kmers);
+int rc_launch_last_base_variants(rc_ctx *ctx, const uint64_t *d_codes, size_t n, int32_t *d_max2);
+
+// rc_correct.hip
+struct rc_device_batch_args {
+    int mode;            // 0 single, 1 paired (reads [0,n/2) are mates of [n/2,n)), 2 interleaved
+    uint32_t n;          // reads
+    uint8_t *seq;        // arena, reads NUL-terminated
+    const uint8_t *qual; // same offsets
+    const uint32_t *off; // n+1
+    int32_t *ret, *l, *m, *h;
+    int max_len;         // longest read in the batch (bases)
+};
+int rc_launch_threshold(rc_ctx *ctx, const rc_device_batch_args &a);
+int rc_launch_correct(rc_ctx *ctx, const rc_device_batch_args &a);

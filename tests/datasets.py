@@ -1,0 +1,106 @@
+"""Seeded synthetic data sets shared by the CPU and GPU parity tests (tools/synth.py, synth-v1)."""
+import numpy as np
+
+import synth
+
+# name -> (k, max_fix_per_k, error_rate, synth kwargs, mode) ; mode 0 single, 1 paired, 2 interleaved
+CONFIGS = {
+    "se_k23": dict(k=23, mfk=4, rate=0.01, mode=0, kw=dict(seed=101, n=3000, length=100, e=0.01)),
+    "pe_k23": dict(k=23, mfk=4, rate=0.01, mode=1, kw=dict(seed=102, n=1500, length=150, e=0.005, paired=True)),
+    "il_k23": dict(k=23, mfk=4, rate=0.01, mode=2, kw=dict(seed=103, n=1500, length=150, e=0.005, paired=True)),
+    "k31_mc8": dict(k=31, mfk=8, rate=0.01, mode=0, kw=dict(seed=104, n=1500, length=150, e=0.05)),
+    "skew": dict(k=23, mfk=4, rate=0.004, mode=0, kw=dict(seed=105, n=3000, length=150, e=0.005, alpha=1.5, bias3=True)),
+    "nrich": dict(k=23, mfk=4, rate=0.01, mode=0, kw=dict(seed=107, n=3000, length=100, e=0.01, p_n=0.01)),
+    "varlen": dict(k=23, mfk=4, rate=0.01, mode=0, kw=dict(seed=108, n=3000, length=100, e=0.02, var_len=True)),
+    "k15": dict(k=15, mfk=4, rate=0.01, mode=0, kw=dict(seed=109, n=2000, length=75, e=0.01, n_tx=50)),
+    "k32": dict(k=32, mfk=4, rate=0.01, mode=0, kw=dict(seed=110, n=2000, length=150, e=0.01)),
+    "pe_var": dict(k=23, mfk=4, rate=0.02, mode=1, kw=dict(seed=111, n=1500, length=120, e=0.03, paired=True, var_len=True, p_n=0.005)),
+}
+
+
+def adversarial_reads(seed=7, n=600, length=100):
+    """Edge cases the reference's screens and k-mer state machine care about (SURVEY §11 fx_edge):
+    reads shorter than / equal to k, 6+ N, isolated N, IUPAC letters, poly-A/T tails, all-A."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    s1, q1, _, _, _ = synth.make_reads(seed, n, length, e=0.01)
+    reads = [s1[i].tobytes() for i in range(n)]
+    quals = [q1[i].tobytes() for i in range(n)]
+    out_r, out_q = [], []
+    for i, (r, q) in enumerate(zip(reads, quals)):
+        r = bytearray(r)
+        kind = i % 12
+        if kind == 0:
+            r = r[:int(rng.integers(1, 23))]
+        elif kind == 1:
+            r = r[:23]
+        elif kind == 2:
+            for p in rng.choice(length, 7, replace=False):
+                r[p] = ord('N')
+        elif kind == 3:
+            r[int(rng.integers(0, length))] = ord('N')
+        elif kind == 4:
+            for p in rng.choice(length, 3, replace=False):
+                r[p] = rng.choice(list(b"RYKMSWBDHV"))
+        elif kind == 5:
+            t = int(rng.integers(10, 60))
+            r[length - t:] = b"A" * t
+        elif kind == 6:
+            t = int(rng.integers(10, 60))
+            r[:t] = b"T" * t
+        elif kind == 7:
+            r = bytearray(b"A" * length)
+        elif kind == 8:
+            for p in range(40, 46):
+                r[p] = ord("ACGT"[(b"ACGT".index(r[p]) + 1) % 4]) if r[p] in b"ACGT" else r[p]
+        elif kind == 9:
+            r[0] = ord('N')
+            r[-1] = ord('N')
+        elif kind == 10:
+            r = r[:24 + int(rng.integers(0, 10))]
+        q = bytes(q[:len(r)])
+        out_r.append(bytes(r))
+        out_q.append(q)
+    return out_r, out_q
+
+
+def make(name):
+    """Returns dict(k, mfk, rate, mode, keys, counts, seqs1, quals1, seqs2, quals2) as python bytes lists."""
+    if name == "edge":
+        r, q = adversarial_reads()
+        s1, _, _, _, _ = synth.make_reads(7, 600, 100, e=0.01)
+        keys, cnt = synth.count_kmers([s1], 23)
+        return dict(k=23, mfk=4, rate=0.01, mode=0, keys=keys, counts=cnt, seqs1=r, quals1=q, seqs2=None, quals2=None)
+    c = CONFIGS[name]
+    kw = dict(c["kw"])
+    seed, n, length = kw.pop("seed"), kw.pop("n"), kw.pop("length")
+    s1, q1, s2, q2, lens = synth.make_reads(seed, n, length, **kw)
+    keys, cnt = synth.count_kmers([s1, s2], c["k"], [lens, lens] if lens is not None else None)
+
+    def rows(a):
+        if a is None:
+            return None
+        return [a[i, :(length if lens is None else lens[i])].tobytes() for i in range(len(a))]
+    r1, qq1, r2, qq2 = rows(s1), rows(q1), rows(s2), rows(q2)
+    if c["mode"] == 2:
+        r1 = [x for p in zip(r1, r2) for x in p]
+        qq1 = [x for p in zip(qq1, qq2) for x in p]
+        r2 = qq2 = None
+    return dict(k=c["k"], mfk=c["mfk"], rate=c["rate"], mode=c["mode"], keys=keys, counts=cnt,
+                seqs1=r1, quals1=qq1, seqs2=r2, quals2=qq2)
+
+
+def run_oracle(po, d, threads=4, fn=None):
+    """Runs the oracle (or any same-signature batch function) on data set d.
+    Returns (ret, l, m, h, corrected_arena1[, corrected_arena2])."""
+    T = po.Table(d["k"], len(d["keys"]))
+    T.put_many(d["keys"], d["counts"])
+    P = po.make_params(d["k"], d["mfk"], d["rate"], b"H")
+    a, off = po.pack_reads(d["seqs1"])
+    qa, _ = po.pack_reads(d["quals1"])
+    if d["mode"] == 1:
+        a2, off2 = po.pack_reads(d["seqs2"])
+        qa2, _ = po.pack_reads(d["quals2"])
+        res = po.correct_batch(P, T, 1, a, qa, off, a2, qa2, off2, threads=threads, fn=fn)
+        return res + (a, a2)
+    res = po.correct_batch(P, T, d["mode"], a, qa, off, threads=threads, fn=fn)
+    return res + (a,)

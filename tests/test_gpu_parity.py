@@ -1,0 +1,146 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle on the same
+seeded inputs.  Integer / byte work => bit-exact everywhere."""
+import numpy as np
+import pytest
+
+import datasets
+
+pytestmark = pytest.mark.gpu
+
+
+def _table(ctx_factory, d):
+    ctx = ctx_factory(d["k"], d["mfk"])
+    ctx.table_build(d["keys"], d["counts"])
+    ctx.set_run_params(d["rate"], b"H")
+    return ctx
+
+
+def _revcomp_codes(codes, k):
+    out = np.zeros_like(codes)
+    c = codes.copy()
+    for _ in range(k):
+        out = (out << np.uint64(2)) | (np.uint64(3) - (c & np.uint64(3)))
+        c = c >> np.uint64(2)
+    return out
+
+
+@pytest.mark.parametrize("k", [15, 23, 31, 32])
+def test_table_lookup_matches_store(gpu_ctx_factory, k):
+    rng = np.random.Generator(np.random.PCG64(k))
+    n = 200000
+    mask = np.uint64((1 << (2 * k)) - 1) if k < 32 else np.uint64(0xFFFFFFFFFFFFFFFF)
+    fwd = rng.integers(0, 1 << 63, size=n, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=n, dtype=np.uint64)
+    fwd &= mask
+    can = np.minimum(fwd, _revcomp_codes(fwd, k))
+    can = np.unique(can)
+    counts = rng.integers(2, 1 << 30, size=len(can)).astype(np.int32)
+    ctx = gpu_ctx_factory(k)
+    ctx.table_build(can, counts)
+    assert np.array_equal(ctx.lookup(can), counts)                       # canonical form
+    assert np.array_equal(ctx.lookup(_revcomp_codes(can, k)), counts)    # the other strand
+    absent = rng.integers(0, 1 << 63, size=n, dtype=np.uint64) & mask
+    absent_can = np.minimum(absent, _revcomp_codes(absent, k))
+    present = np.isin(absent_can, can)
+    got = ctx.lookup(absent)
+    assert (got[~present] == 0).all()
+    st = ctx.table_stats()
+    assert st["entries"] == len(can) and st["bytes"] == st["buckets"] * 64
+
+
+def test_table_later_duplicate_wins(gpu_ctx_factory):
+    # Store.h:55: hash[key] = cnt overwrites
+    k = 23
+    codes = np.array([5, 77, 5, 1234567, 77, 5], dtype=np.uint64)
+    counts = np.array([10, 20, 30, 40, 50, 60], dtype=np.int32)
+    ctx = gpu_ctx_factory(k)
+    ctx.table_build(codes, counts)
+    assert ctx.lookup(np.array([5, 77, 1234567, 9], dtype=np.uint64)).tolist() == [60, 50, 40, 0]
+
+
+def test_table_empty_and_tiny(gpu_ctx_factory):
+    ctx = gpu_ctx_factory(23)
+    ctx.table_build(np.zeros(0, np.uint64), np.zeros(0, np.int32))
+    assert ctx.lookup(np.array([0, 1, 2], dtype=np.uint64)).tolist() == [0, 0, 0]
+    ctx.table_build(np.array([0], np.uint64), np.array([7], np.int32))  # poly-A k-mer has code 0
+    assert ctx.lookup(np.array([0, 1], dtype=np.uint64)).tolist() == [7, 0]
+
+
+@pytest.mark.parametrize("name", ["se_k23", "k31_mc8", "nrich", "varlen", "k15", "k32", "edge"])
+def test_probe_kernel_counts(gpu_ctx_factory, oracle, name):
+    import torch
+    d = datasets.make(name)
+    ctx = _table(gpu_ctx_factory, d)
+    arena, off = oracle.pack_reads(d["seqs1"])
+    d_seq = torch.from_numpy(arena).cuda()
+    d_cnt = torch.full((len(arena),), -7, dtype=torch.int32, device="cuda")
+    ctx.probe_device(d_seq, len(arena), d_cnt)
+    ctx.sync()
+    got = d_cnt.cpu().numpy()
+    T = oracle.Table(d["k"], len(d["keys"]))
+    T.put_many(d["keys"], d["counts"])
+    P = oracle.make_params(d["k"], d["mfk"], d["rate"], b"H")
+    for i, s in enumerate(d["seqs1"]):
+        want = oracle.kmer_counts(P, T, s)
+        o = int(off[i])
+        assert np.array_equal(got[o:o + len(want)], want), "read %d of %s" % (i, name)
+        # positions that start no k-mer of this read are left untouched
+        assert (got[o + len(want):int(off[i + 1])] == -7).all()
+
+
+@pytest.mark.parametrize("name", ["se_k23", "pe_k23", "il_k23", "k31_mc8", "skew", "nrich", "varlen", "k15", "k32", "pe_var", "edge"])
+def test_correct_batch_matches_oracle(gpu_ctx_factory, oracle, name):
+    d = datasets.make(name)
+    want = datasets.run_oracle(oracle, d)
+    ctx = _table(gpu_ctx_factory, d)
+    a, off = oracle.pack_reads(d["seqs1"])
+    qa, _ = oracle.pack_reads(d["quals1"])
+    if d["mode"] == 1:
+        a2, off2 = oracle.pack_reads(d["seqs2"])
+        qa2, _ = oracle.pack_reads(d["quals2"])
+        got = ctx.correct_batch(1, a, qa, off, a2, qa2, off2) + (a, a2)
+    else:
+        got = ctx.correct_batch(d["mode"], a, qa, off) + (a,)
+    for w, g, what in zip(want, got, ["ret", "l", "m", "h", "seq1", "seq2"]):
+        bad = np.nonzero(w != g)[0]
+        assert len(bad) == 0, "%s differs on %s at %s (want %s got %s)" % (what, name, bad[:5], w[bad[:5]], g[bad[:5]])
+    reads, cors = ctx.summary()
+    assert reads == len(want[0]) and cors == int(want[0][want[0] > 0].sum())
+
+
+def test_paired_equals_interleaved_and_batch_split_invariance(gpu_ctx_factory, oracle):
+    """Size-independent properties: -p and -i give the same per-read results, and the
+    result of a read does not depend on which batch it travels in."""
+    d = datasets.make("pe_k23")
+    ctx = _table(gpu_ctx_factory, d)
+    n = len(d["seqs1"])
+    a1, o1 = oracle.pack_reads(d["seqs1"]); q1, _ = oracle.pack_reads(d["quals1"])
+    a2, o2 = oracle.pack_reads(d["seqs2"]); q2, _ = oracle.pack_reads(d["quals2"])
+    rp = ctx.correct_batch(1, a1, q1, o1, a2, q2, o2)
+    il_s = [x for p in zip(d["seqs1"], d["seqs2"]) for x in p]
+    il_q = [x for p in zip(d["quals1"], d["quals2"]) for x in p]
+    ai, oi = oracle.pack_reads(il_s); qi, _ = oracle.pack_reads(il_q)
+    ri = ctx.correct_batch(2, ai, qi, oi)
+    for x, y in zip(rp, ri):
+        assert np.array_equal(x[:n], y[0::2]) and np.array_equal(x[n:], y[1::2])
+    got_il = oracle.unpack_reads(ai, oi)
+    assert got_il[0::2] == oracle.unpack_reads(a1, o1) and got_il[1::2] == oracle.unpack_reads(a2, o2)
+    # split the interleaved batch in two uneven halves
+    cut = 2 * (n // 3)
+    parts = []
+    for lo, hi in ((0, cut), (cut, 2 * n)):
+        a, o = oracle.pack_reads(il_s[lo:hi]); q, _ = oracle.pack_reads(il_q[lo:hi])
+        r = ctx.correct_batch(2, a, q, o)
+        parts.append((r, oracle.unpack_reads(a, o)))
+    for j in range(4):
+        assert np.array_equal(np.concatenate([parts[0][0][j], parts[1][0][j]]), ri[j])
+    assert parts[0][1] + parts[1][1] == got_il
+
+
+def test_errors_are_loud(gpu_ctx_factory):
+    import rcorrector_amd
+    ctx = gpu_ctx_factory(23)
+    a, off = rcorrector_amd.pack_reads([b"ACGT" * 10])
+    with pytest.raises(rcorrector_amd.RcorrectorError):
+        ctx.correct_batch(0, a, a.copy(), off)  # no table, no run parameters
+    with pytest.raises(rcorrector_amd.RcorrectorError):
+        rcorrector_amd.Context(k=33)
