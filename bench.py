@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py -- corrected reads/s of the MI355X correction path (BASELINE.json metric).
+
+Contract: `python bench.py --gpus N --steps K --warmup W` (N>1 under torch.distributed.run, one
+rank per GPU).  A step = one pass of the whole hot path (probe K1 -> threshold K2 -> correct K3,
+rc_correct_device) over one batch of synthetic reads already resident in HBM.  Default workload
+= BASELINE.json configs[1]: 10 M synthetic 100 bp single-end reads, k=23, k-mer table counted
+from those reads (~50 M k-mers), 1 GPU.  Reads shard across ranks with the table replicated
+(no data-path collective); `value` = reads all ranks corrected / max-over-ranks wall time.
+
+The JSON line also carries
+  roofline     : the hash-probe kernel (K1) timed with HIP events on the library's stream inside
+                 the timed region; achieved = algorithmic bytes (64 B per valid
+                 k-mer + 1 B per base + 4 B per count) / average launch time, vs 8 TB/s HBM3E.
+  cpu_baseline : the CPU oracle (restatement of the reference, oracle/) on a bounded sample of
+                 the same reads and the same table, all host cores -- reported, not the target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402  (before the HIP library: one HIP runtime per process)
+import torch.distributed as dist  # noqa: E402
+
+import rcorrector_amd  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E nominal (MI355X_MICROARCH.md)
+
+
+def synth_reads_gpu(seed, n_reads, length, n_tx, l_tx, alpha, err, dev, chunk=1 << 20):
+    """synth-v1 on the GPU: returns (seq arena uint8 [n*(L+1)], qual arena) with a NUL
+    after every read.  The transcriptome depends only on `seed // 1000` so all ranks share it."""
+    g_tx = torch.Generator(device=dev)
+    g_tx.manual_seed(seed // 1000)
+    tx = torch.randint(0, 4, (n_tx * l_tx,), dtype=torch.uint8, device=dev, generator=g_tx)
+    w = (torch.arange(n_tx, device=dev, dtype=torch.float64) + 1.0) ** (-alpha)
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    seq = torch.zeros((n_reads, length + 1), dtype=torch.uint8, device=dev)
+    qual = torch.zeros((n_reads, length + 1), dtype=torch.uint8, device=dev)
+    ar = torch.arange(length, device=dev)
+    for lo in range(0, n_reads, chunk):
+        m = min(chunk, n_reads - lo)
+        tid = torch.multinomial(w.float(), m, replacement=True, generator=g)
+        start = torch.randint(0, l_tx - length + 1, (m,), device=dev, generator=g)
+        idx = (tid * l_tx + start)[:, None] + ar[None, :]
+        codes = tx[idx]
+        rev = torch.rand(m, device=dev, generator=g) < 0.5
+        codes = torch.where(rev[:, None], 3 - codes.flip(1), codes)
+        mut = torch.rand((m, length), device=dev, generator=g) < err
+        shift = torch.randint(1, 4, (m, length), dtype=torch.uint8, device=dev, generator=g)
+        codes = torch.where(mut, (codes + shift) & 3, codes)
+        seq[lo:lo + m, :length] = lut[codes.long()]
+        q = torch.full((m, length), ord('I'), dtype=torch.uint8, device=dev)
+        q[mut] = ord('#')
+        qual[lo:lo + m, :length] = q
+    return seq.reshape(-1), qual.reshape(-1)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step")
+    ap.add_argument("--len", type=int, default=100)
+    ap.add_argument("-k", type=int, default=23)
+    ap.add_argument("--n-tx", type=int, default=30000)
+    ap.add_argument("--l-tx", type=int, default=1500)
+    ap.add_argument("--err", type=float, default=0.005)
+    ap.add_argument("--alpha", type=float, default=0.8)
+    ap.add_argument("--seed", type=int, default=1001000)
+    ap.add_argument("--cpu-sample", type=int, default=100000, help="reads of the CPU-baseline sample (0 = skip)")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, a.gpus))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    L, k, n = a.len, a.k, a.reads
+    ctx = rcorrector_amd.Context(k=k, max_fix_per_k=4, device=local)
+
+    # the replicated table: every rank counts the k-mers of the rank-0 shard (same seed => same
+    # table everywhere, no communication), then generates its own shard of reads
+    t0 = time.time()
+    seq0, qual0 = synth_reads_gpu(a.seed, n, L, a.n_tx, a.l_tx, a.alpha, a.err, dev)
+    torch.cuda.synchronize()
+    t_gen = time.time() - t0
+    t0 = time.time()
+    n_kmers = ctx.count_reads_device(seq0, seq0.numel(), 2)
+    t_count = time.time() - t0
+    if rank != 0:
+        del seq0, qual0
+        seq0, qual0 = synth_reads_gpu(a.seed + rank, n, L, a.n_tx, a.l_tx, a.alpha, a.err, dev)
+    nbytes = seq0.numel()
+    off = (torch.arange(n + 1, device=dev, dtype=torch.int64) * (L + 1)).to(torch.int32)  # < 2^31 here
+    first_q = qual0[0::(L + 1)][:1000000]
+    last_q = qual0[L - 1::(L + 1)][:1000000]
+    fh = torch.bincount(first_q.long(), minlength=300)[:300].cpu().numpy().astype(np.int32)
+    lh = torch.bincount(last_q.long(), minlength=300)[:300].cpu().numpy().astype(np.int32)
+    bad_q = ctx.bad_quality_from_hist(fh, lh, int(first_q.numel()))
+    error_rate = 0.01  # the reference's fallback (main.cpp:355-356); the estimate needs a dump file order
+    ctx.set_run_params(error_rate, bad_q)
+
+    work = seq0.clone()
+    ret = torch.zeros(n, dtype=torch.int32, device=dev)
+    l_ = torch.zeros_like(ret)
+    m_ = torch.zeros_like(ret)
+    h_ = torch.zeros_like(ret)
+
+    def step():
+        work.copy_(seq0)           # restore the uncorrected reads (the kernel corrects in place)
+        torch.cuda.current_stream().synchronize()
+        ctx.correct_device(0, n, nbytes, L, work, qual0, off, ret, l_, m_, h_)
+        ctx.sync()
+
+    for _ in range(a.warmup):
+        step()
+    ctx.profile(True)
+    ctx.profile_reset()
+    barrier()
+    torch.cuda.synchronize()
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    ctx.sync()
+    barrier()
+    dt = time.perf_counter() - t0
+    ctx.profile(False)
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        stats = torch.tensor([int(n), int((ret > 0).sum().item()), int(ret.clamp(min=0).sum().item())],
+                             dtype=torch.int64, device=dev)
+        dist.all_reduce(stats)  # the one RCCL reduce: global count statistics (main.cpp:32-36)
+        stats = stats.tolist()
+    else:
+        stats = [int(n), int((ret > 0).sum().item()), int(ret.clamp(min=0).sum().item())]
+
+    if rank == 0:
+        total_reads = n * world * a.steps
+        value = total_reads / dt
+        ms_probe, launches = ctx.profile_get(0)
+        ms_thr, _ = ctx.profile_get(1)
+        ms_cor, _ = ctx.profile_get(2)
+        kcnt = L - k + 1
+        alg_bytes = float(n) * (kcnt * 64 + L + 4 * kcnt)   # no N in this workload: every k-mer valid
+        avg_probe_s = ms_probe / max(launches, 1) / 1e3
+        achieved = alg_bytes / avg_probe_s / 1e9 if avg_probe_s > 0 else 0.0
+        ts = ctx.table_stats()
+
+        cpu = None
+        if a.cpu_sample > 0:
+            cpu = cpu_baseline(ctx, seq0, qual0, n, L, k, error_rate, bad_q, a.cpu_sample, ret, work)
+
+        out = {
+            "metric": "corrected reads/sec (%d bp, k=%d)" % (L, k),
+            "value": value, "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8/int32/u64", "data": "synthetic",
+            "config": {"workload": "%d synthetic %d bp single-end reads per GPU, k=%d, %d-k-mer table "
+                       "(BASELINE.json configs[1])" % (n, L, k, n_kmers),
+                       "reads_per_gpu": n, "read_len": L, "k": k, "table_kmers": n_kmers,
+                       "table_bytes": ts["bytes"], "sub_rate": a.err, "error_rate_param": error_rate,
+                       "bad_quality": bad_q.decode("latin1"), "parallelism": "reads sharded x%d, table replicated" % world,
+                       "reads_corrected_frac": stats[1] / float(stats[0]), "bases_corrected": stats[2],
+                       "setup_s": {"synth": round(t_gen, 2), "count_and_build_table": round(t_count, 2)},
+                       "kernel_ms_per_step": {"probe": ms_probe / a.steps, "threshold": ms_thr / a.steps,
+                                              "correct": ms_cor / a.steps}},
+            "roofline": {"kernel": "k_probe (hash probe, K1)", "bound": "hbm", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_probe_s * 1e3,
+                         "launches": launches, "traffic": None},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(ctx, seq0, qual0, n, L, k, error_rate, bad_q, sample, ret_gpu, work_gpu):
+    """The CPU oracle on the first `sample` reads with the same table, all host cores; also checks
+    the GPU results of those reads against it (the oracle is the checker here, never the product)."""
+    from oracle import pyoracle as po
+    po.build()
+    sample = min(sample, n)
+    codes, counts = ctx.table_export()
+    T = po.Table(k, len(codes))
+    T.put_many(codes, counts)
+    P = po.make_params(k, 4, error_rate, bad_q)
+    nb = sample * (L + 1)
+    arena = seq0[:nb].cpu().numpy().copy()
+    qa = qual0[:nb].cpu().numpy().copy()
+    off = (np.arange(sample + 1, dtype=np.int64) * (L + 1)).astype(np.uint32)
+    cores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    r, _, _, _ = po.correct_batch(P, T, 0, arena, qa, off, threads=cores)
+    dt = time.perf_counter() - t0
+    same = bool(np.array_equal(r, ret_gpu[:sample].cpu().numpy()) and
+                np.array_equal(arena, work_gpu[:nb].cpu().numpy()))
+    return {"value": sample / dt, "unit": "reads/s", "cores": cores, "kind": "port",
+            "sample": "first %d reads of the same batch, same table, %d pthreads, %.1f s" % (sample, cores, dt),
+            "gpu_matches_oracle_on_sample": same}
+
+
+if __name__ == "__main__":
+    main()

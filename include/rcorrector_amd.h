@@ -65,6 +65,9 @@ int rc_table_count_reads_device(rc_ctx *ctx, const uint8_t *d_seq, size_t nbytes
                                 int64_t *n_kmers);
 /* Store::GetCount (Store.h:59-66) for n valid k-mer codes (host arrays) */
 int rc_table_lookup(rc_ctx *ctx, const uint64_t *codes, size_t n, int32_t *counts_out);
+/* every stored (canonical code, count) pair, unspecified order -- what `jellyfish dump` would
+ * print (run_rcorrector.pl:280); *n_out = number stored (may exceed cap: call again) */
+int rc_table_export(rc_ctx *ctx, uint64_t *codes, int32_t *counts, size_t cap, size_t *n_out);
 /* bytes of HBM held by the table, number of buckets, number of stored entries */
 int rc_table_stats(const rc_ctx *ctx, uint64_t *bytes, uint64_t *buckets, uint64_t *entries);
 

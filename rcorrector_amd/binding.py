@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 ABI_SYMBOLS = [
     "rc_create", "rc_destroy", "rc_last_error",
     "rc_table_build", "rc_table_build_device", "rc_table_load_jfdump",
-    "rc_table_count_reads_device", "rc_table_lookup", "rc_table_stats",
+    "rc_table_count_reads_device", "rc_table_lookup", "rc_table_export", "rc_table_stats",
     "rc_estimate_error_rate", "rc_bad_quality_from_hist", "rc_set_run_params",
     "rc_correct_batch", "rc_correct_device", "rc_probe_device", "rc_sync",
     "rc_profile_enable", "rc_profile_get", "rc_profile_reset", "rc_summary",
@@ -87,6 +87,7 @@ def load_library():
     L.rc_table_load_jfdump.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64)]
     L.rc_table_count_reads_device.argtypes = [vp, vp, sz, C.c_int, C.POINTER(C.c_int64)]
     L.rc_table_lookup.argtypes = [vp, vp, sz, vp]
+    L.rc_table_export.argtypes = [vp, vp, vp, sz, C.POINTER(C.c_size_t)]
     L.rc_table_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.rc_estimate_error_rate.argtypes = [vp, C.c_double, C.POINTER(C.c_double)]
     L.rc_bad_quality_from_hist.restype = C.c_char
@@ -186,6 +187,15 @@ class Context:
         out = np.zeros(len(codes), dtype=np.int32)
         self._ck(self._L.rc_table_lookup(self._h, codes.ctypes.data, len(codes), out.ctypes.data))
         return out
+
+    def table_export(self):
+        """All stored (canonical code, count) pairs (unspecified order)."""
+        cap = int(self.table_stats()["entries"])
+        codes = np.zeros(cap, dtype=np.uint64)
+        counts = np.zeros(cap, dtype=np.int32)
+        n = C.c_size_t(0)
+        self._ck(self._L.rc_table_export(self._h, codes.ctypes.data, counts.ctypes.data, cap, C.byref(n)))
+        return codes[:n.value], counts[:n.value]
 
     def table_stats(self):
         b, n, e = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)

@@ -281,6 +281,38 @@ int rc_table_lookup(rc_ctx *ctx, const uint64_t *codes, size_t n, int32_t *out)
     return rc;
 }
 
+int rc_table_export(rc_ctx *ctx, uint64_t *codes, int32_t *counts, size_t cap, size_t *n_out)
+{
+    if (!ctx || !n_out || (cap && (!codes || !counts))) return RC_ERR_ARG;
+    if (!ctx->d_buckets) {
+        rc_set_error(ctx, "export: no k-mer table loaded");
+        return RC_ERR_STATE;
+    }
+    RC_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    uint64_t *d_codes = nullptr;
+    int32_t *d_counts = nullptr;
+    unsigned long long *d_n = nullptr, n = 0;
+    RC_CHECK_HIP(ctx, hipMalloc(&d_codes, (cap + 1) * 8));
+    RC_CHECK_HIP(ctx, hipMalloc(&d_counts, (cap + 1) * 4));
+    RC_CHECK_HIP(ctx, hipMalloc(&d_n, 8));
+    RC_CHECK_HIP(ctx, hipMemsetAsync(d_n, 0, 8, ctx->stream));
+    int rc = rc_launch_export(ctx, d_codes, d_counts, d_n, cap);
+    if (rc == RC_OK) {
+        RC_CHECK_HIP(ctx, hipMemcpyAsync(&n, d_n, 8, hipMemcpyDeviceToHost, ctx->stream));
+        RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        const size_t m = n < cap ? (size_t)n : cap;
+        if (m) {
+            RC_CHECK_HIP(ctx, hipMemcpy(codes, d_codes, m * 8, hipMemcpyDeviceToHost));
+            RC_CHECK_HIP(ctx, hipMemcpy(counts, d_counts, m * 4, hipMemcpyDeviceToHost));
+        }
+        *n_out = (size_t)n;
+    }
+    (void)hipFree(d_codes);
+    (void)hipFree(d_counts);
+    (void)hipFree(d_n);
+    return rc;
+}
+
 int rc_table_stats(const rc_ctx *ctx, uint64_t *bytes, uint64_t *buckets, uint64_t *entries)
 {
     if (!ctx) return RC_ERR_ARG;

@@ -194,6 +194,29 @@ int rc_launch_last_base_variants(rc_ctx *ctx, const uint64_t *d_codes, size_t n,
     return RC_OK;
 }
 
+// every stored (canonical code, count) pair, in unspecified order (jf_dump writer / test support)
+__global__ void k_export(const uint32_t *__restrict__ buckets, size_t nslots, uint64_t *__restrict__ codes,
+                         int32_t *__restrict__ counts, unsigned long long *__restrict__ n_out, size_t cap)
+{
+    size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nslots) return;
+    const uint32_t *w = buckets + (s / RC_BUCKET_SLOTS) * RC_BUCKET_DWORDS + (s % RC_BUCKET_SLOTS) * 3;
+    if (w[2] == 0) return;
+    unsigned long long at = atomicAdd(n_out, 1ull);
+    if (at < cap) {
+        codes[at] = ((uint64_t)w[1] << 32) | w[0];
+        counts[at] = (int32_t)w[2];
+    }
+}
+
+int rc_launch_export(rc_ctx *ctx, uint64_t *d_codes, int32_t *d_counts, unsigned long long *d_n, size_t cap)
+{
+    const size_t nslots = (size_t)ctx->nb_alloc * RC_BUCKET_SLOTS;
+    hipLaunchKernelGGL(k_export, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_buckets, nslots, d_codes, d_counts, d_n, cap);
+    RC_CHECK_HIP(ctx, hipGetLastError());
+    return RC_OK;
+}
+
 // ---- K1: probe kernel ----------------------------------------------------------------------
 // counts[a] = GetCount(k-mer starting at arena byte a) for every a whose k-window lies inside one
 // read (reads are NUL-terminated inside the arena, so "inside one read" == "no NUL in the
