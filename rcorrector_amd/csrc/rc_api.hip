@@ -55,7 +55,7 @@ rc_table_view rc_view(const rc_ctx *ctx)
 {
     rc_table_view v;
     v.buckets = ctx->d_buckets;
-    v.home_mask = ctx->home_mask;
+    v.nb_home = ctx->nb_home;
     v.nbuckets_alloc = ctx->nb_alloc;
     return v;
 }
@@ -109,6 +109,7 @@ rc_ctx *rc_create(const rc_config *cfg, char *errbuf, size_t errbuf_len)
         return fail("rc_create: could not create stream/events");
     }
     ctx->work.bytes = 256;
+    if (const char *e = getenv("RC_TABLE_LOAD")) ctx->table_load = atof(e);  // tuning knob
     return ctx;
 }
 

@@ -35,7 +35,7 @@
 
 struct rc_table_view {
     const uint32_t *buckets;  // nbuckets_alloc * 16 dwords, 64-B aligned
-    uint32_t home_mask;       // nbuckets_home - 1 (power of two)
+    uint32_t nb_home;         // number of home buckets (any value; home = mulhi(hash, nb_home))
     uint32_t nbuckets_alloc;  // home buckets + slack (no wrap-around)
 };
 
@@ -81,6 +81,13 @@ RC_HD uint32_t rc_hash(uint64_t key)
     h *= 0x297A2D39u;
     h ^= h >> 15;
     return h;
+}
+
+// home bucket of a canonical code: multiply-shift range reduction of the 32-bit hash, so the
+// bucket count (hence the load factor and the table's HBM/MALL footprint) can be any number
+RC_HD uint32_t rc_home(uint64_t key, uint32_t nb_home)
+{
+    return (uint32_t)(((uint64_t)rc_hash(key) * (uint64_t)nb_home) >> 32);
 }
 
 // ---- rolling code with invalid tracker (KmerCode.cpp:7-42) ---------------------------------

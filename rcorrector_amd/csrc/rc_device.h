@@ -7,7 +7,7 @@
 // Of two equal keys the first in probe order wins (the build places the later Put first).
 __device__ __forceinline__ int rc_table_lookup(const rc_table_view &T, uint64_t canon)
 {
-    uint32_t b = rc_hash(canon) & T.home_mask;
+    uint32_t b = rc_home(canon, T.nb_home);
     const uint32_t klo = (uint32_t)canon, khi = (uint32_t)(canon >> 32);
     for (;;) {
         const uint4 *p = reinterpret_cast<const uint4 *>(T.buckets + (size_t)b * RC_BUCKET_DWORDS);

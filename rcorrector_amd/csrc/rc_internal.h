@@ -45,7 +45,8 @@ struct rc_ctx {
 
     // k-mer table in HBM
     uint32_t *d_buckets = nullptr;
-    uint32_t home_mask = 0;
+    uint32_t nb_home = 0;
+    double table_load = 0.50;  // target slot load factor of the next build
     uint32_t nb_alloc = 0;
     size_t n_entries = 0;   // accepted entries (duplicates included)
     size_t table_bytes = 0;

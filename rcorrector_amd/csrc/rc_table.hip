@@ -25,12 +25,12 @@
 
 // ---- K0: build -----------------------------------------------------------------------------
 __global__ void k_home_and_index(const uint64_t *__restrict__ canon, uint32_t *__restrict__ home,
-                                 uint32_t *__restrict__ idx, size_t n, uint32_t mask)
+                                 uint32_t *__restrict__ idx, size_t n, uint32_t nb_home)
 {
     size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     size_t i = n - 1 - j;  // reversed input order (see header)
-    home[j] = rc_hash(canon[i]) & mask;
+    home[j] = rc_home(canon[i], nb_home);
     idx[j] = (uint32_t)i;
 }
 
@@ -58,13 +58,6 @@ __global__ void k_scatter(const uint32_t *__restrict__ home_sorted, const uint32
     if (s == 0 && home_sorted[j] < b) buckets[(size_t)(b - 1) * RC_BUCKET_DWORDS + 15] = 1u;
 }
 
-static uint32_t pow2_ceil_u32(uint64_t x)
-{
-    uint64_t p = 1;
-    while (p < x) p <<= 1;
-    return (uint32_t)p;
-}
-
 int rc_build_table_from_device_pairs(rc_ctx *ctx, const uint64_t *d_canon, const int32_t *d_counts, size_t n)
 {
     if (n >= (1ull << 31)) {
@@ -75,12 +68,21 @@ int rc_build_table_from_device_pairs(rc_ctx *ctx, const uint64_t *d_canon, const
         (void)hipFree(ctx->d_buckets);
         ctx->d_buckets = nullptr;
     }
-    // home buckets: power of two with slot load factor in (0.2, 0.4]
-    uint64_t want = (uint64_t)(n / 2) + 1;  // n / (5 * 0.4)
-    uint32_t nb_home = pow2_ceil_u32(want < 64 ? 64 : want);
-    ctx->home_mask = nb_home - 1;
+    // home buckets: n / (slots * load).  Random 64-byte gathers on MI355X are request-rate bound
+    // (~55 G/s, tools/microbench_gather.hip) and fall off a cliff once the table outgrows the TLB
+    // reach (~2 GiB), so a dense table wins: fewer bytes => more MALL/L2 hits per probe.
+    double load = ctx->table_load;
+    if (!(load > 0.05 && load <= 0.95)) load = 0.50;
+    uint64_t want = (uint64_t)((double)n / (RC_BUCKET_SLOTS * load)) + 1;
+    if (want < 64) want = 64;
+    if (want >= (1ull << 32) - 8) {
+        rc_set_error(ctx, "table build: bucket count overflow");
+        return RC_ERR_ARG;
+    }
+    uint32_t nb_home = (uint32_t)want;
+    ctx->nb_home = nb_home;
     int bits = 0;
-    while ((1u << bits) < nb_home) ++bits;
+    while ((1ull << bits) < (uint64_t)nb_home) ++bits;
 
     long long p_last = -1;
     uint32_t *home = nullptr, *home_s = nullptr, *idx = nullptr, *idx_s = nullptr;
@@ -97,7 +99,7 @@ int rc_build_table_from_device_pairs(rc_ctx *ctx, const uint64_t *d_canon, const
         RC_CHECK_HIP(ctx, hipMalloc(&idx_s, n * 4));
         RC_CHECK_HIP(ctx, hipMalloc(&q, n * 8));
         RC_CHECK_HIP(ctx, hipMalloc(&qm, n * 8));
-        hipLaunchKernelGGL(k_home_and_index, dim3(G), dim3(B), 0, ctx->stream, d_canon, home, idx, n, ctx->home_mask);
+        hipLaunchKernelGGL(k_home_and_index, dim3(G), dim3(B), 0, ctx->stream, d_canon, home, idx, n, ctx->nb_home);
         RC_CHECK_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp_sort, home, home_s, idx, idx_s, n, 0, bits > 0 ? bits : 1, ctx->stream));
         RC_CHECK_HIP(ctx, rocprim::inclusive_scan(nullptr, tmp_scan, q, qm, n, rocprim::maximum<long long>(), ctx->stream));
         RC_CHECK_HIP(ctx, hipMalloc(&tmp, tmp_sort > tmp_scan ? tmp_sort : tmp_scan));

@@ -1,0 +1,60 @@
+"""GPU: the drop-in `rcorrector` binary (C++ host over the C ABI over the HIP kernels) must write
+the same bytes as the unmodified reference for every golden fixture: *.cor.fq, stderr parameter
+lines, -stdout, gz in/out, any batch size."""
+import gzip
+import os
+import shutil
+
+import pytest
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+CLI = os.path.join(gu.ROOT, "rcorrector_amd", "rcorrector")
+
+
+@pytest.mark.parametrize("name", gu.FIXTURES)
+def test_cli_reproduces_reference_outputs(name, tmp_path):
+    p = gu.run_fixture(CLI, name, tmp_path)
+    gu.assert_same_as_reference(name, tmp_path, p.stderr)
+
+
+@pytest.mark.parametrize("name", ["fx_se_k23", "fx_pe_k23", "fx_il_k23", "fx_edge"])
+def test_cli_small_batches_and_thread_flag(name, tmp_path):
+    # output must not depend on the batch size (the reference's is 512*T, main.cpp:441)
+    p = gu.run_fixture(CLI, name, tmp_path, extra=["-batch", "50", "-t", "8"])
+    gu.assert_same_as_reference(name, tmp_path, p.stderr)
+
+
+def test_cli_stdout_pairs_alternate(tmp_path):
+    p = gu.run_fixture(CLI, "fx_pe_k23", tmp_path, extra=["-stdout"])
+    ref = os.path.join(gu.GOLDEN, "fx_pe_k23", "ref")
+    a = open(os.path.join(ref, "reads_1.cor.fq"), "rb").read().split(b"\n")
+    b = open(os.path.join(ref, "reads_2.cor.fq"), "rb").read().split(b"\n")
+    want = []
+    for i in range(0, len(a) - 1, 4):
+        want += a[i:i + 4] + b[i:i + 4]
+    assert p.stdout.split(b"\n")[:-1] == want
+
+
+def test_cli_gz_in_gz_out(tmp_path):
+    src = os.path.join(gu.GOLDEN, "fx_se_k23")
+    work = tmp_path / "in"
+    work.mkdir()
+    with open(os.path.join(src, "reads.fq"), "rb") as f, gzip.open(work / "reads.fq.gz", "wb") as g:
+        shutil.copyfileobj(f, g)
+    shutil.copy(os.path.join(src, "dump.jf"), work / "dump.jf")
+    out = tmp_path / "out"
+    p = gu.run_fixture(CLI, "fx_se_k23", out, args_override=["-r", str(work / "reads.fq.gz"), "-k", "23", "-c", str(work / "dump.jf")])
+    got = gzip.open(out / "reads.cor.fq.gz", "rb").read()      # name rule Reads.h:39-75,140-147
+    assert got == open(os.path.join(src, "ref", "reads.cor.fq"), "rb").read()
+    assert p.stderr == open(os.path.join(src, "ref", "stderr.txt"), "rb").read()
+
+
+def test_cli_multiple_files_in_one_run(tmp_path):
+    # -r a -r b: batches never span files (Reads.h:332-358); same records as separate runs
+    a = os.path.join(gu.GOLDEN, "fx_se_k23")
+    p = gu.run_fixture(CLI, "fx_se_k23", tmp_path, args_override=["-r", "reads.fq", "-r", os.path.join(a, "reads.fq"), "-k", "23", "-c", "dump.jf", "-batch", "128"])
+    want = open(os.path.join(a, "ref", "reads.cor.fq"), "rb").read()
+    assert open(tmp_path / "reads.cor.fq", "rb").read() == want  # second -r truncates and rewrites the same name
+    assert b"Processed 800 reads" in p.stderr
