@@ -29,6 +29,7 @@ import torch  # noqa: E402  (before the HIP library: one HIP runtime per process
 import torch.distributed as dist  # noqa: E402
 
 import rcorrector_amd  # noqa: E402
+from rcorrector_amd.distributed import reduce_summary  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E nominal (MI355X_MICROARCH.md)
 
@@ -77,7 +78,7 @@ def main():
     ap.add_argument("--err", type=float, default=0.005)
     ap.add_argument("--alpha", type=float, default=0.8)
     ap.add_argument("--seed", type=int, default=1001000)
-    ap.add_argument("--cpu-sample", type=int, default=100000, help="reads of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=1000000, help="reads of the CPU-baseline sample (0 = skip)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -150,12 +151,10 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        stats = torch.tensor([int(n), int((ret > 0).sum().item()), int(ret.clamp(min=0).sum().item())],
-                             dtype=torch.int64, device=dev)
-        dist.all_reduce(stats)  # the one RCCL reduce: global count statistics (main.cpp:32-36)
-        stats = stats.tolist()
-    else:
-        stats = [int(n), int((ret > 0).sum().item()), int(ret.clamp(min=0).sum().item())]
+    n_cor_reads = int((ret > 0).sum().item())
+    # the one RCCL collective of the whole path: global count statistics (main.cpp:32-36)
+    g_reads, g_bases = reduce_summary(n, int(ret.clamp(min=0).sum().item()), device=dev)
+    stats = [g_reads, n_cor_reads * world, g_bases]
 
     if rank == 0:
         total_reads = n * world * a.steps
@@ -168,6 +167,17 @@ def main():
         avg_probe_s = ms_probe / max(launches, 1) / 1e3
         achieved = alg_bytes / avg_probe_s / 1e9 if avg_probe_s > 0 else 0.0
         ts = ctx.table_stats()
+
+        # the host-buffer entry point (rc_correct_batch: H2D + kernels + D2H from pageable memory),
+        # reported for context only -- never `value`
+        hn = min(n, 1_000_000)
+        hseq = seq0[:hn * (L + 1)].cpu().numpy().copy()
+        hqual = qual0[:hn * (L + 1)].cpu().numpy().copy()
+        hoff = (np.arange(hn + 1, dtype=np.int64) * (L + 1)).astype(np.uint32)
+        ctx.correct_batch(0, hseq.copy(), hqual, hoff)
+        th = time.perf_counter()
+        ctx.correct_batch(0, hseq, hqual, hoff)
+        host_rate = hn / (time.perf_counter() - th)
 
         cpu = None
         if a.cpu_sample > 0:
@@ -184,6 +194,7 @@ def main():
                        "table_bytes": ts["bytes"], "sub_rate": a.err, "error_rate_param": error_rate,
                        "bad_quality": bad_q.decode("latin1"), "parallelism": "reads sharded x%d, table replicated" % world,
                        "reads_corrected_frac": stats[1] / float(stats[0]), "bases_corrected": stats[2],
+                       "host_buffer_entry_reads_per_s_pcie_inclusive": host_rate,
                        "setup_s": {"synth": round(t_gen, 2), "count_and_build_table": round(t_count, 2)},
                        "kernel_ms_per_step": {"probe": ms_probe / a.steps, "threshold": ms_thr / a.steps,
                                               "correct": ms_cor / a.steps}},
