@@ -109,6 +109,7 @@ rc_ctx *rc_create(const rc_config *cfg, char *errbuf, size_t errbuf_len)
         return fail("rc_create: could not create stream/events");
     }
     ctx->work.bytes = 256;
+    if (const char *e = getenv("RC_PHASE_PROF")) ctx->phase_prof = atoi(e) != 0;
     if (const char *e = getenv("RC_TABLE_LOAD")) ctx->table_load = atof(e);  // tuning knob
     return ctx;
 }

@@ -5,18 +5,51 @@
 // One 64-lane wavefront (= one workgroup) per read; persistent waves pull read indices from an
 // atomic counter, which is the reference's mutex-protected batchUsed counter (:87-90) and
 // absorbs the heavy tail of the search.  Per-read state is carved out of dynamic LDS.
+#include <cstdio>
+
 #include "rc_internal.h"
 #include "rc_device.h"
 
-struct DevWave {
+// PROF = per-phase s_memtime accounting (dev aid, RC_PHASE_PROF=1); compiled out otherwise
+template <bool PROF>
+struct DevWaveT {
     static const int STRIDE = 64;
     int lane;
+    unsigned long long t_last = 0;
+    int cur_phase = 0;
+    unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    __device__ __forceinline__ void phase(int id)
+    {
+        if (PROF) {
+            unsigned long long t = __builtin_readcyclecounter();
+            acc[cur_phase] += t - t_last;
+            t_last = t;
+            cur_phase = id;
+        }
+    }
     rc_table_view T;
     int k;
     const uint8_t *qualp;
     rc_frame *stack;  // this wave's frames in HBM scratch
 
     __device__ __forceinline__ void sync() { __syncthreads(); }  // 1-wave workgroup: LDS ordering only
+
+    // bit l of the result = pred(base + l) for base + l < n (one element per lane)
+    template <class F>
+    __device__ __forceinline__ uint64_t ballot64(int base, int n, F pred)
+    {
+        const int i = base + lane;
+        bool p = false;
+        if (i < n) p = pred(i);
+        return __ballot(p);
+    }
+    // body(base + l, l) on lane l for base + l < n
+    template <class F>
+    __device__ __forceinline__ void for_lanes64(int base, int n, F body)
+    {
+        const int i = base + lane;
+        if (i < n) body(i, lane);
+    }
 
     __device__ __forceinline__ int reduce_add(int x)
     {
@@ -53,6 +86,31 @@ struct DevWave {
     // ascending bitonic sort of a[0..n) in LDS; a[] has room for the next power of two
     __device__ __forceinline__ void sort(int *a, int n)
     {
+        if (n <= 256) {
+            // rank sort: every lane counts, for each of its <= 4 elements, the elements that sort
+            // before it (value, then index); no barriers inside, all LDS reads are broadcasts
+            int x[4], r[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = lane + 64 * e;
+                x[e] = i < n ? a[i] : 2147483647;
+                r[e] = 0;
+            }
+            for (int j = 0; j < n; ++j) {
+                const int y = a[j];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = lane + 64 * e;
+                    r[e] += (y < x[e] || (y == x[e] && j < i)) ? 1 : 0;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (lane + 64 * e < n) a[r[e]] = x[e];
+            __syncthreads();
+            return;
+        }
         int n2 = 1;
         while (n2 < n) n2 <<= 1;
         for (int i = n + lane; i < n2; i += 64) a[i] = 2147483647;
@@ -103,10 +161,12 @@ struct DevWave {
         __threadfence_block();
     }
 };
+typedef DevWaveT<false> DevWave;
 
 struct rc_lds_layout {
     int cap, cap2;
-    size_t o_counts, o_v, o_isl, o_seg, o_base, o_path, o_best, o_strongb, o_polya, total;
+    size_t o_counts, o_v, o_isl, o_seg, o_base, o_path, o_best, o_strongb, o_polya, o_masks, o_spec, total;
+    int mask_words;
 };
 
 static __host__ __device__ inline rc_lds_layout rc_layout(int cap)
@@ -118,6 +178,11 @@ static __host__ __device__ inline rc_lds_layout rc_layout(int cap)
     L.cap2 = c2;
     const int nseg = cap / 2 + 2;
     size_t o = 0;
+    L.mask_words = cap / 64 + 2;
+    L.o_masks = o;
+    o += (size_t)L.mask_words * 8 * 5;
+    L.o_spec = o;
+    o += (size_t)RC_SPEC * (8 + 4 * 4 + 4);
     L.o_counts = o;
     o += (size_t)cap * 4;
     L.o_v = o;
@@ -151,6 +216,15 @@ __device__ __forceinline__ void rc_carve(uint8_t *lds, const rc_lds_layout &L, r
     S.best = reinterpret_cast<signed char *>(lds + L.o_best);
     S.strongb = lds + L.o_strongb;
     S.polya = lds + L.o_polya;
+    uint64_t *mm = reinterpret_cast<uint64_t *>(lds + L.o_masks);
+    S.m_a = mm;
+    S.m_t = mm + L.mask_words;
+    S.m_n = mm + 2 * L.mask_words;
+    S.m_inv = mm + 3 * L.mask_words;
+    S.m_x = mm + 4 * L.mask_words;
+    S.spec_code = reinterpret_cast<uint64_t *>(lds + L.o_spec);
+    S.spec_cnt = reinterpret_cast<int *>(lds + L.o_spec + RC_SPEC * 8);
+    S.spec_inv = S.spec_cnt + RC_SPEC * 4;
 }
 
 __device__ __forceinline__ int rc_base_code(uint32_t c)
@@ -179,9 +253,11 @@ struct rc_kernel_args {
     int stack_frames;  // per wave
     uint32_t *work;
     int cap;
+    unsigned long long *phase_cycles;  // [8], PROF builds only
 };
 
-__device__ __forceinline__ void rc_load_read(const rc_kernel_args &A, rc_read_state &S, uint32_t r, int lane)
+template <class W>
+__device__ __forceinline__ void rc_load_read(W &w, const rc_kernel_args &A, rc_read_state &S, uint32_t r, int lane)
 {
     const uint32_t o = A.off[r];
     const int len = (int)(A.off[r + 1] - o) - 1;
@@ -192,6 +268,7 @@ __device__ __forceinline__ void rc_load_read(const rc_kernel_args &A, rc_read_st
         S.counts[i] = i < S.kcnt ? A.counts[o + i] : 0;
     }
     __syncthreads();
+    rc_build_masks(w, S);
 }
 
 __global__ __launch_bounds__(64) void k_threshold(rc_kernel_args A)
@@ -207,7 +284,7 @@ __global__ __launch_bounds__(64) void k_threshold(rc_kernel_args A)
     w.qualp = nullptr;
     w.stack = nullptr;
     for (uint32_t r = blockIdx.x; r < A.n; r += gridDim.x) {
-        rc_load_read(A, S, r, w.lane);
+        rc_load_read(w, A, S, r, w.lane);
         int info;
         const int strong = rc_front_end(w, S, A.P, &info);
         if (w.lane == 0) {
@@ -218,14 +295,16 @@ __global__ __launch_bounds__(64) void k_threshold(rc_kernel_args A)
     }
 }
 
+template <bool PROF>
 __global__ __launch_bounds__(64) void k_correct(rc_kernel_args A)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const rc_lds_layout L = rc_layout(A.cap);
     rc_read_state S;
     rc_carve(lds, L, S);
-    DevWave w;
+    DevWaveT<PROF> w;
     w.lane = threadIdx.x;
+    if (PROF) w.t_last = __builtin_readcyclecounter();
     w.T = A.T;
     w.k = A.P.k;
     w.stack = A.stack + (size_t)blockIdx.x * A.stack_frames;
@@ -234,7 +313,8 @@ __global__ __launch_bounds__(64) void k_correct(rc_kernel_args A)
         if (w.lane == 0) r = atomicAdd(A.work, 1u);
         r = (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
         if (r >= A.n) break;
-        rc_load_read(A, S, r, w.lane);
+        w.phase(0);
+        rc_load_read(w, A, S, r, w.lane);
         const uint32_t o = A.off[r];
         w.qualp = A.qual + o;
         const int strong0 = A.strong[r], info0 = A.info[r];
@@ -246,8 +326,10 @@ __global__ __launch_bounds__(64) void k_correct(rc_kernel_args A)
         } else if (A.mode == 2) {
             pair_t = rc_min(strong0, A.strong[r ^ 1u]);
         }
+        w.phase(1);
         if (S.kcnt > 0 && !(info0 & 4)) rc_polya_flags(w, S, A.P.k);
         const int ret = rc_correct_read(w, S, A.P, pair_t, strong0, info0);
+        w.phase(6);
         __syncthreads();
         if (ret > 0) {
             for (int i = w.lane; i < S.len; i += 64) {
@@ -268,6 +350,11 @@ __global__ __launch_bounds__(64) void k_correct(rc_kernel_args A)
             A.h[r] = h;
         }
         __syncthreads();
+        w.phase(7);
+    }
+    if (PROF && w.lane == 0) {
+        w.phase(7);
+        for (int i = 0; i < 8; ++i) atomicAdd(A.phase_cycles + i, w.acc[i]);
     }
 }
 
@@ -318,6 +405,7 @@ static int fill_args(rc_ctx *ctx, const rc_device_batch_args &a, rc_kernel_args 
     A.stack_frames = 0;
     A.work = (uint32_t *)ctx->work.p;
     A.cap = rc_cap_for(a.max_len);
+    A.phase_cycles = nullptr;
     return RC_OK;
 }
 
@@ -350,10 +438,25 @@ int rc_launch_correct(rc_ctx *ctx, const rc_device_batch_args &a)
     rc = rc_dbuf_reserve(ctx, &ctx->stack, (size_t)grid * A.stack_frames * sizeof(rc_frame));
     if (rc) return rc;
     A.stack = (rc_frame *)ctx->stack.p;
-    RC_CHECK_HIP(ctx, hipMemsetAsync(ctx->work.p, 0, 64, ctx->stream));
+    RC_CHECK_HIP(ctx, hipMemsetAsync(ctx->work.p, 0, 128, ctx->stream));
+    A.phase_cycles = (unsigned long long *)((char *)ctx->work.p + 64);
     rc_timer_begin(ctx);
-    hipLaunchKernelGGL(k_correct, dim3(grid), dim3(64), L.total, ctx->stream, A);
+    if (ctx->phase_prof)
+        hipLaunchKernelGGL(k_correct<true>, dim3(grid), dim3(64), L.total, ctx->stream, A);
+    else
+        hipLaunchKernelGGL(k_correct<false>, dim3(grid), dim3(64), L.total, ctx->stream, A);
     rc_timer_end(ctx, RC_T_CORRECT);
+    if (ctx->phase_prof) {
+        unsigned long long pc[8];
+        RC_CHECK_HIP(ctx, hipMemcpyAsync(pc, A.phase_cycles, sizeof pc, hipMemcpyDeviceToHost, ctx->stream));
+        RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        static const char *names[8] = {"dequeue+load", "polya", "islands/segments", "search", "lower-thresholds", "post-filters", "apply+kmerinfo", "store"};
+        unsigned long long tot = 0;
+        for (int i = 0; i < 8; ++i) tot += pc[i];
+        fprintf(stderr, "[rc phase prof] k_correct, %u reads, cycles/read:", a.n);
+        for (int i = 0; i < 8; ++i) fprintf(stderr, " %s=%.0f(%.0f%%)", names[i], (double)pc[i] / a.n, 100.0 * pc[i] / (tot ? tot : 1));
+        fprintf(stderr, "\n");
+    }
     RC_CHECK_HIP(ctx, hipGetLastError());
     return RC_OK;
 }

@@ -64,8 +64,79 @@ struct rc_read_state {
     unsigned char *polya;   // [cap]   bit0 IsPolyA(.,k,2), bit1 IsPolyA(.,k,max(7,k/2))
     rc_island *isl;         // [cap/2+2]
     rc_segment *seg;        // [cap/2+2]
+    // one bit per base (bit i%64 of word i/64), cap/64+1 words each, last word always 0
+    uint64_t *m_a, *m_t;    // base is 'A' / 'T'
+    uint64_t *m_n, *m_inv;  // base is 'N' / is not one of ACGT
+    uint64_t *m_x;          // scratch: trusted k-mers, fixed positions
+    // speculation cache of the search (rc_probe4_cached): extension counts of the next RC_SPEC
+    // positions of the keep-base path, fetched in one gather round
+    int *spec_cnt;          // [RC_SPEC*4]
+    uint64_t *spec_code;    // [RC_SPEC]
+    int *spec_inv;          // [RC_SPEC]
     int len, kcnt;
 };
+
+#define RC_SPEC 16
+
+struct rc_spec_state {
+    int n;    // cached positions (0 = empty)
+    int pos;  // position of entry 0
+    int dir;
+};
+
+RC_HD int rc_popc64(uint64_t x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __popcll(x);
+#else
+    return __builtin_popcountll(x);
+#endif
+}
+RC_HD int rc_ctz64(uint64_t x)  // x != 0
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __ffsll((long long)x) - 1;
+#else
+    return __builtin_ctzll(x);
+#endif
+}
+RC_HD int rc_clz64(uint64_t x)  // x != 0
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __clzll((long long)x);
+#else
+    return __builtin_clzll(x);
+#endif
+}
+
+// bits [i, i+n) of a mask array as the low n bits of the result (n <= 64; the array carries one
+// zero word past the end)
+RC_HD uint64_t rc_window(const uint64_t *m, int i, int n)
+{
+    const int w = i >> 6, sh = i & 63;
+    uint64_t x = m[w] >> sh;
+    if (sh) x |= m[w + 1] << (64 - sh);
+    return n >= 64 ? x : (x & ((1ull << n) - 1ull));
+}
+
+// bit masks of the read's letters; every lane-parallel window test below runs on these
+template <class W>
+RC_HD void rc_build_masks(W &w, rc_read_state &S)
+{
+    const int nw = (S.len + 63) >> 6;
+    for (int c = 0; c <= nw; ++c) {
+        const int b0 = c << 6;
+        const uint64_t ma = w.ballot64(b0, S.len, [&](int i) { return S.base[i] == 0; });
+        const uint64_t mt = w.ballot64(b0, S.len, [&](int i) { return S.base[i] == 3; });
+        const uint64_t mn = w.ballot64(b0, S.len, [&](int i) { return S.base[i] == 4; });
+        const uint64_t mi = w.ballot64(b0, S.len, [&](int i) { return S.base[i] >= 4; });
+        S.m_a[c] = ma;
+        S.m_t[c] = mt;
+        S.m_n[c] = mn;
+        S.m_inv[c] = mi;
+    }
+    w.sync();
+}
 
 RC_HD int rc_min(int a, int b) { return a < b ? a : b; }
 
@@ -74,33 +145,27 @@ RC_HD int rc_min(int a, int b) { return a < b ? a : b; }
 template <class W>
 RC_HD int rc_screened(W &w, const rc_read_state &S, int k)
 {
+    (void)w;
     int n = 0, a = 0, t = 0;
-    for (int i = w.lane; i < S.len; i += W::STRIDE) {
-        int b = S.base[i];
-        n += (b == 4);
-        a += (b == 0);
-        t += (b == 3);
+    const int nw = (S.len + 63) >> 6;
+    for (int c = 0; c < nw; ++c) {
+        n += rc_popc64(S.m_n[c]);
+        a += rc_popc64(S.m_a[c]);
+        t += rc_popc64(S.m_t[c]);
     }
-    n = w.reduce_add(n);
-    a = w.reduce_add(a);
-    t = w.reduce_add(t);
     return n > 5 || a > S.len - k || t > S.len - k;
 }
 
 // IsPolyA for every k-mer window, thresholds 2 and max(7,k/2) (ErrorCorrection.cpp:53-71,
-// :776-779, :826)
+// :776-779, :826): window popcounts of the A / T masks
 template <class W>
 RC_HD void rc_polya_flags(W &w, rc_read_state &S, int k)
 {
     int thr7 = 7;
     if (k / 2 > thr7) thr7 = k / 2;
     for (int i = w.lane; i < S.kcnt; i += W::STRIDE) {
-        int a = 0, t = 0;
-        for (int j = 0; j < k; ++j) {
-            int b = S.base[i + j];
-            a += (b == 0);
-            t += (b == 3);
-        }
+        const int a = rc_popc64(rc_window(S.m_a, i, k));
+        const int t = rc_popc64(rc_window(S.m_t, i, k));
         int f = 0;
         if (a >= k - 2 || t >= k - 2) f |= 1;
         if (a >= k - thr7 || t >= k - thr7) f |= 2;
@@ -123,20 +188,27 @@ RC_HD void rc_masked_sorted(W &w, rc_read_state &S)
 template <class W>
 RC_HD int rc_initial_strong(W &w, const rc_read_state &S, int *found, int *prev)
 {
-    (void)w;
-    int i;
     const int kcnt = S.kcnt;
-    for (i = kcnt - 1; i >= 1; --i)
-        if (S.v[i] > 2 * S.v[i - 1] && S.v[i] > 10) break;
-    if (i >= 1) {
-        *found = 1;
-        *prev = S.v[i - 1];
-        return S.v[i];
+    // highest i in [1, kcnt) with v[i] > 2 v[i-1] && v[i] > 10
+    for (int b0 = ((kcnt - 1) >> 6) << 6; b0 >= 0; b0 -= 64) {
+        const uint64_t m = w.ballot64(b0, kcnt, [&](int i) { return i >= 1 && S.v[i] > 2 * S.v[i - 1] && S.v[i] > 10; });
+        if (m) {
+            const int i = b0 + 63 - rc_clz64(m);
+            *found = 1;
+            *prev = S.v[i - 1];
+            return S.v[i];
+        }
     }
     *found = 0;
     *prev = 0;
-    for (i = 0; i < kcnt; ++i)
-        if (S.v[i] > 0) break;
+    int i = kcnt;  // lowest i with v[i] > 0, else kcnt
+    for (int b0 = 0; b0 < kcnt; b0 += 64) {
+        const uint64_t m = w.ballot64(b0, kcnt, [&](int j) { return S.v[j] > 0; });
+        if (m) {
+            i = b0 + rc_ctz64(m);
+            break;
+        }
+    }
     return S.v[(i + kcnt - 1) / 2];
 }
 
@@ -194,6 +266,51 @@ RC_HD rc_kmer rc_extend(rc_kmer km, int k, int dir, int b)
     return dir > 0 ? rc_append(km, k, b) : rc_prepend(km, k, b);
 }
 
+// The four extension counts of search node (kc, pos).  InferPosThreshold and steps (1)/(3) of the
+// reference all look at the same four k-mers, so they are fetched once per node -- and, because a
+// node's successor along the keep-base path is known in advance (the read's own next base), the
+// extensions of the next RC_SPEC positions are fetched in the SAME gather round: lane (j, c)
+// extends kc by the read's bases pos .. pos+j-1 and probes extension c.  Later nodes hit the cache
+// iff their k-mer state equals the speculated one; anything else (a substitution, a jump, a
+// popped frame) misses and refills from there.  Pure memoisation: results cannot change.
+template <class W>
+RC_HD void rc_probe4_cached(W &w, rc_read_state &S, rc_spec_state &Z, rc_kmer kc, int dir, int pos, int to, int k,
+                            int cnt[4])
+{
+    if (Z.n > 0 && Z.dir == dir) {
+        const int j = (pos - Z.pos) * dir;
+        if (j >= 0 && j < Z.n && S.spec_code[j] == kc.code && S.spec_inv[j] == kc.inv) {
+            cnt[0] = S.spec_cnt[4 * j + 0];
+            cnt[1] = S.spec_cnt[4 * j + 1];
+            cnt[2] = S.spec_cnt[4 * j + 2];
+            cnt[3] = S.spec_cnt[4 * j + 3];
+            return;
+        }
+    }
+    int n = dir > 0 ? (to - pos) : (pos - to + 1);  // nodes left on this side of the segment end
+    if (n > RC_SPEC) n = RC_SPEC;
+    if (n < 1) n = 1;
+    w.sync();
+    w.for_lanes64(0, 4 * n, [&](int q, int) {
+        const int j = q >> 2, c = q & 3;
+        rc_kmer kj = kc;
+        for (int s2 = 0; s2 < j; ++s2) kj = rc_extend(kj, k, dir, S.base[pos + dir * s2]);
+        if (c == 0) {
+            S.spec_code[j] = kj.code;
+            S.spec_inv[j] = kj.inv;
+        }
+        S.spec_cnt[q] = w.get(rc_extend(kj, k, dir, c));
+    });
+    w.sync();
+    Z.n = n;
+    Z.pos = pos;
+    Z.dir = dir;
+    cnt[0] = S.spec_cnt[0];
+    cnt[1] = S.spec_cnt[1];
+    cnt[2] = S.spec_cnt[2];
+    cnt[3] = S.spec_cnt[3];
+}
+
 // terminal bookkeeping, ErrorCorrection.cpp:243-284 / :483-523
 template <class W>
 RC_HD void rc_search_terminal(W &w, rc_read_state &S, rc_search_ctx &C, int pos, int t, int fix_cnt,
@@ -246,6 +363,10 @@ RC_HD void rc_search(W &w, rc_read_state &S, const rc_run_params &P, rc_search_c
     rc_kmer kc = kc0;
     int pos = C.start, t = t0, fix_cnt = 0, bottleneck = 1000000000;
     bool have = true;
+    rc_spec_state Z;
+    Z.n = 0;
+    Z.pos = 0;
+    Z.dir = dir;
 
     for (;;) {
         if (!have) {
@@ -297,7 +418,7 @@ RC_HD void rc_search(W &w, rc_read_state &S, const rc_run_params &P, rc_search_c
         }
 
         int cnt[4];
-        w.probe4(kc, dir, cnt);
+        rc_probe4_cached(w, S, Z, kc, dir, pos, C.to, k, cnt);
         int threshold = rc_pos_threshold(cnt, t, P.error_rate);  // :287 / :525
         const int b = S.base[pos];
         const bool bvalid = b < 4;
@@ -384,7 +505,7 @@ RC_HD void rc_search(W &w, rc_read_state &S, const rc_run_params &P, rc_search_c
                     if (i == pos) {
                         for (int c = 0; c < 4; ++c) cn[c] = cnt[c];
                     } else
-                        w.probe4(tmp, dir, cn);
+                        rc_probe4_cached(w, S, Z, tmp, dir, i, C.to, k, cn);
                     thr = rc_pos_threshold(cn, t, P.error_rate);
                     int bb = S.base[i];
                     tmp = rc_append(tmp, k, bb);
@@ -404,7 +525,7 @@ RC_HD void rc_search(W &w, rc_read_state &S, const rc_run_params &P, rc_search_c
                     if (i == pos) {
                         for (int c = 0; c < 4; ++c) cn[c] = cnt[c];
                     } else
-                        w.probe4(tmp, dir, cn);
+                        rc_probe4_cached(w, S, Z, tmp, dir, i, C.to, k, cn);
                     thr = rc_pos_threshold(cn, t, P.error_rate);
                     int bb = S.base[i];
                     tmp = rc_prepend(tmp, k, bb);
@@ -477,6 +598,7 @@ RC_HD int rc_correct_read(W &w, rc_read_state &S, const rc_run_params &P, int pa
     int iter = 0, total_fix = 0, bad_segment_cnt = 0;
     int tstart = 0, tend = 0;
     for (;;) {  // :854-1291
+        w.phase(2);
         const int allowed_fix = len;
         total_fix = 0;
         bool unfixable = false, force_next = false;
@@ -488,44 +610,64 @@ RC_HD int rc_correct_read(W &w, rc_read_state &S, const rc_run_params &P, int pa
         }
         w.sync();
 
-        // trusted k-mer islands, :870-931
-        for (i = 0; i < kcnt; ++i) {
-            if (S.counts[i] >= strong && !(S.polya[i] & 1)) {
-                ++j;
-            } else {
+        // trusted k-mer islands, :870-931.  trusted[i] = counts[i] >= strong && !IsPolyA(i); the
+        // maximal runs come out of the bit mask (run starts / ends), so the cost is O(#runs).
+        {
+            const int nwk = (kcnt + 63) >> 6;
+            for (int c = 0; c <= nwk; ++c) {
+                const uint64_t tm = w.ballot64(c << 6, kcnt, [&](int q) { return S.counts[q] >= strong && !(S.polya[q] & 1); });
+                S.m_x[c] = tm;
+            }
+            w.sync();
+            int *rs = S.v;                      // run starts
+            int *re = S.v + (kcnt + 1) / 2 + 1; // run ends
+            int ns = 0, ne = 0;
+            for (int c = 0; c < nwk; ++c) {
+                const uint64_t T = S.m_x[c];
+                const uint64_t prev = c ? (S.m_x[c - 1] >> 63) : 0ull;
+                const uint64_t next = S.m_x[c + 1] & 1ull;
+                uint64_t st = T & ~((T << 1) | prev);
+                uint64_t en = T & ~((T >> 1) | (next << 63));
+                while (st) {
+                    rs[ns++] = (c << 6) + rc_ctz64(st);
+                    st &= st - 1;
+                }
+                while (en) {
+                    re[ne++] = (c << 6) + rc_ctz64(en);
+                    en &= en - 1;
+                }
+            }
+            w.sync();
+            if (!(S.m_x[0] & 1ull)) {  // first k-mer untrusted: the scan records a run of length 0 first
+                longest = 0;
+                tstart = 0;
+                tend = -1;
+            }
+            for (int r = 0; r < ns; ++r) {
+                const int f = rs[r], t2 = re[r];
+                j = t2 - f + 1;
                 if (j > longest) {
                     longest = j;
-                    tstart = i - longest;
-                    tend = i - 1;
+                    tstart = f;
+                    tend = t2;
                 }
                 if (j >= 2) {
-                    S.isl[isl_cnt].from = (short)(i - j);
-                    S.isl[isl_cnt].to = (short)(i - 1);
+                    S.isl[isl_cnt].from = (short)f;
+                    S.isl[isl_cnt].to = (short)t2;
                     ++isl_cnt;
                 }
-                j = 0;
             }
+            w.sync();
         }
-        if (j > longest) {
-            longest = j;
-            tstart = i - longest;
-            tend = i - 1;
-        }
-        if (j >= 2) {
-            S.isl[isl_cnt].from = (short)(i - j);
-            S.isl[isl_cnt].to = (short)(i - 1);
-            ++isl_cnt;
-        }
-        w.sync();
 
         // boundary adjustment, :934-965
         for (i = 1; i < isl_cnt; ++i) {
             int pf = S.isl[i - 1].from, pt = S.isl[i - 1].to, cf = S.isl[i].from, ct = S.isl[i].to;
             if (cf <= pt + k) {
                 int len1 = pt - pf, len2 = ct - cf, overlap = pt + k - cf;
-                for (j = pt + 1; j < cf; ++j)
-                    if (S.counts[j] <= 2 && S.counts[j] < trust) break;
-                if (j >= cf) continue;
+                // is there a k-mer strictly between with counts <= 2 && counts < trust?  (gap < k <= 32)
+                const uint64_t weak = w.ballot64(pt + 1, cf, [&](int q) { return S.counts[q] <= 2 && S.counts[q] < trust; });
+                if (!weak) continue;
                 if (overlap > 3) continue;
                 if (len1 < len2)
                     S.isl[i - 1].to = (short)(pt - (overlap + 1));
@@ -535,29 +677,32 @@ RC_HD int rc_correct_read(W &w, rc_read_state &S, const rc_run_params &P, int pa
             }
         }
 
-        // to base space, :968-1007
-        for (i = 0; i < isl_cnt; ++i) {
-            int f = S.isl[i].from, tt = S.isl[i].to;
-            if (f > tt) continue;
-            for (j = f + w.lane; j <= tt + k - 1; j += W::STRIDE) S.strongb[j] = 1;
-        }
-        w.sync();
-        isl_cnt = 0;
-        j = -1;
-        for (i = 0; i < len; ++i) {
-            int sb = S.strongb[i];
-            if (j == -1 && sb) j = i;
-            if (j != -1 && !sb && S.strongb[i - 1]) {
-                S.isl[isl_cnt].from = (short)j;
-                S.isl[isl_cnt].to = (short)(i - 1);
-                ++isl_cnt;
-                j = -1;
+        // to base space, :968-1007: island [from,to] of k-mers covers bases [from, to+k-1]; the
+        // maximal runs of covered bases are the union of these (sorted) intervals
+        {
+            int nb = 0, cura = 0, curb = -2;
+            for (i = 0; i < isl_cnt; ++i) {
+                const int f = S.isl[i].from, tt = S.isl[i].to;
+                if (f > tt) continue;
+                const int a2 = f, b2 = tt + k - 1;
+                for (j = a2 + w.lane; j <= b2; j += W::STRIDE) S.strongb[j] = 1;
+                if (nb > 0 && a2 <= curb + 1) {
+                    if (b2 > curb) curb = b2;
+                } else {
+                    if (nb > 0) {
+                        S.isl[nb - 1].from = (short)cura;
+                        S.isl[nb - 1].to = (short)curb;
+                    }
+                    cura = a2;
+                    curb = b2;
+                    ++nb;
+                }
             }
-        }
-        if (j != -1) {
-            S.isl[isl_cnt].from = (short)j;
-            S.isl[isl_cnt].to = (short)(i - 1);
-            ++isl_cnt;
+            if (nb > 0) {
+                S.isl[nb - 1].from = (short)cura;
+                S.isl[nb - 1].to = (short)curb;
+            }
+            isl_cnt = nb;
         }
         if (isl_cnt == 0) {
             S.isl[0].from = (short)tstart;
@@ -603,6 +748,7 @@ RC_HD int rc_correct_read(W &w, rc_read_state &S, const rc_run_params &P, int pa
         for (i = w.lane; i < len; i += W::STRIDE) S.best[i] = -1;
         w.sync();
         bad_segment_cnt = 0;
+        w.phase(3);
         if (seg_cnt > 0) {  // :1118-1230
             rc_search_ctx C;
             int best_bottleneck = RC_INF;
@@ -665,6 +811,7 @@ RC_HD int rc_correct_read(W &w, rc_read_state &S, const rc_run_params &P, int pa
         if (trust < 10 && !force_next) return -1;  // :1241
 
         // lower the thresholds, :1247-1289
+        w.phase(4);
         rc_masked_sorted(w, S);
         bool has_drop = false;
         for (i = kcnt - 1; i >= 1; --i) {
@@ -688,10 +835,16 @@ RC_HD int rc_correct_read(W &w, rc_read_state &S, const rc_run_params &P, int pa
     }
 
     // ---- post filters (positions list in v[]) ----
-    int cnt = 0;
-    for (int i = 0; i < len; ++i) {  // :1296-1303
-        if (S.base[i] == 4 || S.best[i] == -1) continue;
-        S.v[cnt++] = i;
+    w.phase(5);
+    int cnt = 0;  // positions with a fix on a non-N base, ascending, :1296-1303
+    for (int b0 = 0; b0 < len; b0 += 64) {
+        const uint64_t fm = w.ballot64(b0, len, [&](int q) { return S.base[q] != 4 && S.best[q] != -1; });
+        if (fm) {
+            w.for_lanes64(b0, len, [&](int q, int ln) {
+                if ((fm >> ln) & 1ull) S.v[cnt + rc_popc64(fm & ((1ull << ln) - 1ull))] = q;
+            });
+            cnt += rc_popc64(fm);
+        }
     }
     w.sync();
     const int badq = P.bad_qual;
@@ -754,19 +907,17 @@ RC_HD int rc_correct_read(W &w, rc_read_state &S, const rc_run_params &P, int pa
     }
 
     if (total_fix > 3 && len > 10) {  // end-of-read veto, :1407-1430
-        int tmp = 0;
-        for (int i = 0; i < 10; ++i)
-            if (S.best[i] != -1 && S.base[i] != 4 && w.qual(i) > badq) ++tmp;
+        int tmp = rc_popc64(w.ballot64(0, 10, [&](int q) { return S.best[q] != -1 && S.base[q] != 4 && w.qual(q) > badq; }));
         if (tmp >= 2)
-            for (int i = 0; i < 10; ++i)
-                if (S.base[i] != 4) S.best[i] = -1;
+            w.for_lanes64(0, 10, [&](int q, int) {
+                if (S.base[q] != 4) S.best[q] = -1;
+            });
         w.sync();
-        tmp = 0;
-        for (int i = len - 10; i < len; ++i)
-            if (S.best[i] != -1 && S.base[i] != 4 && w.qual(i) > badq) ++tmp;
+        tmp = rc_popc64(w.ballot64(len - 10, len, [&](int q) { return S.best[q] != -1 && S.base[q] != 4 && w.qual(q) > badq; }));
         if (tmp >= 3)
-            for (int i = len - 10; i < len; ++i)
-                if (S.base[i] != 4) S.best[i] = -1;
+            w.for_lanes64(len - 10, len, [&](int q, int) {
+                if (S.base[q] != 4) S.best[q] = -1;
+            });
         w.sync();
     }
 
@@ -803,27 +954,34 @@ RC_HD void rc_kmer_info(W &w, rc_read_state &S, const rc_run_params &P, int ret,
     const int k = P.k;
     *l = *m = *h = 0;
     if (S.kcnt <= 0) return;
-    int nvalid = 0;
-    for (int i = w.lane; i < S.kcnt; i += W::STRIDE) {
-        bool valid = true, touched = false;
-        rc_kmer kc;
-        kc.code = 0;
-        kc.inv = -1;
-        for (int j = 0; j < k; ++j) {
-            int b = S.base[i + j];
-            if (b >= 4) valid = false;
-            if (ret > 0 && S.best[i + j] != -1) touched = true;
-            kc.code = (kc.code << 2) | (uint64_t)(b & 3);
-        }
-        int c = 2147483647;
-        if (valid) {
-            c = touched ? w.lookup(kc.code) : S.counts[i];
-            if (c == 0) c = 1;
-            ++nvalid;
-        }
-        S.v[i] = c;
+    // fixed positions (their base is now one of ACGT, so they leave the invalid mask)
+    const int nw = (S.len + 63) >> 6;
+    for (int c = 0; c <= nw; ++c) {
+        uint64_t fm = 0;
+        if (ret > 0) fm = w.ballot64(c << 6, S.len, [&](int q) { return S.best[q] != -1; });
+        S.m_x[c] = fm;
     }
-    nvalid = w.reduce_add(nvalid);
+    w.sync();
+    int nvalid = 0;
+    for (int b0 = 0; b0 < S.kcnt; b0 += 64) {
+        const uint64_t vm = w.ballot64(b0, S.kcnt, [&](int q) {
+            return (rc_window(S.m_inv, q, k) & ~rc_window(S.m_x, q, k)) == 0;
+        });
+        nvalid += rc_popc64(vm);
+        w.for_lanes64(b0, S.kcnt, [&](int q, int ln) {
+            int c = 2147483647;
+            if ((vm >> ln) & 1ull) {
+                if (ret > 0 && rc_window(S.m_x, q, k) != 0) {  // window holds a fix: probe the new k-mer
+                    uint64_t code = 0;
+                    for (int jj = 0; jj < k; ++jj) code = (code << 2) | (uint64_t)(S.base[q + jj] & 3);
+                    c = w.lookup(code);
+                } else
+                    c = S.counts[q];
+                if (c == 0) c = 1;
+            }
+            S.v[q] = c;
+        });
+    }
     w.sync();
     if (nvalid == 0) return;
     w.sort(S.v, S.kcnt);

@@ -38,6 +38,7 @@ struct rc_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool profile = false;
+    bool phase_prof = false;  // RC_PHASE_PROF=1: per-phase cycle accounting in k_correct (dev aid)
     rc_kernel_timer timers[RC_T_COUNT];
 
     rc_run_params P;

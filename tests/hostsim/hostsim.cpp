@@ -23,9 +23,25 @@ struct HostWave {
     long probes4 = 0, probes1 = 0, max_sp = 0;
 
     void sync() {}
+    void phase(int) {}
+    template <class F>
+    uint64_t ballot64(int base, int n, F pred)
+    {
+        uint64_t m = 0;
+        for (int l = 0; l < 64; ++l)
+            if (base + l < n && base + l >= 0 && pred(base + l)) m |= 1ull << l;
+        return m;
+    }
+    template <class F>
+    void for_lanes64(int base, int n, F body)
+    {
+        for (int l = 0; l < 64; ++l)
+            if (base + l < n) body(base + l, l);
+    }
     int reduce_add(int x) { return x; }
     int get(rc_kmer km)
     {
+        ++gets;
         rco_kmer q;
         q.code = km.code;
         q.inv = km.inv;
@@ -36,6 +52,7 @@ struct HostWave {
         ++probes4;
         for (int c = 0; c < 4; ++c) cnt[c] = get(rc_extend(km, k, dir, c));
     }
+    long gets = 0;
     int probe1(rc_kmer km)
     {
         ++probes1;
@@ -66,6 +83,8 @@ struct Buffers {
     std::vector<signed char> path, best;
     std::vector<rc_island> isl;
     std::vector<rc_segment> seg;
+    std::vector<uint64_t> ma, mt, mn, mi, mx, scode;
+    std::vector<int> scnt, sinv;
     rc_read_state S;
     explicit Buffers(int cap)
     {
@@ -80,6 +99,14 @@ struct Buffers {
         best.resize(cap);
         isl.resize(cap / 2 + 2);
         seg.resize(cap / 2 + 2);
+        ma.resize(cap / 64 + 2);
+        mt.resize(cap / 64 + 2);
+        mn.resize(cap / 64 + 2);
+        mi.resize(cap / 64 + 2);
+        mx.resize(cap / 64 + 2);
+        scode.resize(RC_SPEC);
+        scnt.resize(RC_SPEC * 4);
+        sinv.resize(RC_SPEC);
         S.base = base.data();
         S.strongb = strongb.data();
         S.polya = polya.data();
@@ -89,6 +116,14 @@ struct Buffers {
         S.best = best.data();
         S.isl = isl.data();
         S.seg = seg.data();
+        S.m_a = ma.data();
+        S.m_t = mt.data();
+        S.m_n = mn.data();
+        S.m_inv = mi.data();
+        S.m_x = mx.data();
+        S.spec_code = scode.data();
+        S.spec_cnt = scnt.data();
+        S.spec_inv = sinv.data();
     }
 };
 
@@ -104,13 +139,14 @@ int base_code(char c)
     }
 }
 
-void load_read(Buffers &B, const rco_params *p, const rco_table *t, const char *seq)
+void load_read(Buffers &B, HostWave &w, const rco_params *p, const rco_table *t, const char *seq)
 {
     int len = (int)strlen(seq);
     B.S.len = len;
     B.S.kcnt = len >= p->k ? len - p->k + 1 : 0;
     for (int i = 0; i < len; ++i) B.S.base[i] = (unsigned char)base_code(seq[i]);
     if (B.S.kcnt > 0) rco_kmer_counts(p, t, seq, B.S.counts);  // stands in for the probe kernel
+    rc_build_masks(w, B.S);
 }
 
 }  // namespace
@@ -141,7 +177,7 @@ void hostsim_correct_batch(const rco_params *p, const rco_table *t, rco_batch *b
     };
     // threshold kernel
     for (size_t r = 0; r < total; ++r) {
-        load_read(B, p, t, seq_of(r));
+        load_read(B, w, p, t, seq_of(r));
         int inf;
         strong[r] = rc_front_end(w, B.S, P, &inf);
         info[r] = inf;
@@ -149,7 +185,7 @@ void hostsim_correct_batch(const rco_params *p, const rco_table *t, rco_batch *b
     // correction kernel
     for (size_t r = 0; r < total; ++r) {
         char *seq = seq_of(r);
-        load_read(B, p, t, seq);
+        load_read(B, w, p, t, seq);
         w.qualp = qual_of(r);
         int pair_t = -1;
         if (b->mode == 1) {
@@ -175,7 +211,7 @@ void hostsim_correct_batch(const rco_params *p, const rco_table *t, rco_batch *b
         b->h[r] = h;
     }
     if (st) {
-        st->probes4 = w.probes4;
+        st->probes4 = w.gets;
         st->probes1 = w.probes1;
         st->max_stack = w.max_sp;
         st->reads = (long)total;
