@@ -24,7 +24,8 @@ class RcorrectorError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(HERE, "librcorrector_amd.so")
+    # RC_LIB lets a developer A/B a differently built library; the default is the in-tree build
+    return os.environ.get("RC_LIB") or os.path.join(HERE, "librcorrector_amd.so")
 
 
 def build_library(quiet=True):

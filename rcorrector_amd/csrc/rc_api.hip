@@ -443,7 +443,7 @@ int rc_correct_device(rc_ctx *ctx, const rc_device_batch *b)
     a.h = b->d_h;
     a.max_len = b->max_read_len;
     if ((rc = rc_launch_probe(ctx, b->d_seq, (size_t)b->nbytes, (int32_t *)ctx->counts.p))) return rc;
-    if ((rc = rc_launch_threshold(ctx, a))) return rc;
+    if (a.mode != 0 && (rc = rc_launch_threshold(ctx, a))) return rc;  // single-end: fused into k_correct
     if ((rc = rc_launch_correct(ctx, a))) return rc;
     return RC_OK;
 }

@@ -18,6 +18,7 @@ struct DevWaveT {
     unsigned long long t_last = 0;
     int cur_phase = 0;
     unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    __device__ __forceinline__ void stat(int, int) {}
     __device__ __forceinline__ void phase(int id)
     {
         if (PROF) {
@@ -32,7 +33,16 @@ struct DevWaveT {
     const uint8_t *qualp;
     rc_frame *stack;  // this wave's frames in HBM scratch
 
-    __device__ __forceinline__ void sync() { __syncthreads(); }  // 1-wave workgroup: LDS ordering only
+    // Lanes of ONE wave exchange data through LDS.  DS instructions of a wave execute in issue
+    // order, so no hardware wait is needed -- only the compiler must keep LDS accesses on their
+    // side of this point (a wavefront-scope fence; __syncthreads() would also drain every pending
+    // global load/store with s_waitcnt vmcnt(0), dozens of times per read).
+    __device__ __forceinline__ void sync()
+    {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
 
     // bit l of the result = pred(base + l) for base + l < n (one element per lane)
     template <class F>
@@ -83,38 +93,68 @@ struct DevWaveT {
 
     __device__ __forceinline__ int lookup(uint64_t code) { return rc_table_lookup(T, rc_canonical(code, k)); }
 
-    // ascending bitonic sort of a[0..n) in LDS; a[] has room for the next power of two
-    __device__ __forceinline__ void sort(int *a, int n)
+    // in-register bitonic network over E*64 elements (element g = e*64 + lane lives in x[e]):
+    // strides below 64 exchange through the lane crossbar, strides >= 64 between a lane's own
+    // registers.  No LDS traffic inside the network, ~5 VALU per compare-exchange.
+    template <int E>
+    __device__ __forceinline__ void bitonic_regs(int *a, int n)
     {
-        if (n <= 256) {
-            // rank sort: every lane counts, for each of its <= 4 elements, the elements that sort
-            // before it (value, then index); no barriers inside, all LDS reads are broadcasts
-            int x[4], r[4];
+        int x[E];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int i = lane + 64 * e;
-                x[e] = i < n ? a[i] : 2147483647;
-                r[e] = 0;
-            }
-            for (int j = 0; j < n; ++j) {
-                const int y = a[j];
+        for (int e = 0; e < E; ++e) {
+            const int g = e * 64 + lane;
+            x[e] = g < n ? a[g] : 2147483647;
+        }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int i = lane + 64 * e;
-                    r[e] += (y < x[e] || (y == x[e] && j < i)) ? 1 : 0;
+        for (int size = 2; size <= E * 64; size <<= 1) {
+#pragma unroll
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                if (stride >= 64) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        const int pe = e ^ (stride >> 6);
+                        if (pe > e) {
+                            const bool up = ((e * 64) & size) == 0;
+                            const int lo = x[e] < x[pe] ? x[e] : x[pe];
+                            const int hi = x[e] < x[pe] ? x[pe] : x[e];
+                            x[e] = up ? lo : hi;
+                            x[pe] = up ? hi : lo;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        const int g = e * 64 + lane;
+                        const int y = __shfl_xor(x[e], stride, 64);
+                        const bool up = (g & size) == 0;
+                        const bool lower = (lane & stride) == 0;
+                        const int lo = x[e] < y ? x[e] : y;
+                        const int hi = x[e] < y ? y : x[e];
+                        x[e] = (up == lower) ? lo : hi;
+                    }
                 }
             }
-            __syncthreads();
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (lane + 64 * e < n) a[r[e]] = x[e];
-            __syncthreads();
-            return;
         }
+        sync();
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int g = e * 64 + lane;
+            if (g < n) a[g] = x[e];
+        }
+        sync();
+    }
+
+    // ascending sort of a[0..n) in LDS (register network up to 256 elements, LDS bitonic above;
+    // a[] has room for the next power of two)
+    __device__ __forceinline__ void sort(int *a, int n)
+    {
+        if (n <= 64) return bitonic_regs<1>(a, n);
+        if (n <= 128) return bitonic_regs<2>(a, n);
+        if (n <= 256) return bitonic_regs<4>(a, n);
         int n2 = 1;
         while (n2 < n) n2 <<= 1;
         for (int i = n + lane; i < n2; i += 64) a[i] = 2147483647;
-        __syncthreads();
+        sync();
         for (int size = 2; size <= n2; size <<= 1) {
             for (int stride = size >> 1; stride > 0; stride >>= 1) {
                 for (int t = lane; t < (n2 >> 1); t += 64) {
@@ -127,7 +167,7 @@ struct DevWaveT {
                         a[par] = x;
                     }
                 }
-                __syncthreads();
+                sync();
             }
         }
     }
@@ -165,7 +205,7 @@ typedef DevWaveT<false> DevWave;
 
 struct rc_lds_layout {
     int cap, cap2;
-    size_t o_counts, o_v, o_isl, o_seg, o_base, o_path, o_best, o_strongb, o_polya, o_masks, o_spec, total;
+    size_t o_counts, o_v, o_isl, o_seg, o_base, o_path, o_best, o_strongb, o_polya, o_qual, o_masks, o_spec, total;
     int mask_words;
 };
 
@@ -182,7 +222,7 @@ static __host__ __device__ inline rc_lds_layout rc_layout(int cap)
     L.o_masks = o;
     o += (size_t)L.mask_words * 8 * 5;
     L.o_spec = o;
-    o += (size_t)RC_SPEC * (8 + 4 * 4 + 4);
+    o += (size_t)RC_SPEC * (8 + 4 * 4 + 4 + 4 * 4);
     L.o_counts = o;
     o += (size_t)cap * 4;
     L.o_v = o;
@@ -201,6 +241,8 @@ static __host__ __device__ inline rc_lds_layout rc_layout(int cap)
     o += cap;
     L.o_polya = o;
     o += cap;
+    L.o_qual = o;
+    o += cap;
     L.total = (o + 15) & ~(size_t)15;
     return L;
 }
@@ -216,6 +258,7 @@ __device__ __forceinline__ void rc_carve(uint8_t *lds, const rc_lds_layout &L, r
     S.best = reinterpret_cast<signed char *>(lds + L.o_best);
     S.strongb = lds + L.o_strongb;
     S.polya = lds + L.o_polya;
+    S.qual = reinterpret_cast<signed char *>(lds + L.o_qual);
     uint64_t *mm = reinterpret_cast<uint64_t *>(lds + L.o_masks);
     S.m_a = mm;
     S.m_t = mm + L.mask_words;
@@ -225,6 +268,10 @@ __device__ __forceinline__ void rc_carve(uint8_t *lds, const rc_lds_layout &L, r
     S.spec_code = reinterpret_cast<uint64_t *>(lds + L.o_spec);
     S.spec_cnt = reinterpret_cast<int *>(lds + L.o_spec + RC_SPEC * 8);
     S.spec_inv = S.spec_cnt + RC_SPEC * 4;
+    S.spec_ret = S.spec_inv + RC_SPEC;
+    S.spec_keep = S.spec_ret + RC_SPEC;
+    S.spec_thr = S.spec_keep + RC_SPEC;
+    S.spec_mask = S.spec_thr + RC_SPEC;
 }
 
 __device__ __forceinline__ int rc_base_code(uint32_t c)
@@ -257,7 +304,7 @@ struct rc_kernel_args {
 };
 
 template <class W>
-__device__ __forceinline__ void rc_load_read(W &w, const rc_kernel_args &A, rc_read_state &S, uint32_t r, int lane)
+__device__ __forceinline__ void rc_load_read(W &w, const rc_kernel_args &A, rc_read_state &S, uint32_t r, int lane, bool with_qual)
 {
     const uint32_t o = A.off[r];
     const int len = (int)(A.off[r + 1] - o) - 1;
@@ -266,8 +313,9 @@ __device__ __forceinline__ void rc_load_read(W &w, const rc_kernel_args &A, rc_r
     for (int i = lane; i < len; i += 64) {
         S.base[i] = (unsigned char)rc_base_code(A.seq[o + i]);
         S.counts[i] = i < S.kcnt ? A.counts[o + i] : 0;
+        if (with_qual) S.qual[i] = (signed char)A.qual[o + i];
     }
-    __syncthreads();
+    w.sync();
     rc_build_masks(w, S);
 }
 
@@ -284,19 +332,23 @@ __global__ __launch_bounds__(64) void k_threshold(rc_kernel_args A)
     w.qualp = nullptr;
     w.stack = nullptr;
     for (uint32_t r = blockIdx.x; r < A.n; r += gridDim.x) {
-        rc_load_read(w, A, S, r, w.lane);
+        rc_load_read(w, A, S, r, w.lane, false);
         int info;
         const int strong = rc_front_end(w, S, A.P, &info);
         if (w.lane == 0) {
             A.strong[r] = strong;
             A.info[r] = info;
         }
-        __syncthreads();
+        w.sync();
     }
 }
 
+#ifndef RC_K3_WAVES
+#define RC_K3_WAVES 6  // waves per SIMD the register allocation of k_correct is held to
+#endif
+
 template <bool PROF>
-__global__ __launch_bounds__(64) void k_correct(rc_kernel_args A)
+__global__ __launch_bounds__(64, RC_K3_WAVES) void k_correct(rc_kernel_args A)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const rc_lds_layout L = rc_layout(A.cap);
@@ -314,10 +366,17 @@ __global__ __launch_bounds__(64) void k_correct(rc_kernel_args A)
         r = (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
         if (r >= A.n) break;
         w.phase(0);
-        rc_load_read(w, A, S, r, w.lane);
+        rc_load_read(w, A, S, r, w.lane, true);
         const uint32_t o = A.off[r];
         w.qualp = A.qual + o;
-        const int strong0 = A.strong[r], info0 = A.info[r];
+        int strong0, info0;
+        if (A.mode == 0) {  // single-end: no mate to wait for, the threshold pass runs right here
+            w.phase(1);
+            strong0 = rc_front_end(w, S, A.P, &info0);
+        } else {
+            strong0 = A.strong[r];
+            info0 = A.info[r];
+        }
         int pair_t = -1;
         if (A.mode == 1) {
             const uint32_t half = A.n >> 1;
@@ -327,10 +386,10 @@ __global__ __launch_bounds__(64) void k_correct(rc_kernel_args A)
             pair_t = rc_min(strong0, A.strong[r ^ 1u]);
         }
         w.phase(1);
-        if (S.kcnt > 0 && !(info0 & 4)) rc_polya_flags(w, S, A.P.k);
+        if (A.mode != 0 && S.kcnt > 0 && !(info0 & 4)) rc_polya_flags(w, S, A.P.k);
         const int ret = rc_correct_read(w, S, A.P, pair_t, strong0, info0);
         w.phase(6);
-        __syncthreads();
+        w.sync();
         if (ret > 0) {
             for (int i = w.lane; i < S.len; i += 64) {
                 const int f = S.best[i];
@@ -339,7 +398,7 @@ __global__ __launch_bounds__(64) void k_correct(rc_kernel_args A)
                     S.base[i] = (unsigned char)f;
                 }
             }
-            __syncthreads();
+            w.sync();
         }
         int l, m, h;
         rc_kmer_info(w, S, A.P, ret, &l, &m, &h);
@@ -349,7 +408,7 @@ __global__ __launch_bounds__(64) void k_correct(rc_kernel_args A)
             A.m[r] = m;
             A.h[r] = h;
         }
-        __syncthreads();
+        w.sync();
         w.phase(7);
     }
     if (PROF && w.lane == 0) {
@@ -432,7 +491,7 @@ int rc_launch_correct(rc_ctx *ctx, const rc_device_batch_args &a)
     int rc = fill_args(ctx, a, A);
     if (rc) return rc;
     const rc_lds_layout L = rc_layout(A.cap);
-    unsigned grid = (unsigned)ctx->n_cu * 16u;
+    unsigned grid = (unsigned)ctx->n_cu * 4u * RC_K3_WAVES;
     if (grid > a.n) grid = a.n;
     A.stack_frames = A.cap + 64;
     rc = rc_dbuf_reserve(ctx, &ctx->stack, (size_t)grid * A.stack_frames * sizeof(rc_frame));

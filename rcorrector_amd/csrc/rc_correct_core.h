@@ -17,7 +17,7 @@
 //   w.probe4(km, dir, cnt)      counts of the four one-base extensions of km (lanes 0..3 probe)
 //   w.probe1(km)                count of one k-mer
 //   w.sort(a, n)                ascending in-LDS sort
-//   w.qual(i)                   quality character i of the read (HBM)
+//   (int)S.qual[i]                   quality character i of the read (HBM)
 //   w.stack_push/pop/top        search stack frames (HBM scratch)
 // The device back end is in rc_correct.hip; tests/hostsim has a lane-serial one (STRIDE = 1)
 // that lets the CPU test-suite diff this exact control flow against the oracle.
@@ -62,6 +62,7 @@ struct rc_read_state {
     signed char *best;      // [cap]   accepted fixes (the reference's fix[])
     unsigned char *strongb; // [cap]   isStrongTrusted per base
     unsigned char *polya;   // [cap]   bit0 IsPolyA(.,k,2), bit1 IsPolyA(.,k,max(7,k/2))
+    signed char *qual;      // [cap]   quality characters (only the vetoes read them)
     rc_island *isl;         // [cap/2+2]
     rc_segment *seg;        // [cap/2+2]
     // one bit per base (bit i%64 of word i/64), cap/64+1 words each, last word always 0
@@ -73,6 +74,10 @@ struct rc_read_state {
     int *spec_cnt;          // [RC_SPEC*4]
     uint64_t *spec_code;    // [RC_SPEC]
     int *spec_inv;          // [RC_SPEC]
+    int *spec_ret;          // [RC_SPEC] max(GetBound(max count),1) per cached node
+    int *spec_keep;         // [RC_SPEC] count of the keep-base extension (-1: base not ACGT)
+    int *spec_thr;          // [RC_SPEC] threshold of the node (InferPosThreshold)
+    int *spec_mask;         // [RC_SPEC] substitution candidates of the node
     int len, kcnt;
 };
 
@@ -274,8 +279,8 @@ RC_HD rc_kmer rc_extend(rc_kmer km, int k, int dir, int b)
 // iff their k-mer state equals the speculated one; anything else (a substitution, a jump, a
 // popped frame) misses and refills from there.  Pure memoisation: results cannot change.
 template <class W>
-RC_HD void rc_probe4_cached(W &w, rc_read_state &S, rc_spec_state &Z, rc_kmer kc, int dir, int pos, int to, int k,
-                            int cnt[4])
+RC_HD int rc_probe4_cached(W &w, rc_read_state &S, rc_spec_state &Z, rc_kmer kc, int dir, int pos, int to, int k,
+                           int cnt[4])
 {
     if (Z.n > 0 && Z.dir == dir) {
         const int j = (pos - Z.pos) * dir;
@@ -284,9 +289,10 @@ RC_HD void rc_probe4_cached(W &w, rc_read_state &S, rc_spec_state &Z, rc_kmer kc
             cnt[1] = S.spec_cnt[4 * j + 1];
             cnt[2] = S.spec_cnt[4 * j + 2];
             cnt[3] = S.spec_cnt[4 * j + 3];
-            return;
+            return j;
         }
     }
+    w.stat(3, 1);
     int n = dir > 0 ? (to - pos) : (pos - to + 1);  // nodes left on this side of the segment end
     if (n > RC_SPEC) n = RC_SPEC;
     if (n < 1) n = 1;
@@ -309,6 +315,7 @@ RC_HD void rc_probe4_cached(W &w, rc_read_state &S, rc_spec_state &Z, rc_kmer kc
     cnt[1] = S.spec_cnt[1];
     cnt[2] = S.spec_cnt[2];
     cnt[3] = S.spec_cnt[3];
+    return 0;
 }
 
 // terminal bookkeeping, ErrorCorrection.cpp:243-284 / :483-523
@@ -347,6 +354,123 @@ RC_HD void rc_search_terminal(W &w, rc_read_state &S, rc_search_ctx &C, int pos,
     } else if (fix_cnt == C.max_fix_cnt && bottleneck == C.best_bottleneck) {
         C.best_fix_cnt += 1;
     }
+}
+
+// InferPosThreshold's clamp (ErrorCorrection.cpp:165-172) given ret = max(GetBound(max),1)
+RC_HD int rc_clamp_threshold(int ret, int upper)
+{
+    if (upper > ret || upper <= 0) return ret;
+    return upper;
+}
+
+// Keep-run fast path.  The cache holds the extension counts of nodes j0 .. Z.n-1 of the keep-base
+// path that starts at the current node.  As long as a node's first child is "keep the base"
+// (:302-312 / :539-549) the descent does nothing but: compute the node's threshold, remember a
+// frame if substitution candidates exist, set fix[pos] = -1, lower the bottleneck, move on.  All of
+// that is evaluated for every cached node at once (one lane per node); the number of leading
+// nodes that really keep their base is read off a ballot.  Returns that number R and updates the
+// current node to the node where the run stops (whose counts are still cached if R < Z.n - j0).
+template <class W>
+RC_HD int rc_keep_run(W &w, rc_read_state &S, const rc_run_params &P, const rc_spec_state &Z, int j0, int dir, rc_kmer &kc,
+                      int &pos, int &t, int fix_cnt, int &bottleneck, int &sp)
+{
+    const int k = P.k;
+    const int n = Z.n;
+    // per node: ret and the keep-base count
+    w.for_lanes64(j0, n, [&](int jj, int) {
+        const int c0 = S.spec_cnt[4 * jj], c1 = S.spec_cnt[4 * jj + 1], c2 = S.spec_cnt[4 * jj + 2], c3 = S.spec_cnt[4 * jj + 3];
+        int mx = 0;
+        mx = c0 > mx ? c0 : mx;
+        mx = c1 > mx ? c1 : mx;
+        mx = c2 > mx ? c2 : mx;
+        mx = c3 > mx ? c3 : mx;
+        int ret = rc_bound_i(mx, P.error_rate);
+        if (ret < 1) ret = 1;
+        S.spec_ret[jj] = ret;
+        const int b = S.base[Z.pos + dir * jj];
+        int kc2 = -1;
+        kc2 = b == 0 ? c0 : kc2;
+        kc2 = b == 1 ? c1 : kc2;
+        kc2 = b == 2 ? c2 : kc2;
+        kc2 = b == 3 ? c3 : kc2;
+        S.spec_keep[jj] = kc2;
+    });
+    w.sync();
+    // thresholds: right passes t unchanged, left hands the node's threshold down as the next t (:546)
+    w.for_lanes64(j0, n, [&](int jj, int) {
+        int thr;
+        if (dir > 0) {
+            thr = rc_clamp_threshold(S.spec_ret[jj], t);
+        } else {
+            int tt = t;
+            for (int i = j0; i <= jj; ++i) tt = rc_clamp_threshold(S.spec_ret[i], tt);
+            thr = tt;
+        }
+        S.spec_thr[jj] = thr;
+    });
+    w.sync();
+    const uint64_t okm = w.ballot64(j0, n, [&](int jj) { return S.spec_keep[jj] >= S.spec_thr[jj]; });
+    // leading ones of okm
+    const uint64_t notok = ~okm;
+    int R = notok ? rc_ctz64(notok) : 64;
+    if (R > n - j0) R = n - j0;
+    w.stat(0, 1);
+    w.stat(1, R);
+    w.stat(2, n - j0);
+    if (R == 0) return 0;
+    // substitution candidates of the kept nodes, fix[pos] = -1
+    const uint64_t fm = w.ballot64(j0, j0 + R, [&](int jj) {
+        const int p2 = Z.pos + dir * jj;
+        const int b = S.base[p2];
+        const int pa = dir > 0 ? S.polya[p2 - k + 1] : S.polya[p2];
+        int m2 = 0;
+        if (!S.strongb[p2] && !(pa & 1)) {
+            const int thr = S.spec_thr[jj];
+            for (int c = 0; c < 4; ++c)
+                if (c != b && S.spec_cnt[4 * jj + c] >= thr) m2 |= 1 << c;
+        }
+        S.spec_mask[jj] = m2;
+        S.path[p2] = -1;
+        return m2 != 0;
+    });
+    w.sync();
+    // frames for the branch points, in path order
+    uint64_t f2 = fm;
+    while (f2) {
+        const int jj = j0 + rc_ctz64(f2);
+        f2 &= f2 - 1;
+        rc_frame f;
+        f.code = S.spec_code[jj];
+        f.inv = S.spec_inv[jj];
+        f.pos = Z.pos + dir * jj;
+        f.t = (dir > 0 || jj == j0) ? t : S.spec_thr[jj - 1];
+        f.threshold = S.spec_thr[jj];
+        f.fix_cnt = fix_cnt;
+        int bb = bottleneck;
+        for (int i = j0; i < jj; ++i) bb = rc_min(bb, S.spec_keep[i]);
+        f.bottleneck = bb;
+        for (int c = 0; c < 4; ++c) f.cnt[c] = S.spec_cnt[4 * jj + c];
+        f.mask = S.spec_mask[jj];
+        w.stack_push(sp, f);
+        ++sp;
+    }
+    // the node the run stops at
+    const int idx = j0 + R;
+    int bb = bottleneck;
+    for (int i = j0; i < idx; ++i) bb = rc_min(bb, S.spec_keep[i]);
+    bottleneck = bb;
+    if (dir < 0) t = S.spec_thr[idx - 1];
+    if (idx < n) {
+        kc.code = S.spec_code[idx];
+        kc.inv = S.spec_inv[idx];
+    } else {
+        rc_kmer last;
+        last.code = S.spec_code[idx - 1];
+        last.inv = S.spec_inv[idx - 1];
+        kc = rc_extend(last, k, dir, S.base[Z.pos + dir * (idx - 1)]);
+    }
+    pos = Z.pos + dir * idx;
+    return R;
 }
 
 // one SearchPaths_Right/_Left call tree (ErrorCorrection.cpp:201-442 / :444-678), depth-first
@@ -418,7 +542,12 @@ RC_HD void rc_search(W &w, rc_read_state &S, const rc_run_params &P, rc_search_c
         }
 
         int cnt[4];
-        rc_probe4_cached(w, S, Z, kc, dir, pos, C.to, k, cnt);
+        const int j0 = rc_probe4_cached(w, S, Z, kc, dir, pos, C.to, k, cnt);
+        // descend along "keep the base" for as many cached nodes as take that branch
+        if (rc_keep_run(w, S, P, Z, j0, dir, kc, pos, t, fix_cnt, bottleneck, sp) > 0) {
+            have = true;
+            continue;
+        }
         int threshold = rc_pos_threshold(cnt, t, P.error_rate);  // :287 / :525
         const int b = S.base[pos];
         const bool bvalid = b < 4;
@@ -445,13 +574,30 @@ RC_HD void rc_search(W &w, rc_read_state &S, const rc_run_params &P, rc_search_c
                 nbott = rc_min(bottleneck, c0);
                 first = true;
             } else if (threshold == 1 && t <= 2) {  // accidental gap, :313-338 / :550-573
+                // the reference extends one base at a time until the count recovers, giving up after
+                // k probes (the k-th probe's answer is never used) or at the segment end.  All
+                // candidate windows are probed in one gather round; the first hit is the one the
+                // sequential loop would have stopped at.
                 rc_kmer tmp = rc_extend(kc, k, dir, b);
-                int steps = 0, i = pos, c1 = c0;
-                for (; c1 < threshold && steps < k; ++steps) {
-                    i += dir;
-                    if (dir > 0 ? (i >= C.to) : (i < C.to)) break;
-                    tmp = rc_extend(tmp, k, dir, S.base[i]);
-                    c1 = w.probe1(tmp);
+                int m = dir > 0 ? (C.to - 1 - pos) : (pos - C.to);  // positions left in range
+                if (m > k - 1) m = k - 1;
+                int steps = k, i = pos;
+                (void)c0;
+                if (m > 0) {
+                    const rc_kmer tmp0 = tmp;
+                    const uint64_t hit = w.ballot64(1, m + 1, [&](int sN) {
+                        rc_kmer tq = tmp0;
+                        for (int u = 1; u <= sN; ++u) tq = rc_extend(tq, k, dir, S.base[pos + dir * u]);
+                        return w.get(tq) >= threshold;
+                    });
+                    w.stat(4, 1);
+                    w.stat(5, m);
+                    if (hit) {
+                        const int sN = 1 + rc_ctz64(hit);
+                        for (int u = 1; u <= sN; ++u) tmp = rc_extend(tmp, k, dir, S.base[pos + dir * u]);
+                        i = pos + dir * sN;
+                        steps = sN;
+                    }
                 }
                 if (steps < k && (dir > 0 ? (i < C.to) : (i >= C.to))) {
                     int lo = dir > 0 ? pos : i, hi = dir > 0 ? i : pos;
@@ -848,10 +994,10 @@ RC_HD int rc_correct_read(W &w, rc_read_state &S, const rc_run_params &P, int pa
     }
     w.sync();
     const int badq = P.bad_qual;
-    const int q0 = w.qual(0);
+    const int q0 = (int)S.qual[0];
     for (int i = 1; i < cnt; ++i) {  // pairwise veto, :1314-1398
         const int pi = S.v[i], pp = S.v[i - 1];
-        if (q0 != 0 && (w.qual(pi) <= badq && w.qual(pp) <= badq)) continue;
+        if (q0 != 0 && ((int)S.qual[pi] <= badq && (int)S.qual[pp] <= badq)) continue;
         if (pi - pp + 1 <= k) {
             int min_single = RC_INF, min_double = RC_INF, taga = -1, tagb = -1;
             const int pprev = i >= 2 ? S.v[i - 2] : -1;
@@ -907,13 +1053,13 @@ RC_HD int rc_correct_read(W &w, rc_read_state &S, const rc_run_params &P, int pa
     }
 
     if (total_fix > 3 && len > 10) {  // end-of-read veto, :1407-1430
-        int tmp = rc_popc64(w.ballot64(0, 10, [&](int q) { return S.best[q] != -1 && S.base[q] != 4 && w.qual(q) > badq; }));
+        int tmp = rc_popc64(w.ballot64(0, 10, [&](int q) { return S.best[q] != -1 && S.base[q] != 4 && (int)S.qual[q] > badq; }));
         if (tmp >= 2)
             w.for_lanes64(0, 10, [&](int q, int) {
                 if (S.base[q] != 4) S.best[q] = -1;
             });
         w.sync();
-        tmp = rc_popc64(w.ballot64(len - 10, len, [&](int q) { return S.best[q] != -1 && S.base[q] != 4 && w.qual(q) > badq; }));
+        tmp = rc_popc64(w.ballot64(len - 10, len, [&](int q) { return S.best[q] != -1 && S.base[q] != 4 && (int)S.qual[q] > badq; }));
         if (tmp >= 3)
             w.for_lanes64(len - 10, len, [&](int q, int) {
                 if (S.base[q] != 4) S.best[q] = -1;
@@ -926,7 +1072,7 @@ RC_HD int rc_correct_read(W &w, rc_read_state &S, const rc_run_params &P, int pa
         int acc = 0;
         S.v[0] = 0;
         for (int i = 0; i < len; ++i) {
-            if (S.base[i] != 4 && S.best[i] != -1) acc += (w.qual(i) > badq) ? 2 : 1;
+            if (S.base[i] != 4 && S.best[i] != -1) acc += ((int)S.qual[i] > badq) ? 2 : 1;
             S.v[i + 1] = acc;
         }
         w.sync();

@@ -5,6 +5,8 @@
 // table as the probe target, and diffed against the oracle by tests/test_hostsim.py.  Nothing in
 // the product path links this file.
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -24,6 +26,8 @@ struct HostWave {
 
     void sync() {}
     void phase(int) {}
+    long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    void stat(int i, int v) { stats[i] += v; }
     template <class F>
     uint64_t ballot64(int base, int n, F pred)
     {
@@ -80,11 +84,11 @@ struct HostWave {
 struct Buffers {
     std::vector<unsigned char> base, strongb, polya;
     std::vector<int> counts, v;
-    std::vector<signed char> path, best;
+    std::vector<signed char> path, best, qualv;
     std::vector<rc_island> isl;
     std::vector<rc_segment> seg;
     std::vector<uint64_t> ma, mt, mn, mi, mx, scode;
-    std::vector<int> scnt, sinv;
+    std::vector<int> scnt, sinv, sret, skeep, sthr, smask;
     rc_read_state S;
     explicit Buffers(int cap)
     {
@@ -97,6 +101,8 @@ struct Buffers {
         v.resize(cap2);
         path.resize(cap);
         best.resize(cap);
+        qualv.resize(cap);
+        S.qual = qualv.data();
         isl.resize(cap / 2 + 2);
         seg.resize(cap / 2 + 2);
         ma.resize(cap / 64 + 2);
@@ -107,6 +113,10 @@ struct Buffers {
         scode.resize(RC_SPEC);
         scnt.resize(RC_SPEC * 4);
         sinv.resize(RC_SPEC);
+        sret.resize(RC_SPEC);
+        skeep.resize(RC_SPEC);
+        sthr.resize(RC_SPEC);
+        smask.resize(RC_SPEC);
         S.base = base.data();
         S.strongb = strongb.data();
         S.polya = polya.data();
@@ -124,6 +134,10 @@ struct Buffers {
         S.spec_code = scode.data();
         S.spec_cnt = scnt.data();
         S.spec_inv = sinv.data();
+        S.spec_ret = sret.data();
+        S.spec_keep = skeep.data();
+        S.spec_thr = sthr.data();
+        S.spec_mask = smask.data();
     }
 };
 
@@ -187,6 +201,7 @@ void hostsim_correct_batch(const rco_params *p, const rco_table *t, rco_batch *b
         char *seq = seq_of(r);
         load_read(B, w, p, t, seq);
         w.qualp = qual_of(r);
+        for (int i = 0; i < B.S.len; ++i) B.S.qual[i] = (signed char)w.qualp[i];
         int pair_t = -1;
         if (b->mode == 1) {
             size_t mate = r < b->n ? r + b->n : r - b->n;
@@ -214,6 +229,7 @@ void hostsim_correct_batch(const rco_params *p, const rco_table *t, rco_batch *b
         st->probes4 = w.gets;
         st->probes1 = w.probes1;
         st->max_stack = w.max_sp;
+        if (getenv("HOSTSIM_STATS")) fprintf(stderr, "keep_run calls=%ld sumR=%ld sum_avail=%ld refills=%ld gap_attempts=%ld gap_probes=%ld reads=%ld\n", w.stats[0], w.stats[1], w.stats[2], w.stats[3], w.stats[4], w.stats[5], (long)total);
         st->reads = (long)total;
     }
 }

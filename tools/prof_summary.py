@@ -40,15 +40,20 @@ def main():
             return
         acc = defaultdict(lambda: [0, 0.0])
         for r in csv.DictReader(open(f)):
-            kn = short(r["Kernel_Name"])
+            kn = short(r["Kernel_Name"]).replace("void ", "")
             if not (kn.startswith("k_") or "rc_" in kn):
                 continue
             a = acc[(kn, r["Counter_Name"])]
+            v = float(r["Counter_Value"])
             a[0] += 1
-            a[1] += float(r["Counter_Value"])
-        print("%-40s %-28s %10s %20s %20s" % ("kernel", "counter", "dispatches", "mean", "sum"))
-        for (kn, cn), (n, s) in sorted(acc.items()):
-            print("%-40s %-28s %10d %20.1f %20.1f" % (kn, cn, n, s / n, s))
+            a[1] += v
+            if len(a) < 3:
+                a.append(v)
+            else:
+                a[2] = max(a[2], v)
+        print("%-40s %-28s %10s %20s %20s" % ("kernel", "counter", "dispatches", "largest dispatch", "sum"))
+        for (kn, cn), (n, s, mx) in sorted(acc.items()):
+            print("%-40s %-28s %10d %20.1f %20.1f" % (kn, cn, n, mx, s))
 
 
 if __name__ == "__main__":
