@@ -19,6 +19,13 @@ struct DevWaveT {
     int cur_phase = 0;
     unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     __device__ __forceinline__ void stat(int, int) {}
+    __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+    __device__ __forceinline__ uint64_t uni64(uint64_t x)
+    {
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32));
+        return ((uint64_t)hi << 32) | lo;
+    }
     __device__ __forceinline__ void phase(int id)
     {
         if (PROF) {
@@ -65,7 +72,7 @@ struct DevWaveT {
     {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
-        return x;
+        return __builtin_amdgcn_readfirstlane(x);
     }
 
     __device__ __forceinline__ int get(rc_kmer km)
@@ -182,18 +189,18 @@ struct DevWaveT {
     __device__ __forceinline__ void stack_top(int idx, rc_frame &f)
     {
         const volatile rc_frame *p = stack + idx;
-        f.code = p->code;
-        f.inv = p->inv;
-        f.pos = p->pos;
-        f.t = p->t;
-        f.threshold = p->threshold;
-        f.fix_cnt = p->fix_cnt;
-        f.bottleneck = p->bottleneck;
-        f.cnt[0] = p->cnt[0];
-        f.cnt[1] = p->cnt[1];
-        f.cnt[2] = p->cnt[2];
-        f.cnt[3] = p->cnt[3];
-        f.mask = p->mask;
+        f.code = uni64(p->code);
+        f.inv = __builtin_amdgcn_readfirstlane(p->inv);
+        f.pos = __builtin_amdgcn_readfirstlane(p->pos);
+        f.t = __builtin_amdgcn_readfirstlane(p->t);
+        f.threshold = __builtin_amdgcn_readfirstlane(p->threshold);
+        f.fix_cnt = __builtin_amdgcn_readfirstlane(p->fix_cnt);
+        f.bottleneck = __builtin_amdgcn_readfirstlane(p->bottleneck);
+        f.cnt[0] = __builtin_amdgcn_readfirstlane(p->cnt[0]);
+        f.cnt[1] = __builtin_amdgcn_readfirstlane(p->cnt[1]);
+        f.cnt[2] = __builtin_amdgcn_readfirstlane(p->cnt[2]);
+        f.cnt[3] = __builtin_amdgcn_readfirstlane(p->cnt[3]);
+        f.mask = __builtin_amdgcn_readfirstlane(p->mask);
     }
     __device__ __forceinline__ void stack_set_mask(int idx, int mask)
     {
@@ -343,6 +350,9 @@ __global__ __launch_bounds__(64) void k_threshold(rc_kernel_args A)
     }
 }
 
+#ifndef RC_DEQUEUE
+#define RC_DEQUEUE 8  // reads per work-counter atomic
+#endif
 #ifndef RC_K3_WAVES
 #define RC_K3_WAVES 6  // waves per SIMD the register allocation of k_correct is held to
 #endif
@@ -360,11 +370,19 @@ __global__ __launch_bounds__(64, RC_K3_WAVES) void k_correct(rc_kernel_args A)
     w.T = A.T;
     w.k = A.P.k;
     w.stack = A.stack + (size_t)blockIdx.x * A.stack_frames;
+    // work distribution: the reference's mutex-protected counter (ErrorCorrection.cpp:87-90), taken
+    // RC_DEQUEUE reads at a time -- one device-scope atomic word sustains only ~88 dequeues/us on
+    // MI355X, which at one read per dequeue would cap the kernel at ~88 M reads/s by itself
+    uint32_t chunk_lo = 0, chunk_hi = 0;
     for (;;) {
-        uint32_t r = 0;
-        if (w.lane == 0) r = atomicAdd(A.work, 1u);
-        r = (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
-        if (r >= A.n) break;
+        if (chunk_lo >= chunk_hi) {
+            uint32_t r0 = 0;
+            if (w.lane == 0) r0 = atomicAdd(A.work, (uint32_t)RC_DEQUEUE);
+            chunk_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)r0);
+            if (chunk_lo >= A.n) break;
+            chunk_hi = chunk_lo + RC_DEQUEUE < A.n ? chunk_lo + RC_DEQUEUE : A.n;
+        }
+        const uint32_t r = chunk_lo++;
         w.phase(0);
         rc_load_read(w, A, S, r, w.lane, true);
         const uint32_t o = A.off[r];

@@ -145,6 +145,12 @@ RC_HD void rc_build_masks(W &w, rc_read_state &S)
 
 RC_HD int rc_min(int a, int b) { return a < b ? a : b; }
 
+// A value every lane of the wave agrees on, read from LDS: RC_U moves it to a scalar register on
+// the device (v_readfirstlane) so that everything computed from it -- k-mer shifts, compares,
+// branches -- runs on the scalar unit instead of occupying the vector ALU 64 lanes wide.
+#define RC_U(x) (w.uni((int)(x)))
+#define RC_U64(x) (w.uni64((uint64_t)(x)))
+
 // ---- front end ---------------------------------------------------------------------------------
 // screens of ErrorCorrection.cpp:735-755 (=:1507-1527); returns 1 if the read is rejected
 template <class W>
@@ -200,8 +206,8 @@ RC_HD int rc_initial_strong(W &w, const rc_read_state &S, int *found, int *prev)
         if (m) {
             const int i = b0 + 63 - rc_clz64(m);
             *found = 1;
-            *prev = S.v[i - 1];
-            return S.v[i];
+            *prev = RC_U(S.v[i - 1]);
+            return RC_U(S.v[i]);
         }
     }
     *found = 0;
@@ -214,7 +220,7 @@ RC_HD int rc_initial_strong(W &w, const rc_read_state &S, int *found, int *prev)
             break;
         }
     }
-    return S.v[(i + kcnt - 1) / 2];
+    return RC_U(S.v[(i + kcnt - 1) / 2]);
 }
 
 // GetStrongTrustedThreshold (ErrorCorrection.cpp:1482-1565).  Requires base[], counts[],
@@ -284,11 +290,11 @@ RC_HD int rc_probe4_cached(W &w, rc_read_state &S, rc_spec_state &Z, rc_kmer kc,
 {
     if (Z.n > 0 && Z.dir == dir) {
         const int j = (pos - Z.pos) * dir;
-        if (j >= 0 && j < Z.n && S.spec_code[j] == kc.code && S.spec_inv[j] == kc.inv) {
-            cnt[0] = S.spec_cnt[4 * j + 0];
-            cnt[1] = S.spec_cnt[4 * j + 1];
-            cnt[2] = S.spec_cnt[4 * j + 2];
-            cnt[3] = S.spec_cnt[4 * j + 3];
+        if (j >= 0 && j < Z.n && RC_U64(S.spec_code[j]) == kc.code && RC_U(S.spec_inv[j]) == kc.inv) {
+            cnt[0] = RC_U(S.spec_cnt[4 * j + 0]);
+            cnt[1] = RC_U(S.spec_cnt[4 * j + 1]);
+            cnt[2] = RC_U(S.spec_cnt[4 * j + 2]);
+            cnt[3] = RC_U(S.spec_cnt[4 * j + 3]);
             return j;
         }
     }
@@ -311,10 +317,10 @@ RC_HD int rc_probe4_cached(W &w, rc_read_state &S, rc_spec_state &Z, rc_kmer kc,
     Z.n = n;
     Z.pos = pos;
     Z.dir = dir;
-    cnt[0] = S.spec_cnt[0];
-    cnt[1] = S.spec_cnt[1];
-    cnt[2] = S.spec_cnt[2];
-    cnt[3] = S.spec_cnt[3];
+    cnt[0] = RC_U(S.spec_cnt[0]);
+    cnt[1] = RC_U(S.spec_cnt[1]);
+    cnt[2] = RC_U(S.spec_cnt[2]);
+    cnt[3] = RC_U(S.spec_cnt[3]);
     return 0;
 }
 
@@ -440,34 +446,34 @@ RC_HD int rc_keep_run(W &w, rc_read_state &S, const rc_run_params &P, const rc_s
         const int jj = j0 + rc_ctz64(f2);
         f2 &= f2 - 1;
         rc_frame f;
-        f.code = S.spec_code[jj];
-        f.inv = S.spec_inv[jj];
+        f.code = RC_U64(S.spec_code[jj]);
+        f.inv = RC_U(S.spec_inv[jj]);
         f.pos = Z.pos + dir * jj;
-        f.t = (dir > 0 || jj == j0) ? t : S.spec_thr[jj - 1];
-        f.threshold = S.spec_thr[jj];
+        f.t = (dir > 0 || jj == j0) ? t : RC_U(S.spec_thr[jj - 1]);
+        f.threshold = RC_U(S.spec_thr[jj]);
         f.fix_cnt = fix_cnt;
         int bb = bottleneck;
-        for (int i = j0; i < jj; ++i) bb = rc_min(bb, S.spec_keep[i]);
+        for (int i = j0; i < jj; ++i) bb = rc_min(bb, RC_U(S.spec_keep[i]));
         f.bottleneck = bb;
-        for (int c = 0; c < 4; ++c) f.cnt[c] = S.spec_cnt[4 * jj + c];
-        f.mask = S.spec_mask[jj];
+        for (int c = 0; c < 4; ++c) f.cnt[c] = RC_U(S.spec_cnt[4 * jj + c]);
+        f.mask = RC_U(S.spec_mask[jj]);
         w.stack_push(sp, f);
         ++sp;
     }
     // the node the run stops at
     const int idx = j0 + R;
     int bb = bottleneck;
-    for (int i = j0; i < idx; ++i) bb = rc_min(bb, S.spec_keep[i]);
+    for (int i = j0; i < idx; ++i) bb = rc_min(bb, RC_U(S.spec_keep[i]));
     bottleneck = bb;
-    if (dir < 0) t = S.spec_thr[idx - 1];
+    if (dir < 0) t = RC_U(S.spec_thr[idx - 1]);
     if (idx < n) {
-        kc.code = S.spec_code[idx];
-        kc.inv = S.spec_inv[idx];
+        kc.code = RC_U64(S.spec_code[idx]);
+        kc.inv = RC_U(S.spec_inv[idx]);
     } else {
         rc_kmer last;
-        last.code = S.spec_code[idx - 1];
-        last.inv = S.spec_inv[idx - 1];
-        kc = rc_extend(last, k, dir, S.base[Z.pos + dir * (idx - 1)]);
+        last.code = RC_U64(S.spec_code[idx - 1]);
+        last.inv = RC_U(S.spec_inv[idx - 1]);
+        kc = rc_extend(last, k, dir, RC_U(S.base[Z.pos + dir * (idx - 1)]));
     }
     pos = Z.pos + dir * idx;
     return R;
@@ -514,7 +520,7 @@ RC_HD void rc_search(W &w, rc_read_state &S, const rc_run_params &P, rc_search_c
             kc = rc_extend(fk, k, dir, c);
             pos = f.pos + dir;
             t = dir > 0 ? f.t : f.threshold;
-            fix_cnt = f.fix_cnt + (S.base[f.pos] < 4 ? 1 : 0);
+            fix_cnt = f.fix_cnt + (RC_U(S.base[f.pos]) < 4 ? 1 : 0);
             bottleneck = rc_min(f.bottleneck, rc_sel4(f.cnt, c));
             have = true;
         }
@@ -549,13 +555,13 @@ RC_HD void rc_search(W &w, rc_read_state &S, const rc_run_params &P, rc_search_c
             continue;
         }
         int threshold = rc_pos_threshold(cnt, t, P.error_rate);  // :287 / :525
-        const int b = S.base[pos];
+        const int b = RC_U(S.base[pos]);
         const bool bvalid = b < 4;
 
         int mask = 0;  // substitution candidates, :343-352 / :577-588
         {
-            const int pa = dir > 0 ? S.polya[pos - k + 1] : S.polya[pos];
-            if (!S.strongb[pos] && !(pa & 1)) {
+            const int pa = RC_U(dir > 0 ? S.polya[pos - k + 1] : S.polya[pos]);
+            if (!RC_U(S.strongb[pos]) && !(pa & 1)) {
                 for (int c = 0; c < 4; ++c)
                     if (c != b && cnt[c] >= threshold) mask |= 1 << c;
             }
@@ -594,7 +600,7 @@ RC_HD void rc_search(W &w, rc_read_state &S, const rc_run_params &P, rc_search_c
                     w.stat(5, m);
                     if (hit) {
                         const int sN = 1 + rc_ctz64(hit);
-                        for (int u = 1; u <= sN; ++u) tmp = rc_extend(tmp, k, dir, S.base[pos + dir * u]);
+                        for (int u = 1; u <= sN; ++u) tmp = rc_extend(tmp, k, dir, RC_U(S.base[pos + dir * u]));
                         i = pos + dir * sN;
                         steps = sN;
                     }
@@ -653,7 +659,7 @@ RC_HD void rc_search(W &w, rc_read_state &S, const rc_run_params &P, rc_search_c
                     } else
                         rc_probe4_cached(w, S, Z, tmp, dir, i, C.to, k, cn);
                     thr = rc_pos_threshold(cn, t, P.error_rate);
-                    int bb = S.base[i];
+                    int bb = RC_U(S.base[i]);
                     tmp = rc_append(tmp, k, bb);
                     c1 = (bb < 4) ? rc_sel4(cn, bb) : 0;
                     S.path[i] = -1;
@@ -673,7 +679,7 @@ RC_HD void rc_search(W &w, rc_read_state &S, const rc_run_params &P, rc_search_c
                     } else
                         rc_probe4_cached(w, S, Z, tmp, dir, i, C.to, k, cn);
                     thr = rc_pos_threshold(cn, t, P.error_rate);
-                    int bb = S.base[i];
+                    int bb = RC_U(S.base[i]);
                     tmp = rc_prepend(tmp, k, bb);
                     c1 = (bb < 4) ? rc_sel4(cn, bb) : 0;
                     S.path[i] = -1;
@@ -708,7 +714,7 @@ RC_HD rc_kmer rc_anchor(W &w, const rc_read_state &S, int k, int a)
     rc_kmer kc;
     kc.code = 0;
     kc.inv = -1;
-    for (int i = a; i < a + k; ++i) kc = rc_append(kc, k, S.base[i]);
+    for (int i = a; i < a + k; ++i) kc = rc_append(kc, k, RC_U(S.base[i]));
     return kc;
 }
 
@@ -769,9 +775,9 @@ RC_HD int rc_correct_read(W &w, rc_read_state &S, const rc_run_params &P, int pa
             int *re = S.v + (kcnt + 1) / 2 + 1; // run ends
             int ns = 0, ne = 0;
             for (int c = 0; c < nwk; ++c) {
-                const uint64_t T = S.m_x[c];
-                const uint64_t prev = c ? (S.m_x[c - 1] >> 63) : 0ull;
-                const uint64_t next = S.m_x[c + 1] & 1ull;
+                const uint64_t T = RC_U64(S.m_x[c]);
+                const uint64_t prev = c ? (RC_U64(S.m_x[c - 1]) >> 63) : 0ull;
+                const uint64_t next = RC_U64(S.m_x[c + 1]) & 1ull;
                 uint64_t st = T & ~((T << 1) | prev);
                 uint64_t en = T & ~((T >> 1) | (next << 63));
                 while (st) {
@@ -784,13 +790,13 @@ RC_HD int rc_correct_read(W &w, rc_read_state &S, const rc_run_params &P, int pa
                 }
             }
             w.sync();
-            if (!(S.m_x[0] & 1ull)) {  // first k-mer untrusted: the scan records a run of length 0 first
+            if (!(RC_U64(S.m_x[0]) & 1ull)) {  // first k-mer untrusted: the scan records a run of length 0 first
                 longest = 0;
                 tstart = 0;
                 tend = -1;
             }
             for (int r = 0; r < ns; ++r) {
-                const int f = rs[r], t2 = re[r];
+                const int f = RC_U(rs[r]), t2 = RC_U(re[r]);
                 j = t2 - f + 1;
                 if (j > longest) {
                     longest = j;
@@ -808,7 +814,7 @@ RC_HD int rc_correct_read(W &w, rc_read_state &S, const rc_run_params &P, int pa
 
         // boundary adjustment, :934-965
         for (i = 1; i < isl_cnt; ++i) {
-            int pf = S.isl[i - 1].from, pt = S.isl[i - 1].to, cf = S.isl[i].from, ct = S.isl[i].to;
+            int pf = RC_U(S.isl[i - 1].from), pt = RC_U(S.isl[i - 1].to), cf = RC_U(S.isl[i].from), ct = RC_U(S.isl[i].to);
             if (cf <= pt + k) {
                 int len1 = pt - pf, len2 = ct - cf, overlap = pt + k - cf;
                 // is there a k-mer strictly between with counts <= 2 && counts < trust?  (gap < k <= 32)
@@ -828,7 +834,7 @@ RC_HD int rc_correct_read(W &w, rc_read_state &S, const rc_run_params &P, int pa
         {
             int nb = 0, cura = 0, curb = -2;
             for (i = 0; i < isl_cnt; ++i) {
-                const int f = S.isl[i].from, tt = S.isl[i].to;
+                const int f = RC_U(S.isl[i].from), tt = RC_U(S.isl[i].to);
                 if (f > tt) continue;
                 const int a2 = f, b2 = tt + k - 1;
                 for (j = a2 + w.lane; j <= b2; j += W::STRIDE) S.strongb[j] = 1;
@@ -860,7 +866,7 @@ RC_HD int rc_correct_read(W &w, rc_read_state &S, const rc_run_params &P, int pa
         // segments, :1009-1046
         int seg_cnt = 0;
         {
-            int f0 = S.isl[0].from, t0 = S.isl[0].to;
+            int f0 = RC_U(S.isl[0].from), t0 = RC_U(S.isl[0].to);
             if (f0 > 0) {
                 S.seg[seg_cnt].from = 0;
                 S.seg[seg_cnt].to = (short)(f0 - 1);
@@ -869,14 +875,14 @@ RC_HD int rc_correct_read(W &w, rc_read_state &S, const rc_run_params &P, int pa
                 ++seg_cnt;
             }
             for (i = 0; i < isl_cnt - 1; ++i) {
-                int af = S.isl[i].from, at = S.isl[i].to, bf = S.isl[i + 1].from, bt = S.isl[i + 1].to;
+                int af = RC_U(S.isl[i].from), at = RC_U(S.isl[i].to), bf = RC_U(S.isl[i + 1].from), bt = RC_U(S.isl[i + 1].to);
                 S.seg[seg_cnt].from = (short)(at + 1);
                 S.seg[seg_cnt].to = (short)(bf - 1);
                 S.seg[seg_cnt].lanchor = (short)(at - af + 1);
                 S.seg[seg_cnt].ranchor = (short)(bt - bf + 1);
                 ++seg_cnt;
             }
-            int lf = S.isl[i].from, lt = S.isl[i].to;
+            int lf = RC_U(S.isl[i].from), lt = RC_U(S.isl[i].to);
             if (lt < len - 1) {
                 S.seg[seg_cnt].from = (short)(lt + 1);
                 S.seg[seg_cnt].to = (short)len;
@@ -902,13 +908,13 @@ RC_HD int rc_correct_read(W &w, rc_read_state &S, const rc_run_params &P, int pa
             C.trial_cnt = 0;
             C.max_fix_cnt = allowed_fix;
             for (int si = 0; si < seg_cnt; ++si) {
-                const int sf = S.seg[si].from, st = S.seg[si].to;
+                const int sf = RC_U(S.seg[si].from), st = RC_U(S.seg[si].to);
                 C.top2a = C.top2b = -1;
                 C.trial_cnt = 0;
                 C.max_fix_cnt = (st - sf + 1) * P.max_fix_per_k / k * 2 + 1;
                 if (C.max_fix_cnt < P.max_fix_per_k) C.max_fix_cnt = P.max_fix_per_k;
                 C.best_bottleneck = -1;
-                if (S.seg[si].lanchor >= S.seg[si].ranchor) {
+                if (RC_U(S.seg[si].lanchor) >= RC_U(S.seg[si].ranchor)) {
                     int extend = (st == len) ? 0 : (k - 1);
                     int a = sf - k;
                     if (a < 0) return -1;  // the reference reads seq[-1] here (undefined)
@@ -941,7 +947,7 @@ RC_HD int rc_correct_read(W &w, rc_read_state &S, const rc_run_params &P, int pa
             if (best_bottleneck != -1) {  // :1178-1192
                 best_fix_cnt = 1;
                 for (i = 0; i < seg_cnt; ++i)
-                    if (S.seg[i].top2[1] >= best_bottleneck) best_fix_cnt *= 2;
+                    if (RC_U(S.seg[i].top2[1]) >= best_bottleneck) best_fix_cnt *= 2;
             }
             if (best_bottleneck != -1 && iter == 0 &&
                 rc_less_than_bound(best_bottleneck, strong, P.error_rate))  // :1195
@@ -961,7 +967,7 @@ RC_HD int rc_correct_read(W &w, rc_read_state &S, const rc_run_params &P, int pa
         rc_masked_sorted(w, S);
         bool has_drop = false;
         for (i = kcnt - 1; i >= 1; --i) {
-            int vi = S.v[i], vp = S.v[i - 1];
+            int vi = RC_U(S.v[i]), vp = RC_U(S.v[i - 1]);
             if (vi > strong) continue;
             if (vi > 2 * vp && vi > 10) {
                 has_drop = true;
@@ -973,7 +979,7 @@ RC_HD int rc_correct_read(W &w, rc_read_state &S, const rc_run_params &P, int pa
         }
         if (has_drop) {
             ++iter;
-            int vi = S.v[i];
+            int vi = RC_U(S.v[i]);
             trust = rc_bound_i(vi, P.error_rate);
             strong = vi;
         } else
@@ -994,21 +1000,21 @@ RC_HD int rc_correct_read(W &w, rc_read_state &S, const rc_run_params &P, int pa
     }
     w.sync();
     const int badq = P.bad_qual;
-    const int q0 = (int)S.qual[0];
+    const int q0 = RC_U(S.qual[0]);
     for (int i = 1; i < cnt; ++i) {  // pairwise veto, :1314-1398
-        const int pi = S.v[i], pp = S.v[i - 1];
-        if (q0 != 0 && ((int)S.qual[pi] <= badq && (int)S.qual[pp] <= badq)) continue;
+        const int pi = RC_U(S.v[i]), pp = RC_U(S.v[i - 1]);
+        if (q0 != 0 && (RC_U(S.qual[pi]) <= badq && RC_U(S.qual[pp]) <= badq)) continue;
         if (pi - pp + 1 <= k) {
             int min_single = RC_INF, min_double = RC_INF, taga = -1, tagb = -1;
-            const int pprev = i >= 2 ? S.v[i - 2] : -1;
-            const int pnext = i < cnt - 1 ? S.v[i + 1] : -1;
+            const int pprev = i >= 2 ? RC_U(S.v[i - 2]) : -1;
+            const int pnext = i < cnt - 1 ? RC_U(S.v[i + 1]) : -1;
             int j = pp - k + 1;
             if (j < 0) j = 0;
             for (; j < kcnt; ++j) {
                 if (i >= 2 && j <= pprev) continue;
                 if (i < cnt - 1 && j + k - 1 >= pnext) break;
                 if (j + k - 1 >= pi) break;
-                int cj = S.counts[j];
+                int cj = RC_U(S.counts[j]);
                 if (cj < min_single) {
                     min_single = cj;
                     taga = j;
@@ -1017,7 +1023,7 @@ RC_HD int rc_correct_read(W &w, rc_read_state &S, const rc_run_params &P, int pa
             for (; j < kcnt; ++j) {
                 if (i < cnt - 1 && j + k - 1 >= pnext) break;
                 if (j > pp) break;
-                int cj = S.counts[j];
+                int cj = RC_U(S.counts[j]);
                 if (cj < min_double) {
                     min_double = cj;
                     tagb = j;
@@ -1026,7 +1032,7 @@ RC_HD int rc_correct_read(W &w, rc_read_state &S, const rc_run_params &P, int pa
             for (; j < kcnt; ++j) {
                 if (i < cnt - 1 && j + k - 1 >= pnext) break;
                 if (j > pi) break;
-                int cj = S.counts[j];
+                int cj = RC_U(S.counts[j]);
                 if (cj < min_single) {
                     min_single = cj;
                     taga = j;
@@ -1131,7 +1137,7 @@ RC_HD void rc_kmer_info(W &w, rc_read_state &S, const rc_run_params &P, int ret,
     w.sync();
     if (nvalid == 0) return;
     w.sort(S.v, S.kcnt);
-    *l = S.v[0];
-    *m = S.v[nvalid / 2];
-    *h = S.v[nvalid - 1];
+    *l = RC_U(S.v[0]);
+    *m = RC_U(S.v[nvalid / 2]);
+    *h = RC_U(S.v[nvalid - 1]);
 }

@@ -26,6 +26,8 @@ struct HostWave {
 
     void sync() {}
     void phase(int) {}
+    int uni(int x) { return x; }
+    uint64_t uni64(uint64_t x) { return x; }
     long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     void stat(int i, int v) { stats[i] += v; }
     template <class F>
