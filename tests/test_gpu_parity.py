@@ -144,3 +144,81 @@ def test_errors_are_loud(gpu_ctx_factory):
         ctx.correct_batch(0, a, a.copy(), off)  # no table, no run parameters
     with pytest.raises(rcorrector_amd.RcorrectorError):
         rcorrector_amd.Context(k=33)
+
+
+def test_count_reads_device_matches_exact_counts(gpu_ctx_factory, oracle):
+    """stages 0-2 replacement: k-mer counting on the GPU == exact canonical counts >= 2 (what
+    `jellyfish count -C` + `dump -L 2` yields), incl. reads with N and ragged lengths."""
+    import torch
+    import synth
+    for name in ("varlen", "nrich", "k31_mc8"):
+        d = datasets.make(name)
+        arena, off = oracle.pack_reads(d["seqs1"])
+        ctx = gpu_ctx_factory(d["k"])
+        n = ctx.count_reads_device(torch.from_numpy(arena).cuda(), len(arena), 2)
+        codes, counts = ctx.table_export()
+        o = np.argsort(codes)
+        assert n == len(d["keys"]) == len(codes)
+        assert np.array_equal(codes[o], d["keys"]) and np.array_equal(counts[o].astype(np.int64), d["counts"])
+        # and the table answers like the one built from the dump
+        assert np.array_equal(ctx.lookup(d["keys"]), d["counts"].astype(np.int32))
+
+
+@pytest.mark.parametrize("fx,k,wk", [("fx_highcov", 23, 0.9), ("fx_se_k23", 23, 0.95), ("fx_k32", 32, 0.95)])
+def test_jfdump_load_and_error_rate_match_oracle(gpu_ctx_factory, oracle, fx, k, wk):
+    """main.cpp:294-358 through the C ABI: 'Stored N kmers' and ERROR_RATE, incl. the data-driven
+    (non-0.01) branch and a shuffled dump order."""
+    import os
+    import golden_util as gu
+    dump = os.path.join(gu.GOLDEN, fx, "dump.jf")
+    T = oracle.Table(k, 1 << 16)
+    stored = T.load_dump(dump)
+    want = T.error_rate(dump, wk)
+    ctx = gpu_ctx_factory(k)
+    assert ctx.load_jfdump(dump) == stored
+    got = ctx.estimate_error_rate(wk)
+    assert got == want  # the same IEEE doubles, bit for bit
+    if fx == "fx_highcov":
+        assert got != 0.01
+    codes, counts = T.export()
+    assert np.array_equal(ctx.lookup(codes), counts)
+
+
+def test_full_scale_properties(gpu_ctx_factory):
+    """At bench scale (1 M reads here, the bench itself checks 3 M against the oracle): results do
+    not depend on how the batch is cut, and correcting an already corrected batch with the same
+    table only ever touches reads it touched before (ret == 0 reads are fixed points)."""
+    import torch
+    import bench as B
+    dev = torch.device("cuda", 0)
+    n, L, k = 1_000_000, 100, 23
+    seq, qual = B.synth_reads_gpu(4242000, n, L, 3000, 1500, 0.8, 0.005, dev)
+    ctx = gpu_ctx_factory(k)
+    ctx.count_reads_device(seq, seq.numel(), 2)
+    ctx.set_run_params(0.01, b"H")
+    off = (torch.arange(n + 1, device=dev, dtype=torch.int64) * (L + 1)).to(torch.int32)
+
+    def run(s, lo, hi):
+        m = hi - lo
+        r = [torch.zeros(m, dtype=torch.int32, device=dev) for _ in range(4)]
+        o = (off[lo:hi + 1] - off[lo]).contiguous()
+        ctx.correct_device(0, m, m * (L + 1), L, s[lo * (L + 1):hi * (L + 1)], qual[lo * (L + 1):hi * (L + 1)], o, *r)
+        ctx.sync()
+        return r
+    a = seq.clone()
+    whole = run(a, 0, n)
+    b = seq.clone()
+    cut = 333_334
+    p1, p2 = run(b, 0, cut), run(b, cut, n)
+    assert torch.equal(a, b)
+    for x, y, z in zip(whole, p1, p2):
+        assert torch.equal(x, torch.cat([y, z]))
+    assert int((whole[0] > 0).sum()) > 100_000
+    # fixed points: reads reported clean (ret == 0) come back unchanged and clean again
+    c = a.clone()
+    again = run(c, 0, n)
+    clean = whole[0] == 0
+    assert torch.equal(again[0][clean], torch.zeros_like(again[0][clean]))
+    rows_a = a.view(n, L + 1)[clean]
+    rows_c = c.view(n, L + 1)[clean]
+    assert torch.equal(rows_a, rows_c)

@@ -41,7 +41,7 @@ def main():
         acc = defaultdict(lambda: [0, 0.0])
         for r in csv.DictReader(open(f)):
             kn = short(r["Kernel_Name"]).replace("void ", "")
-            if not (kn.startswith("k_") or "rc_" in kn):
+            if not (kn.startswith("k_") or "rc_" in kn or kn.startswith("gather")):
                 continue
             a = acc[(kn, r["Counter_Name"])]
             v = float(r["Counter_Value"])
