@@ -34,9 +34,11 @@ from rcorrector_amd.distributed import reduce_summary  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E nominal (MI355X_MICROARCH.md)
 
 
-def synth_reads_gpu(seed, n_reads, length, n_tx, l_tx, alpha, err, dev, chunk=1 << 20):
+def synth_reads_gpu(seed, n_reads, length, n_tx, l_tx, alpha, err, dev, chunk=1 << 20, paired=False, frag_len=300):
     """synth-v1 on the GPU: returns (seq arena uint8 [n*(L+1)], qual arena) with a NUL
-    after every read.  The transcriptome depends only on `seed // 1000` so all ranks share it."""
+    after every read.  The transcriptome depends only on `seed // 1000` so all ranks share it.
+    paired: n_reads/2 fragments of frag_len bases; the arena holds all first mates, then all second
+    mates (mate 2 = reverse complement of the fragment's tail), the layout rc_correct_device mode 1 wants."""
     g_tx = torch.Generator(device=dev)
     g_tx.manual_seed(seed // 1000)
     tx = torch.randint(0, 4, (n_tx * l_tx,), dtype=torch.uint8, device=dev, generator=g_tx)
@@ -46,15 +48,11 @@ def synth_reads_gpu(seed, n_reads, length, n_tx, l_tx, alpha, err, dev, chunk=1 
     lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
     seq = torch.zeros((n_reads, length + 1), dtype=torch.uint8, device=dev)
     qual = torch.zeros((n_reads, length + 1), dtype=torch.uint8, device=dev)
-    ar = torch.arange(length, device=dev)
-    for lo in range(0, n_reads, chunk):
-        m = min(chunk, n_reads - lo)
-        tid = torch.multinomial(w.float(), m, replacement=True, generator=g)
-        start = torch.randint(0, l_tx - length + 1, (m,), device=dev, generator=g)
-        idx = (tid * l_tx + start)[:, None] + ar[None, :]
-        codes = tx[idx]
-        rev = torch.rand(m, device=dev, generator=g) < 0.5
-        codes = torch.where(rev[:, None], 3 - codes.flip(1), codes)
+    span = frag_len if paired else length
+    n_units = n_reads // 2 if paired else n_reads
+    ar = torch.arange(span, device=dev)
+
+    def emit(codes, lo, m):
         mut = torch.rand((m, length), device=dev, generator=g) < err
         shift = torch.randint(1, 4, (m, length), dtype=torch.uint8, device=dev, generator=g)
         codes = torch.where(mut, (codes + shift) & 3, codes)
@@ -62,6 +60,18 @@ def synth_reads_gpu(seed, n_reads, length, n_tx, l_tx, alpha, err, dev, chunk=1 
         q = torch.full((m, length), ord('I'), dtype=torch.uint8, device=dev)
         q[mut] = ord('#')
         qual[lo:lo + m, :length] = q
+
+    for lo in range(0, n_units, chunk):
+        m = min(chunk, n_units - lo)
+        tid = torch.multinomial(w.float(), m, replacement=True, generator=g)
+        start = torch.randint(0, l_tx - span + 1, (m,), device=dev, generator=g)
+        idx = (tid * l_tx + start)[:, None] + ar[None, :]
+        codes = tx[idx]
+        rev = torch.rand(m, device=dev, generator=g) < 0.5
+        codes = torch.where(rev[:, None], 3 - codes.flip(1), codes)
+        emit(codes[:, :length], lo, m)
+        if paired:
+            emit((3 - codes.flip(1))[:, :length], n_units + lo, m)
     return seq.reshape(-1), qual.reshape(-1)
 
 
@@ -78,6 +88,7 @@ def main():
     ap.add_argument("--err", type=float, default=0.005)
     ap.add_argument("--alpha", type=float, default=0.8)
     ap.add_argument("--seed", type=int, default=1001000)
+    ap.add_argument("--paired", action="store_true", help="paired-end batch (mode 1): --reads counts both mates")
     ap.add_argument("--host-path", action="store_true",
                     help="also time the host-buffer entry point rc_correct_batch (PCIe inclusive; reported, never `value`)")
     ap.add_argument("--cpu-sample", type=int, default=3000000, help="reads of the CPU-baseline sample (0 = skip)")
@@ -98,12 +109,15 @@ def main():
             dist.barrier()
 
     L, k, n = a.len, a.k, a.reads
+    mode = 1 if a.paired else 0
+    if a.paired and n % 2:
+        raise SystemExit('--paired needs an even --reads')
     ctx = rcorrector_amd.Context(k=k, max_fix_per_k=4, device=local)
 
     # the replicated table: every rank counts the k-mers of the rank-0 shard (same seed => same
     # table everywhere, no communication), then generates its own shard of reads
     t0 = time.time()
-    seq0, qual0 = synth_reads_gpu(a.seed, n, L, a.n_tx, a.l_tx, a.alpha, a.err, dev)
+    seq0, qual0 = synth_reads_gpu(a.seed, n, L, a.n_tx, a.l_tx, a.alpha, a.err, dev, paired=a.paired)
     torch.cuda.synchronize()
     t_gen = time.time() - t0
     t0 = time.time()
@@ -111,7 +125,7 @@ def main():
     t_count = time.time() - t0
     if rank != 0:
         del seq0, qual0
-        seq0, qual0 = synth_reads_gpu(a.seed + rank, n, L, a.n_tx, a.l_tx, a.alpha, a.err, dev)
+        seq0, qual0 = synth_reads_gpu(a.seed + rank, n, L, a.n_tx, a.l_tx, a.alpha, a.err, dev, paired=a.paired)
     nbytes = seq0.numel()
     off = (torch.arange(n + 1, device=dev, dtype=torch.int64) * (L + 1)).to(torch.int32)  # < 2^31 here
     first_q = qual0[0::(L + 1)][:1000000]
@@ -131,7 +145,7 @@ def main():
     def step():
         work.copy_(seq0)           # restore the uncorrected reads (the kernel corrects in place)
         torch.cuda.current_stream().synchronize()
-        ctx.correct_device(0, n, nbytes, L, work, qual0, off, ret, l_, m_, h_)
+        ctx.correct_device(mode, n, nbytes, L, work, qual0, off, ret, l_, m_, h_)
         ctx.sync()
 
     for _ in range(a.warmup):
@@ -184,7 +198,7 @@ def main():
             host_rate = hn / (time.perf_counter() - th)
 
         cpu = None
-        if a.cpu_sample > 0:
+        if a.cpu_sample > 0 and not a.paired:
             cpu = cpu_baseline(ctx, seq0, qual0, n, L, k, error_rate, bad_q, a.cpu_sample, ret, work)
 
         out = {
@@ -192,15 +206,16 @@ def main():
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8/int32/u64", "data": "synthetic",
-            "config": {"workload": "%d synthetic %d bp single-end reads per GPU, k=%d, %d-k-mer table "
-                       "(BASELINE.json configs[1])" % (n, L, k, n_kmers),
+            "config": {"workload": "%d synthetic %d bp %s reads per GPU, k=%d, %d-k-mer table%s"
+                       % (n, L, "paired-end" if a.paired else "single-end", k, n_kmers,
+                          " (BASELINE.json configs[1])" if (not a.paired and L == 100 and n == 10_000_000) else ""),
                        "reads_per_gpu": n, "read_len": L, "k": k, "table_kmers": n_kmers,
                        "table_bytes": ts["bytes"], "sub_rate": a.err, "error_rate_param": error_rate,
                        "bad_quality": bad_q.decode("latin1"), "parallelism": "reads sharded x%d, table replicated" % world,
                        "reads_corrected_frac": stats[1] / float(stats[0]), "bases_corrected": stats[2],
                        "host_buffer_entry_reads_per_s_pcie_inclusive": host_rate,
                        "setup_s": {"synth": round(t_gen, 2), "count_and_build_table": round(t_count, 2)},
-                       "kernel_ms_per_step": {"probe": ms_probe / a.steps, "threshold": ms_thr / a.steps,
+                       "mode": "paired" if a.paired else "single", "kernel_ms_per_step": {"probe": ms_probe / a.steps, "threshold": ms_thr / a.steps,
                                               "correct": ms_cor / a.steps}},
             "roofline": {"kernel": "k_probe (hash probe, K1)", "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

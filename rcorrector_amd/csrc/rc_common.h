@@ -29,9 +29,16 @@
 // ---- table bucket: 64 B = 5 x {key_lo,key_hi,count} + 1 meta dword -------------------------
 // count == 0 marks an empty slot (stored counts are >= 2 by construction, main.cpp:299).
 // meta bit0 = "some key whose home is <= this bucket lives in a later bucket" (probe goes on).
+// RC_BUCKET128: 128-byte buckets of 10 slots (the fabric fetches 128 B per L2 miss anyway)
+#if defined(RC_BUCKET128)
+#define RC_BUCKET_SLOTS 10
+#define RC_BUCKET_DWORDS 32
+#define RC_BUCKET_BYTES 128
+#else
 #define RC_BUCKET_SLOTS 5
 #define RC_BUCKET_DWORDS 16
 #define RC_BUCKET_BYTES 64
+#endif
 
 struct rc_table_view {
     const uint32_t *buckets;  // nbuckets_alloc * 16 dwords, 64-B aligned

@@ -37,7 +37,6 @@ struct DevWaveT {
     }
     rc_table_view T;
     int k;
-    const uint8_t *qualp;
     rc_frame *stack;  // this wave's frames in HBM scratch
 
     // Lanes of ONE wave exchange data through LDS.  DS instructions of a wave execute in issue
@@ -78,24 +77,6 @@ struct DevWaveT {
     __device__ __forceinline__ int get(rc_kmer km)
     {
         return km.inv == -1 ? rc_table_lookup(T, rc_canonical(km.code, k)) : 0;
-    }
-
-    // the four one-base extensions of km: lane c (c < 4) probes extension c
-    __device__ __forceinline__ void probe4(rc_kmer km, int dir, int cnt[4])
-    {
-        int mine = 0;
-        if (lane < 4) mine = get(rc_extend(km, k, dir, lane));
-        cnt[0] = __builtin_amdgcn_readlane(mine, 0);
-        cnt[1] = __builtin_amdgcn_readlane(mine, 1);
-        cnt[2] = __builtin_amdgcn_readlane(mine, 2);
-        cnt[3] = __builtin_amdgcn_readlane(mine, 3);
-    }
-
-    __device__ __forceinline__ int probe1(rc_kmer km)
-    {
-        int mine = 0;
-        if (lane == 0) mine = get(km);
-        return __builtin_amdgcn_readlane(mine, 0);
     }
 
     __device__ __forceinline__ int lookup(uint64_t code) { return rc_table_lookup(T, rc_canonical(code, k)); }
@@ -178,8 +159,6 @@ struct DevWaveT {
             }
         }
     }
-
-    __device__ __forceinline__ int qual(int i) { return (int)(signed char)qualp[i]; }
 
     __device__ __forceinline__ void stack_push(int sp, const rc_frame &f)
     {
@@ -336,7 +315,6 @@ __global__ __launch_bounds__(64) void k_threshold(rc_kernel_args A)
     w.lane = threadIdx.x;
     w.T = A.T;
     w.k = A.P.k;
-    w.qualp = nullptr;
     w.stack = nullptr;
     for (uint32_t r = blockIdx.x; r < A.n; r += gridDim.x) {
         rc_load_read(w, A, S, r, w.lane, false);
@@ -386,7 +364,6 @@ __global__ __launch_bounds__(64, RC_K3_WAVES) void k_correct(rc_kernel_args A)
         w.phase(0);
         rc_load_read(w, A, S, r, w.lane, true);
         const uint32_t o = A.off[r];
-        w.qualp = A.qual + o;
         int strong0, info0;
         if (A.mode == 0) {  // single-end: no mate to wait for, the threshold pass runs right here
             w.phase(1);

@@ -12,15 +12,18 @@
 //   GetKmerInformation         ErrorCorrection.cpp:1567-1602   -> rc_kmer_info()
 //
 // The template parameter W is the wave back end:
-//   W::lane, W::STRIDE          lane id and lane count (64 on the device)
-//   w.sync()                    orders LDS traffic between lanes of the wave
-//   w.probe4(km, dir, cnt)      counts of the four one-base extensions of km (lanes 0..3 probe)
-//   w.probe1(km)                count of one k-mer
-//   w.sort(a, n)                ascending in-LDS sort
-//   (int)S.qual[i]                   quality character i of the read (HBM)
-//   w.stack_push/pop/top        search stack frames (HBM scratch)
-// The device back end is in rc_correct.hip; tests/hostsim has a lane-serial one (STRIDE = 1)
-// that lets the CPU test-suite diff this exact control flow against the oracle.
+//   W::lane, W::STRIDE            lane id and lane count (64 on the device)
+//   w.sync()                      orders LDS traffic between the lanes of the wave
+//   w.ballot64(base, n, pred)     bit l = pred(base + l), one element per lane
+//   w.for_lanes64(base, n, body)  body(base + l, l) on lane l
+//   w.uni(x) / w.uni64(x)         a wave-uniform value -> scalar register (RC_U / RC_U64)
+//   w.reduce_add(x)               sum over lanes
+//   w.get(kmer) / w.lookup(code)  Store::GetCount of a k-mer state / of a valid forward code
+//   w.sort(a, n)                  ascending in-LDS sort
+//   w.stack_push/top/set_mask     search stack frames (HBM scratch)
+//   w.phase(id) / w.stat(i, v)    optional accounting hooks
+// The device back end is DevWaveT in rc_correct.hip; tests/hostsim has a lane-serial one
+// (STRIDE = 1) that lets the CPU test-suite diff this exact control flow against the oracle.
 #pragma once
 #include "rc_common.h"
 

@@ -11,14 +11,20 @@ __device__ __forceinline__ int rc_table_lookup(const rc_table_view &T, uint64_t 
     const uint32_t klo = (uint32_t)canon, khi = (uint32_t)(canon >> 32);
     for (;;) {
         const uint4 *p = reinterpret_cast<const uint4 *>(T.buckets + (size_t)b * RC_BUCKET_DWORDS);
-        const uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+        uint32_t d[RC_BUCKET_DWORDS];
+#pragma unroll
+        for (int q = 0; q < RC_BUCKET_DWORDS / 4; ++q) {
+            const uint4 v = p[q];
+            d[4 * q + 0] = v.x;
+            d[4 * q + 1] = v.y;
+            d[4 * q + 2] = v.z;
+            d[4 * q + 3] = v.w;
+        }
         int r = 0;
-        r = (q0.x == klo && q0.y == khi) ? (int)q0.z : r;
-        r = (q0.w == klo && q1.x == khi && r == 0) ? (int)q1.y : r;
-        r = (q1.z == klo && q1.w == khi && r == 0) ? (int)q2.x : r;
-        r = (q2.y == klo && q2.z == khi && r == 0) ? (int)q2.w : r;
-        r = (q3.x == klo && q3.y == khi && r == 0) ? (int)q3.z : r;
-        if (r != 0 || !(q3.w & 1u)) return r;
+#pragma unroll
+        for (int s2 = 0; s2 < RC_BUCKET_SLOTS; ++s2)
+            r = (d[3 * s2] == klo && d[3 * s2 + 1] == khi && r == 0) ? (int)d[3 * s2 + 2] : r;
+        if (r != 0 || !(d[RC_BUCKET_DWORDS - 1] & 1u)) return r;
         ++b;
     }
 }

@@ -55,7 +55,7 @@ __global__ void k_scatter(const uint32_t *__restrict__ home_sorted, const uint32
     w[0] = (uint32_t)key;
     w[1] = (uint32_t)(key >> 32);
     w[2] = (uint32_t)counts[i];
-    if (s == 0 && home_sorted[j] < b) buckets[(size_t)(b - 1) * RC_BUCKET_DWORDS + 15] = 1u;
+    if (s == 0 && home_sorted[j] < b) buckets[(size_t)(b - 1) * RC_BUCKET_DWORDS + (RC_BUCKET_DWORDS - 1)] = 1u;
 }
 
 int rc_build_table_from_device_pairs(rc_ctx *ctx, const uint64_t *d_canon, const int32_t *d_counts, size_t n)

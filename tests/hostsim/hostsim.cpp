@@ -22,7 +22,7 @@ struct HostWave {
     int k;
     const char *qualp;
     std::vector<rc_frame> stack;
-    long probes4 = 0, probes1 = 0, max_sp = 0;
+    long max_sp = 0;
 
     void sync() {}
     void phase(int) {}
@@ -53,17 +53,7 @@ struct HostWave {
         q.inv = km.inv;
         return rco_table_get(tab, &q);
     }
-    void probe4(rc_kmer km, int dir, int cnt[4])
-    {
-        ++probes4;
-        for (int c = 0; c < 4; ++c) cnt[c] = get(rc_extend(km, k, dir, c));
-    }
     long gets = 0;
-    int probe1(rc_kmer km)
-    {
-        ++probes1;
-        return get(km);
-    }
     int lookup(uint64_t code)
     {
         rc_kmer km;
@@ -72,7 +62,6 @@ struct HostWave {
         return get(km);
     }
     void sort(int *a, int n) { std::sort(a, a + n); }
-    int qual(int i) { return (int)(signed char)qualp[i]; }
     void stack_push(int sp, const rc_frame &f)
     {
         if ((int)stack.size() <= sp) stack.resize(sp + 1);
@@ -229,7 +218,7 @@ void hostsim_correct_batch(const rco_params *p, const rco_table *t, rco_batch *b
     }
     if (st) {
         st->probes4 = w.gets;
-        st->probes1 = w.probes1;
+        st->probes1 = 0;
         st->max_stack = w.max_sp;
         if (getenv("HOSTSIM_STATS")) fprintf(stderr, "keep_run calls=%ld sumR=%ld sum_avail=%ld refills=%ld gap_attempts=%ld gap_probes=%ld reads=%ld\n", w.stats[0], w.stats[1], w.stats[2], w.stats[3], w.stats[4], w.stats[5], (long)total);
         st->reads = (long)total;
