@@ -39,6 +39,16 @@ def run_ref(d, args):
     p = subprocess.run(cmd, cwd=d, stderr=subprocess.PIPE, check=True)
     open(os.path.join(out, "stderr.txt"), "wb").write(p.stderr)
     open(os.path.join(d, "cmd.txt"), "w").write(" ".join(args) + "\n")
+    # the -verbose transcript (per-read counts, every (strong, trust) iteration, the trusted
+    # bitmap, post-correction counts: ErrorCorrection.cpp:686-689,759-770,856-857,1088-1094,
+    # 1590-1597), kept gzip-compressed next to the outputs
+    import gzip
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        pv = subprocess.run([REF] + args + ["-od", tmp, "-verbose"], cwd=d, stdout=subprocess.PIPE,
+                            stderr=subprocess.DEVNULL, check=True)
+    with gzip.GzipFile(os.path.join(d, "verbose.txt.gz"), "wb", mtime=0) as g:
+        g.write(pv.stdout)
 
 
 def dump_of(path, arrays, k, lens=None, order=None):

@@ -63,3 +63,15 @@ def test_oracle_threads_and_stdout(oracle_cli, tmp_path):
     for i in range(0, len(a) - 1, 4):
         want += a[i:i + 4] + b[i:i + 4]
     assert p.stdout.split(b"\n")[:-1] == want
+
+
+@pytest.mark.parametrize("name", gu.FIXTURES)
+def test_oracle_verbose_transcript_matches_reference(oracle_cli, name, tmp_path):
+    """-verbose exposes the intermediate state of every read (original counts, each
+    (strongTrustThreshold, trustThreshold) iteration incl. the INT_MIN ones, the strong-trusted
+    bitmap, post-correction counts); the oracle must print the reference's transcript byte for byte."""
+    import gzip
+    want = gzip.open(os.path.join(gu.GOLDEN, name, "verbose.txt.gz"), "rb").read()
+    p = gu.run_fixture(oracle_cli, name, tmp_path, extra=["-verbose"])
+    assert p.stdout == want
+    assert want.count(b"strong trust threshold=") >= want.count(b"Before correction:")
