@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "../../include/rcorrector_amd.h"
@@ -192,59 +193,116 @@ int rc_table_load_jfdump(rc_ctx *c, const char *path, int64_t *stored)
     D.codes.clear();
     D.inv_mid.clear();
     D.load_state_invalid = 0;
+    auto is_ws = [](char ch) { return ch == ' ' || ch == '\n' || ch == '\t' || ch == '\r' || ch == '\f' || ch == '\v'; };
+
+    // the text is cut at entry starts ('>' right after white space) and the pieces are parsed by
+    // several host threads; the per-piece results are concatenated in file order
+    struct piece {
+        std::vector<uint64_t> codes, put_codes;
+        std::vector<int8_t> inv_mid;
+        std::vector<int32_t> put_counts;
+        int64_t accepted = 0;
+        int last_state_invalid = -1;  // -1: no accepted entry in this piece
+    };
+    unsigned T = std::thread::hardware_concurrency();
+    if (T == 0) T = 4;
+    if (T > 32) T = 32;
+    if ((size_t)sz < (1u << 20)) T = 1;
+    std::vector<size_t> cut(T + 1, (size_t)sz);
+    cut[0] = 0;
+    for (unsigned t = 1; t < T; ++t) {
+        size_t pos = (size_t)sz * t / T;
+        if (pos < cut[t - 1]) pos = cut[t - 1];
+        while (pos < (size_t)sz && !(buf[pos] == '>' && (pos == 0 || is_ws(buf[pos - 1])))) ++pos;
+        cut[t] = pos;
+    }
+    std::vector<piece> pieces(T);
+    auto parse = [&](unsigned t) {
+        piece &P = pieces[t];
+        const char *p = buf.data() + cut[t], *end = buf.data() + cut[t + 1];
+        const size_t guess = (size_t)(end - p) / (size_t)(k + 4) + 16;
+        P.codes.reserve(guess);
+        P.inv_mid.reserve(guess);
+        P.put_codes.reserve(guess);
+        P.put_counts.reserve(guess);
+        while (true) {
+            while (p < end && is_ws(*p)) ++p;
+            if (p >= end) break;
+            const char *t0 = p;
+            while (p < end && !is_ws(*p)) ++p;
+            long long cnt = 0;  // atoi(&token[1])
+            {
+                const char *q = t0 + 1;
+                bool neg = false;
+                if (q < p && (*q == '-' || *q == '+')) {
+                    neg = *q == '-';
+                    ++q;
+                }
+                while (q < p && *q >= '0' && *q <= '9') {
+                    cnt = cnt * 10 + (*q - '0');
+                    if (cnt > 0x7fffffffLL) cnt = 0x7fffffffLL;
+                    ++q;
+                }
+                if (neg) cnt = -cnt;
+            }
+            while (p < end && is_ws(*p)) ++p;
+            const char *k0 = p;
+            while (p < end && !is_ws(*p)) ++p;
+            uint64_t code = 0;
+            int inv = -1;
+            for (const char *q = k0; q < p; ++q) {
+                int b;
+                switch (*q) {
+                case 'A': b = 0; break;
+                case 'C': b = 1; break;
+                case 'G': b = 2; break;
+                case 'T': b = 3; break;
+                default: b = -1;
+                }
+                if (inv != -1) ++inv;
+                code = ((code << 2) & mask) | (uint64_t)(b & 3);
+                if (b == -1) inv = 0;
+                if (inv >= k) inv = -1;
+            }
+            P.codes.push_back(code);
+            P.inv_mid.push_back(inv > 0 ? 1 : 0);
+            if (cnt <= 1) continue;
+            P.last_state_invalid = (inv != -1);
+            ++P.accepted;
+            if (inv == -1) {  // Store::Put ignores invalid k-mers, Store.h:53-54
+                P.put_codes.push_back(code);
+                P.put_counts.push_back((int32_t)cnt);
+            }
+        }
+    };
+    if (T == 1) {
+        parse(0);
+    } else {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < T; ++t) th.emplace_back(parse, t);
+        for (auto &x : th) x.join();
+    }
     std::vector<uint64_t> put_codes;
     std::vector<int32_t> put_counts;
-    const char *p = buf.data(), *end = buf.data() + sz;
-    auto is_ws = [](char ch) { return ch == ' ' || ch == '\n' || ch == '\t' || ch == '\r' || ch == '\f' || ch == '\v'; };
     int64_t accepted = 0;
-    while (true) {
-        while (p < end && is_ws(*p)) ++p;
-        if (p >= end) break;
-        const char *t0 = p;
-        while (p < end && !is_ws(*p)) ++p;
-        // atoi(&token[1])
-        long long cnt = 0;
-        {
-            const char *q = t0 + 1;
-            bool neg = false;
-            if (q < p && (*q == '-' || *q == '+')) {
-                neg = *q == '-';
-                ++q;
-            }
-            while (q < p && *q >= '0' && *q <= '9') {
-                cnt = cnt * 10 + (*q - '0');
-                if (cnt > 0x7fffffffLL) cnt = 0x7fffffffLL;
-                ++q;
-            }
-            if (neg) cnt = -cnt;
+    {
+        size_t n_all = 0, n_put = 0;
+        for (auto &P : pieces) {
+            n_all += P.codes.size();
+            n_put += P.put_codes.size();
         }
-        while (p < end && is_ws(*p)) ++p;
-        const char *k0 = p;
-        while (p < end && !is_ws(*p)) ++p;
-        uint64_t code = 0;
-        int inv = -1;
-        for (const char *q = k0; q < p; ++q) {
-            int b;
-            switch (*q) {
-            case 'A': b = 0; break;
-            case 'C': b = 1; break;
-            case 'G': b = 2; break;
-            case 'T': b = 3; break;
-            default: b = -1;
-            }
-            if (inv != -1) ++inv;
-            code = ((code << 2) & mask) | (uint64_t)(b & 3);
-            if (b == -1) inv = 0;
-            if (inv >= k) inv = -1;
-        }
-        D.codes.push_back(code);
-        D.inv_mid.push_back(inv > 0 ? 1 : 0);
-        if (cnt <= 1) continue;
-        D.load_state_invalid = (inv != -1);
-        ++accepted;
-        if (inv == -1) {  // Store::Put ignores invalid k-mers, Store.h:53-54
-            put_codes.push_back(code);
-            put_counts.push_back((int32_t)cnt);
+        D.codes.reserve(n_all);
+        D.inv_mid.reserve(n_all);
+        put_codes.reserve(n_put);
+        put_counts.reserve(n_put);
+        for (auto &P : pieces) {
+            D.codes.insert(D.codes.end(), P.codes.begin(), P.codes.end());
+            D.inv_mid.insert(D.inv_mid.end(), P.inv_mid.begin(), P.inv_mid.end());
+            put_codes.insert(put_codes.end(), P.put_codes.begin(), P.put_codes.end());
+            put_counts.insert(put_counts.end(), P.put_counts.begin(), P.put_counts.end());
+            accepted += P.accepted;
+            if (P.last_state_invalid >= 0) D.load_state_invalid = P.last_state_invalid;
+            P = piece();
         }
     }
     D.valid = true;

@@ -5,20 +5,28 @@
 //   flags        main.cpp:50-71,165-268     -r/-p/-i/-c/-k/-od/-t/-maxcor/-maxcorK/-wk/-stdout/-verbose
 //   file typing  Reads.h:108-162            first byte '>' FASTA, '@' FASTQ; ".gz" by the last two chars
 //   output name  Reads.h:39-75,140-157      <od>/<name minus last extension>.cor.f[aq][.gz]
-//   record       Reads.h:360-421            "<id> l:%d m:%d h:%d[ cor| unfixable_error]"
+//   record       Reads.h:224-266,360-421    4 lines in; "<id> l:%d m:%d h:%d[ cor| unfixable_error]" out
 //   batching     main.cpp:439-523           batches never span files; mates travel together
 //
-// Extra (not in the reference): -gpus N shards batches over N GPUs (table replicated, ordered
-// writer), and -batch N sets the reads per batch.  -t is accepted; the GPU path does not need it.
+// Host pipeline: one reader thread cuts the input into batches of whole records
+// (block reads, memchr line index, parallel packing into the SoA arenas of the C ABI), one worker
+// per GPU runs rc_correct_batch, one writer thread formats in parallel and writes in input order.
+//
+// Extra flags (not in the reference): -gpus N shards batches over N GPUs (table replicated),
+// -batch N sets the reads per batch.  -t sets the host threads used for packing / formatting.
 // -verbose (per-read trace on stdout) is not provided by the GPU path and is refused loudly.
+#include <fcntl.h>
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
+#include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <memory>
@@ -30,18 +38,17 @@
 #include "../../include/rcorrector_amd.h"
 
 #define MAX_READ_FILE 100    // Reads.h:11
-#define MAX_READ_LENGTH 1024 // utils.h:7
+#define MAX_READ_LENGTH 1024 // utils.h:7  (fgets buffer: 1023 characters + NUL)
 #define MAX_ID_LENGTH 2048   // utils.h:8
 
 static bool g_stdout = false;
+static bool g_timing = false;  // RC_TIMING=1: phase timings on stderr (off by default: stderr is part of the contract)
+static int g_threads = 8;
 
-struct ReadFile {
-    std::string path;
-    bool paired = false, interleaved = false, fastq = true, out_gz = false;
-    gzFile in = nullptr;
-    FILE *out = nullptr;
-    gzFile outz = nullptr;
-};
+static double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 static void die(const char *fmt, ...)
 {
@@ -51,6 +58,124 @@ static void die(const char *fmt, ...)
     va_end(ap);
     exit(1);
 }
+
+template <class F>
+static void parallel_for(size_t n, F fn)
+{
+    const size_t T = std::min<size_t>((size_t)g_threads, n ? (n + 4095) / 4096 : 1);
+    if (T <= 1) {
+        fn((size_t)0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < T; ++t) th.emplace_back([=, &fn]() { fn(n * t / T, n * (t + 1) / T); });
+    for (auto &x : th) x.join();
+}
+
+// ---- input: a stream of bytes cut into blocks of whole records --------------------------------
+struct Source {
+    std::string path;
+    bool is_gz = false;
+    int fd = -1;
+    gzFile gz = nullptr;
+    std::vector<char> buf;  // unconsumed bytes [0, have)
+    size_t have = 0;
+    bool eof = false;
+
+    void open(const std::string &p)
+    {
+        path = p;
+        size_t len = p.size();
+        is_gz = len >= 2 && p[len - 2] == 'g' && p[len - 1] == 'z';  // File.h:51-55
+        if (is_gz) {
+            gz = gzopen(p.c_str(), "r");
+            if (!gz) die("ERROR: Could not access file %s\n", p.c_str());
+            gzbuffer(gz, 1 << 20);
+        } else {
+            fd = ::open(p.c_str(), O_RDONLY);
+            if (fd < 0) die("ERROR: Could not access file %s\n", p.c_str());
+        }
+        have = 0;
+        eof = false;
+    }
+    void close()
+    {
+        if (gz) gzclose(gz);
+        if (fd >= 0) ::close(fd);
+        gz = nullptr;
+        fd = -1;
+    }
+    void refill()
+    {
+        const size_t CH = 32u << 20;
+        if (buf.size() < have + CH + 8) buf.resize(have + CH + 8);
+        long n = is_gz ? gzread(gz, buf.data() + have, (unsigned)CH) : (long)::read(fd, buf.data() + have, CH);
+        if (n <= 0)
+            eof = true;
+        else
+            have += (size_t)n;
+    }
+};
+
+// a batch of raw records: the text plus the start of every line (lines_per_record per record)
+struct Block {
+    std::vector<char> text;
+    std::vector<uint32_t> line;  // line i = text[line[i] .. line[i+1]-1), without its '\n'
+    size_t records = 0;
+};
+
+// up to max_records whole records from the source (fewer only at end of file)
+static void take_records(Source &s, size_t max_records, int lines_per_record, Block &b)
+{
+    b.text.clear();
+    b.line.clear();
+    b.records = 0;
+    const size_t want_lines = max_records * (size_t)lines_per_record;
+    size_t end = 0;  // one past the '\n' of the last indexed line
+    std::vector<uint32_t> starts;
+    starts.reserve(std::min<size_t>(want_lines, (size_t)1 << 22) + 8);
+    for (;;) {
+        while (starts.size() < want_lines && end < s.have) {
+            const char *nl = (const char *)memchr(s.buf.data() + end, '\n', s.have - end);
+            if (!nl) break;
+            starts.push_back((uint32_t)end);
+            end = (size_t)(nl - s.buf.data()) + 1;
+        }
+        if (starts.size() >= want_lines) break;
+        if (s.eof) {
+            if (end < s.have) {  // last line without '\n' (fgets hands it over as it is): add the newline
+                if (s.buf.size() < s.have + 1) s.buf.resize(s.have + 1);
+                s.buf[s.have++] = '\n';
+                continue;
+            }
+            break;
+        }
+        if (s.have >= (1ull << 31)) die("ERROR: %s: a batch exceeds 2 GiB of text; lower -batch\n", s.path.c_str());
+        s.refill();
+    }
+    // a record cut short by the end of the file: its missing lines read as empty (fgets leaves "")
+    while (starts.size() % (size_t)lines_per_record) {
+        if (s.buf.size() < s.have + 1) s.buf.resize(s.have + 1);
+        s.buf[s.have++] = '\n';
+        starts.push_back((uint32_t)end);
+        end += 1;
+    }
+    b.records = starts.size() / (size_t)lines_per_record;
+    if (b.records == 0) return;
+    b.text.assign(s.buf.data(), s.buf.data() + end);
+    starts.push_back((uint32_t)end);
+    b.line.swap(starts);
+    memmove(s.buf.data(), s.buf.data() + end, s.have - end);
+    s.have -= end;
+}
+
+struct ReadFile {
+    std::string path;
+    bool paired = false, interleaved = false, fastq = true, out_gz = false;
+    Source src;
+    FILE *out = nullptr;
+    gzFile outz = nullptr;
+};
 
 // Reads.h:39-75
 static std::string base_name(const std::string &path)
@@ -73,23 +198,25 @@ static std::string base_name(const std::string &path)
     return in.substr(j + 1);
 }
 
+// Reads.h:108-162: type the file by its first byte, open (truncate) the output
 static void open_file(ReadFile &f, const char *path, bool paired, bool interleaved, const std::string &od)
 {
     f.path = path;
     f.paired = paired;
     f.interleaved = interleaved;
-    f.in = gzopen(path, "r");
-    if (!f.in) die("ERROR: Could not access file %s\n", path);
-    char first[2048];
-    first[0] = 0;
-    gzgets(f.in, first, sizeof first);
-    if (first[0] == '>')
+    f.src.open(path);
+    f.src.refill();
+    const char first = f.src.have ? f.src.buf[0] : 0;
+    if (first == '>')
         f.fastq = false;
-    else if (first[0] == '@')
+    else if (first == '@')
         f.fastq = true;
-    else
-        die("\"%s\"'s format is wrong: %s\n", path, first);
-    gzrewind(f.in);
+    else {
+        std::string l(f.src.buf.data(), std::min<size_t>(f.src.have, 200));
+        const size_t nl = l.find('\n');
+        if (nl != std::string::npos) l = l.substr(0, nl + 1);
+        die("\"%s\"'s format is wrong: %s\n", path, l.c_str());
+    }
     size_t len = strlen(path);
     f.out_gz = len >= 2 && path[len - 2] == 'g' && path[len - 1] == 'z';
     std::string outp = od + "/" + base_name(path) + (f.fastq ? ".cor.fq" : ".cor.fa") + (f.out_gz ? ".gz" : "");
@@ -99,57 +226,143 @@ static void open_file(ReadFile &f, const char *path, bool paired, bool interleav
     } else if (f.out_gz) {
         f.outz = gzopen(outp.c_str(), "w1");  // compressLevel 1, Reads.h:84, File.h:62-66
         if (!f.outz) die("ERROR: Could not access file %s\n", outp.c_str());
+        gzbuffer(f.outz, 1 << 20);
     } else {
         f.out = fopen(outp.c_str(), "w");
         if (!f.out) die("ERROR: Could not access file %s\n", outp.c_str());
     }
 }
 
-// one batch of reads of one file (plus its mate file), SoA for the C ABI
-struct Batch {
-    int file = 0;
-    int mode = 0;
-    std::vector<char> seq, qual, seq2, qual2;
-    std::vector<uint32_t> off, off2;
-    std::vector<std::string> id, id2;
-    std::vector<int32_t> ret, l, m, h;
-    size_t n() const { return id.size(); }
-};
-
-struct Reader {
-    std::vector<ReadFile> files, mates;
-};
-
 static void emit(ReadFile &f, const char *s, size_t n)
 {
-    if (f.out_gz)
-        gzwrite(f.outz, s, (unsigned)n);
-    else
+    if (n == 0) return;
+    if (f.out_gz) {
+        for (size_t o = 0; o < n;) {
+            unsigned c = (unsigned)std::min<size_t>(n - o, (size_t)1 << 30);
+            gzwrite(f.outz, s + o, c);
+            o += c;
+        }
+    } else
         fwrite(s, 1, n, f.out);
 }
 
-// Reads.h:360-421
-static void write_record(ReadFile &f, const std::string &id, const char *seq, const char *qual, int cor, int l, int m, int h,
-                         std::string &line)
-{
-    char info[96];
-    snprintf(info, sizeof info, " l:%d m:%d h:%d", l, m, h);
-    line.clear();
-    line += id;
-    line += info;
-    if (cor == -1)
-        line += " unfixable_error";
-    else if (cor > 0)
-        line += " cor";
-    line += '\n';
-    line += seq;
-    line += '\n';
-    if (f.fastq) {
-        line += "+\n";
-        line += qual;
-        line += '\n';
+// ---- one batch travelling through the pipeline -------------------------------------------------
+struct Arena {  // one file's share of a batch
+    Block blk;
+    int lpr = 4;  // lines per record
+    std::vector<char> seq, qual;
+    std::vector<uint32_t> off;
+    size_t n() const { return blk.records; }
+    const char *line(size_t rec, int which, uint32_t *len) const
+    {
+        const size_t li = rec * (size_t)lpr + (size_t)which;
+        *len = blk.line[li + 1] - blk.line[li] - 1;
+        return blk.text.data() + blk.line[li];
     }
-    emit(f, line.data(), line.size());
+};
+
+struct Job {
+    int file = 0;
+    int mode = 0;
+    bool fastq = true;
+    Arena a, b;
+    std::vector<int32_t> ret, l, m, h;
+    bool done = false;
+    int rc = 0;
+    std::string err;
+};
+
+// Reads.h:224-266 for a whole block: sequence -> NUL-terminated arena, quality cut / padded to the
+// sequence length for the kernels (the output prints the quality line verbatim, see put_record)
+static void pack_arena(Arena &A, const std::string &path)
+{
+    const size_t n = A.n();
+    A.off.resize(n + 1);
+    A.off[0] = 0;
+    uint64_t total = 0;
+    for (size_t r = 0; r < n; ++r) {
+        uint32_t sl, il;
+        A.line(r, 1, &sl);
+        A.line(r, 0, &il);
+        if (sl > MAX_READ_LENGTH - 1)
+            die("ERROR: %s: a read of %u bases exceeds the limit of %d (utils.h:7)\n", path.c_str(), sl, MAX_READ_LENGTH - 1);
+        if (il > MAX_ID_LENGTH - 1) die("ERROR: %s: a header line longer than %d characters\n", path.c_str(), MAX_ID_LENGTH - 1);
+        total += sl + 1;
+        A.off[r + 1] = (uint32_t)total;
+    }
+    if (total >= (1ull << 32)) die("ERROR: batch too large; lower -batch\n");
+    A.seq.resize(total);
+    A.qual.assign(total, 0);
+    parallel_for(n, [&](size_t lo, size_t hi) {
+        for (size_t r = lo; r < hi; ++r) {
+            uint32_t sl, ql = 0;
+            const char *s = A.line(r, 1, &sl);
+            char *d = A.seq.data() + A.off[r];
+            memcpy(d, s, sl);
+            d[sl] = 0;
+            if (A.lpr == 4) {
+                const char *q = A.line(r, 3, &ql);
+                memcpy(A.qual.data() + A.off[r], q, std::min(ql, sl));
+            }
+        }
+    });
+}
+
+static inline char *put_int(char *p, int v)
+{
+    char tmp[16];
+    int n = 0;
+    unsigned u = v < 0 ? 0u - (unsigned)v : (unsigned)v;
+    do {
+        tmp[n++] = (char)('0' + u % 10);
+        u /= 10;
+    } while (u);
+    if (v < 0) *p++ = '-';
+    while (n) *p++ = tmp[--n];
+    return p;
+}
+
+// Reads.h:360-421: one record.  The quality line is printed as fgets left it in the reference:
+// stripped of its newline only when it is exactly as long as the sequence line (Reads.h:255-262).
+static inline void put_record(std::vector<char> &out, const Arena &A, size_t r, bool fastq, int cor, int l, int m, int h)
+{
+    uint32_t il, ql = 0;
+    const char *id = A.line(r, 0, &il);
+    const char *seq = A.seq.data() + A.off[r];
+    const uint32_t sl = A.off[r + 1] - A.off[r] - 1;
+    const char *q = fastq ? A.line(r, 3, &ql) : nullptr;
+    const size_t need = (size_t)il + sl + ql + 96;
+    const size_t at = out.size();
+    out.resize(at + need);
+    char *p = out.data() + at;
+    memcpy(p, id, il);
+    p += il;
+    memcpy(p, " l:", 3);
+    p = put_int(p + 3, l);
+    memcpy(p, " m:", 3);
+    p = put_int(p + 3, m);
+    memcpy(p, " h:", 3);
+    p = put_int(p + 3, h);
+    if (cor == -1) {
+        memcpy(p, " unfixable_error", 16);
+        p += 16;
+    } else if (cor > 0) {
+        memcpy(p, " cor", 4);
+        p += 4;
+    }
+    *p++ = '\n';
+    memcpy(p, seq, sl);
+    p += sl;
+    *p++ = '\n';
+    if (fastq) {
+        *p++ = '+';
+        *p++ = '\n';
+        memcpy(p, q, ql);
+        p += ql;
+        if (ql != sl) *p++ = '\n';  // fgets kept the quality line's own newline
+        *p++ = '\n';
+    }
+    out.resize((size_t)(p - out.data()));
 }
 
 static void print_help()
@@ -176,15 +389,6 @@ static void print_help()
             "\t-batch INT: reads per GPU batch (default: 1048576)\n");
 }
 
-// a batch travelling through the pipeline, with the verbatim quality strings for the writer
-struct Job {
-    Batch b;
-    std::vector<std::string> q1, q2;
-    bool done = false;
-    int rc = 0;
-    std::string err;
-};
-
 int main(int argc, char **argv)
 {
     int k = 23, max_fix_per_k = 4, gpus = 1, i;
@@ -193,6 +397,7 @@ int main(int argc, char **argv)
     std::string od = "./";
     size_t batch_reads = 1 << 20;
     bool verbose = false;
+    int t_flag = 0;
     if (argc == 1) {
         print_help();
         return 0;
@@ -213,7 +418,7 @@ int main(int argc, char **argv)
         } else if (!strcmp("-k", argv[i]))
             k = atoi(argv[++i]);
         else if (!strcmp("-t", argv[i]))
-            ++i;
+            t_flag = atoi(argv[++i]);
         else if (!strcmp("-maxcor", argv[i]))
             ++i;
         else if (!strcmp("-maxcorK", argv[i]))
@@ -240,26 +445,32 @@ int main(int argc, char **argv)
     if (!dump) die("Could not open file %s\n", "(no -c given)");
     if (gpus < 1) gpus = 1;
     if (batch_reads < 2) batch_reads = 2;
+    batch_reads &= ~(size_t)1;
+    {
+        unsigned hc = std::thread::hardware_concurrency();
+        g_threads = t_flag > 1 ? t_flag : (int)std::min<unsigned>(hc ? hc : 8, 32);
+        if (g_threads < 1) g_threads = 1;
+    }
+    g_timing = getenv("RC_TIMING") != nullptr;
 
-    Reader rd;
+    std::vector<ReadFile> files(0), mates(0);
+    files.reserve(MAX_READ_FILE);
+    mates.reserve(MAX_READ_FILE);
     for (i = 1; i < argc; ++i) {  // main.cpp:250-268
-        if (rd.files.size() >= MAX_READ_FILE && (!strcmp("-r", argv[i]) || !strcmp("-p", argv[i]) || !strcmp("-i", argv[i])))
-            die("The number of read files exceeds the limit %d.\n", MAX_READ_FILE);
+        const bool is_in = !strcmp("-r", argv[i]) || !strcmp("-p", argv[i]) || !strcmp("-i", argv[i]);
+        if (!is_in) continue;
+        if (files.size() >= MAX_READ_FILE) die("The number of read files exceeds the limit %d.\n", MAX_READ_FILE);
+        files.emplace_back();
+        mates.emplace_back();
         if (!strcmp("-r", argv[i])) {
-            rd.files.emplace_back();
-            rd.mates.emplace_back();
-            open_file(rd.files.back(), argv[i + 1], false, false, od);
+            open_file(files.back(), argv[i + 1], false, false, od);
             ++i;
         } else if (!strcmp("-p", argv[i])) {
-            rd.files.emplace_back();
-            rd.mates.emplace_back();
-            open_file(rd.files.back(), argv[i + 1], true, false, od);
-            open_file(rd.mates.back(), argv[i + 2], true, false, od);
+            open_file(files.back(), argv[i + 1], true, false, od);
+            open_file(mates.back(), argv[i + 2], true, false, od);
             i += 2;
-        } else if (!strcmp("-i", argv[i])) {
-            rd.files.emplace_back();
-            rd.mates.emplace_back();
-            open_file(rd.files.back(), argv[i + 1], false, true, od);
+        } else {
+            open_file(files.back(), argv[i + 1], false, true, od);
             ++i;
         }
     }
@@ -272,6 +483,7 @@ int main(int argc, char **argv)
         ctx[g] = rc_create(&cfg, err, sizeof err);
         if (!ctx[g]) die("rcorrector: %s\n", err);
     }
+    const double t_start = now_s();
     int64_t stored = 0;
     for (int g = 0; g < gpus; ++g)
         if (rc_table_load_jfdump(ctx[g], dump, &stored)) die("rcorrector: %s\n", rc_last_error(ctx[g]));
@@ -282,43 +494,46 @@ int main(int argc, char **argv)
 
     // GetBadQuality, main.cpp:88-128: first <= 1M records of the primary files, in order
     char bad_q = 0;
-    if (!rd.files.empty() && rd.files[0].fastq) {
+    if (!files.empty() && files[0].fastq) {
         std::vector<int32_t> fh(300, 0), lh(300, 0);
         int total = 0;
-        std::vector<char> s, q;
-        std::string id;
-        static char idb[MAX_ID_LENGTH], sb[MAX_READ_LENGTH], qb[MAX_READ_LENGTH], plus[2048];
-        for (size_t fi = 0; fi < rd.files.size() && total < 1000000; ++fi) {
-            ReadFile &f = rd.files[fi];
-            while (total < 1000000 && gzgets(f.in, idb, MAX_ID_LENGTH)) {
-                sb[0] = qb[0] = 0;
-                gzgets(f.in, sb, MAX_READ_LENGTH);
-                if (f.fastq) {
-                    gzgets(f.in, plus, sizeof plus);
-                    gzgets(f.in, qb, MAX_READ_LENGTH);
+        for (size_t fi = 0; fi < files.size() && total < 1000000; ++fi) {
+            Source s;
+            s.open(files[fi].path);
+            Block b;
+            const int lpr = files[fi].fastq ? 4 : 2;
+            while (total < 1000000) {
+                take_records(s, std::min<size_t>((size_t)(1000000 - total), (size_t)1 << 18), lpr, b);
+                if (b.records == 0) break;
+                for (size_t r = 0; r < b.records; ++r) {
+                    const uint32_t *L = b.line.data() + r * (size_t)lpr;
+                    const uint32_t sl = L[2] - L[1] - 1, ql = lpr == 4 ? L[4] - L[3] - 1 : 0;
+                    ++total;
+                    if (sl == 0 || lpr != 4) continue;
+                    const char *q = b.text.data() + L[3];
+                    // qual[strlen(seq)-1] and qual[0] of the reference's fgets buffers
+                    const unsigned char lastq = sl - 1 < ql ? (unsigned char)q[sl - 1] : (sl - 1 == ql ? (unsigned char)'\n' : 0);
+                    const unsigned char firstq = ql ? (unsigned char)q[0] : (unsigned char)'\n';
+                    ++lh[lastq];
+                    ++fh[firstq];
                 }
-                size_t len = strlen(sb);
-                if (len && sb[len - 1] == '\n') sb[len - 1] = 0;
-                if (f.fastq && len && qb[len - 1] == '\n') qb[len - 1] = 0;
-                size_t sl = strlen(sb);
-                if (sl == 0) continue;
-                ++lh[(int)(unsigned char)qb[sl - 1]];
-                ++fh[(int)(unsigned char)qb[0]];
-                ++total;
             }
-            gzrewind(f.in);
+            s.close();
         }
         bad_q = rc_bad_quality_from_hist(fh.data(), lh.data(), total);
     }
     fprintf(stderr, "Bad quality threshold is '%c'\n", bad_q);
     for (int g = 0; g < gpus; ++g) rc_set_run_params(ctx[g], rate, bad_q);
+    const double t_setup = now_s();
 
-    // pipeline: reader (this thread) -> one worker per GPU -> ordered writer (this thread)
+    // pipeline: reader (this thread) -> one worker per GPU -> writer thread (input order)
     std::mutex mu;
     std::condition_variable cv;
-    std::deque<std::shared_ptr<Job>> order;                   // submission order, for the writer
+    std::deque<std::shared_ptr<Job>> order;  // submission order, for the writer
     std::vector<std::deque<std::shared_ptr<Job>>> q((size_t)gpus);
-    bool closing = false;
+    bool closing = false, reader_done = false;
+    const size_t max_in_flight = (size_t)(2 * gpus + 2);
+
     std::vector<std::thread> workers;
     for (int g = 0; g < gpus; ++g) {
         workers.emplace_back([&, g]() {
@@ -331,28 +546,28 @@ int main(int argc, char **argv)
                     j = q[g].front();
                     q[g].pop_front();
                 }
-                Batch &b = j->b;
-                const size_t total = b.mode == 1 ? 2 * b.n() : b.n();
-                b.ret.assign(total, 0);
-                b.l.assign(total, 0);
-                b.m.assign(total, 0);
-                b.h.assign(total, 0);
+                const size_t n = j->a.n();
+                const size_t total = j->mode == 1 ? 2 * n : n;
+                j->ret.assign(total, 0);
+                j->l.assign(total, 0);
+                j->m.assign(total, 0);
+                j->h.assign(total, 0);
                 rc_batch rb;
                 memset(&rb, 0, sizeof rb);
-                rb.mode = b.mode;
-                rb.n = b.n();
-                rb.seq = b.seq.data();
-                rb.qual = b.qual.data();
-                rb.off = b.off.data();
-                if (b.mode == 1) {
-                    rb.seq2 = b.seq2.data();
-                    rb.qual2 = b.qual2.data();
-                    rb.off2 = b.off2.data();
+                rb.mode = j->mode;
+                rb.n = n;
+                rb.seq = j->a.seq.data();
+                rb.qual = j->a.qual.data();
+                rb.off = j->a.off.data();
+                if (j->mode == 1) {
+                    rb.seq2 = j->b.seq.data();
+                    rb.qual2 = j->b.qual.data();
+                    rb.off2 = j->b.off.data();
                 }
-                rb.ret = b.ret.data();
-                rb.l = b.l.data();
-                rb.m = b.m.data();
-                rb.h = b.h.data();
+                rb.ret = j->ret.data();
+                rb.l = j->l.data();
+                rb.m = j->m.data();
+                rb.h = j->h.data();
                 int rc = rc_correct_batch(ctx[g], &rb);
                 {
                     std::lock_guard<std::mutex> lk(mu);
@@ -366,108 +581,98 @@ int main(int argc, char **argv)
     }
 
     uint64_t total_reads = 0, total_cor = 0;
-    std::string line;
-    auto drain = [&](bool all) {
+    std::thread writer([&]() {
         for (;;) {
             std::shared_ptr<Job> j;
             {
                 std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return (!order.empty() && order.front()->done) || (reader_done && order.empty()); });
                 if (order.empty()) return;
-                if (!all && order.size() < (size_t)(2 * gpus) && !order.front()->done) return;
-                cv.wait(lk, [&] { return order.front()->done; });
                 j = order.front();
-                order.pop_front();
             }
             if (j->rc) die("rcorrector: %s\n", j->err.c_str());
-            Batch &b = j->b;
-            ReadFile &f = rd.files[b.file], &g2 = rd.mates[b.file];
-            const size_t n = b.n();
-            auto upd = [&](int c) {  // UpdateSummary, main.cpp:73-79
-                ++total_reads;
-                if (c > 0) total_cor += (uint64_t)c;
-            };
-            if (b.mode == 1 && g_stdout) {  // main.cpp:487-495
-                for (size_t u = 0; u < n; ++u) {
-                    write_record(f, b.id[u], b.seq.data() + b.off[u], j->q1[u].c_str(), b.ret[u], b.l[u], b.m[u], b.h[u], line);
-                    upd(b.ret[u]);
-                    write_record(g2, b.id2[u], b.seq2.data() + b.off2[u], j->q2[u].c_str(), b.ret[n + u], b.l[n + u], b.m[n + u], b.h[n + u], line);
-                    upd(b.ret[n + u]);
-                }
-            } else {
-                for (size_t u = 0; u < n; ++u) {
-                    write_record(f, b.id[u], b.seq.data() + b.off[u], j->q1[u].c_str(), b.ret[u], b.l[u], b.m[u], b.h[u], line);
-                    upd(b.ret[u]);
-                }
-                if (b.mode == 1)
-                    for (size_t u = 0; u < n; ++u) {
-                        write_record(g2, b.id2[u], b.seq2.data() + b.off2[u], j->q2[u].c_str(), b.ret[n + u], b.l[n + u], b.m[n + u], b.h[n + u], line);
-                        upd(b.ret[n + u]);
+            const size_t n = j->a.n();
+            ReadFile &f = files[(size_t)j->file], &g2 = mates[(size_t)j->file];
+            const bool alternate = j->mode == 1 && g_stdout;  // main.cpp:487-495
+            // format slices in parallel, write them in order
+            const size_t S = std::max<size_t>(1, std::min<size_t>((size_t)g_threads, (n + 8191) / 8192));
+            std::vector<std::vector<char>> o1(S), o2(S);
+            auto fmt = [&](size_t lo, size_t hi) {
+                for (size_t s = lo; s < hi; ++s) {
+                    const size_t r0 = n * s / S, r1 = n * (s + 1) / S;
+                    o1[s].reserve((r1 - r0) * 300);
+                    for (size_t r = r0; r < r1; ++r) {
+                        put_record(o1[s], j->a, r, j->fastq, j->ret[r], j->l[r], j->m[r], j->h[r]);
+                        if (alternate) put_record(o1[s], j->b, r, j->fastq, j->ret[n + r], j->l[n + r], j->m[n + r], j->h[n + r]);
                     }
+                    if (j->mode == 1 && !alternate) {
+                        o2[s].reserve((r1 - r0) * 300);
+                        for (size_t r = r0; r < r1; ++r)
+                            put_record(o2[s], j->b, r, j->fastq, j->ret[n + r], j->l[n + r], j->m[n + r], j->h[n + r]);
+                    }
+                }
+            };
+            if (S == 1) {
+                fmt(0, 1);
+            } else {
+                std::vector<std::thread> th;
+                for (size_t s = 0; s < S; ++s) th.emplace_back([&, s]() { fmt(s, s + 1); });
+                for (auto &x : th) x.join();
             }
+            for (size_t s = 0; s < S; ++s) emit(f, o1[s].data(), o1[s].size());
+            if (j->mode == 1 && !alternate)
+                for (size_t s = 0; s < S; ++s) emit(g2, o2[s].data(), o2[s].size());
+            for (size_t r = 0; r < j->ret.size(); ++r) {  // UpdateSummary, main.cpp:73-79
+                ++total_reads;
+                if (j->ret[r] > 0) total_cor += (uint64_t)j->ret[r];
+            }
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                order.pop_front();
+            }
+            cv.notify_all();
         }
-    };
+    });
 
-    // reader loop.  The verbatim quality line of each record is kept next to the batch because the
-    // output prints it unchanged even when it is longer or shorter than the sequence.
+    // reader
     {
         size_t seqno = 0;
-        for (size_t fi = 0; fi < rd.files.size(); ++fi) {
-            ReadFile &f = rd.files[fi];
+        for (size_t fi = 0; fi < files.size(); ++fi) {
+            ReadFile &f = files[fi];
+            const int lpr = f.fastq ? 4 : 2;
             for (;;) {
                 auto j = std::make_shared<Job>();
-                Batch &b = j->b;
-                b.file = (int)fi;
-                b.mode = f.paired ? 1 : (f.interleaved ? 2 : 0);
-                b.off.push_back(0);
-                b.off2.push_back(0);
-                static char idb[MAX_ID_LENGTH], sb[MAX_READ_LENGTH], qb[MAX_READ_LENGTH], plus[2048];
-                auto read_one = [&](ReadFile &rf, std::vector<char> &sa, std::vector<char> &qa, std::vector<uint32_t> &off,
-                                    std::vector<std::string> &ids, std::vector<std::string> &quals) -> bool {
-                    if (!gzgets(rf.in, idb, MAX_ID_LENGTH)) return false;
-                    sb[0] = qb[0] = 0;
-                    gzgets(rf.in, sb, MAX_READ_LENGTH);
-                    if (rf.fastq) {
-                        gzgets(rf.in, plus, sizeof plus);
-                        gzgets(rf.in, qb, MAX_READ_LENGTH);
-                    }
-                    size_t il = strlen(idb);
-                    if (il && idb[il - 1] == '\n') idb[il - 1] = 0;
-                    size_t len = strlen(sb);
-                    if (len && sb[len - 1] == '\n') sb[len - 1] = 0;
-                    if (rf.fastq && len && qb[len - 1] == '\n') qb[len - 1] = 0;
-                    size_t sl = strlen(sb), ql = strlen(qb);
-                    ids.emplace_back(idb);
-                    quals.emplace_back(qb);
-                    sa.insert(sa.end(), sb, sb + sl + 1);
-                    size_t at = qa.size();
-                    qa.resize(at + sl + 1, 0);
-                    memcpy(qa.data() + at, qb, ql < sl ? ql : sl);
-                    off.push_back((uint32_t)sa.size());
-                    return true;
-                };
-                const size_t cap = batch_reads & ~(size_t)1;
-                while (b.id.size() < cap) {
-                    if (!read_one(f, b.seq, b.qual, b.off, b.id, j->q1)) break;
-                    if (f.paired && !read_one(rd.mates[fi], b.seq2, b.qual2, b.off2, b.id2, j->q2))
-                        die("ERROR: The files are not paired!\n");
+                j->file = (int)fi;
+                j->mode = f.paired ? 1 : (f.interleaved ? 2 : 0);
+                j->fastq = f.fastq;
+                j->a.lpr = lpr;
+                j->b.lpr = f.paired ? (mates[fi].fastq ? 4 : 2) : lpr;
+                take_records(f.src, batch_reads, lpr, j->a.blk);
+                if (f.paired) {
+                    take_records(mates[fi].src, j->a.blk.records ? j->a.blk.records : 1, j->b.lpr, j->b.blk);
+                    if (j->b.blk.records != j->a.blk.records) die("ERROR: The files are not paired!\n");
                 }
-                if (b.id.empty()) {
-                    if (f.paired && gzgets(rd.mates[fi].in, idb, MAX_ID_LENGTH)) die("ERROR: The files are not paired!\n");
-                    break;
-                }
-                if (b.mode == 2 && (b.id.size() & 1)) die("ERROR: interleaved file %s holds an odd number of reads\n", f.path.c_str());
+                if (j->a.blk.records == 0) break;
+                if (j->mode == 2 && (j->a.blk.records & 1)) die("ERROR: interleaved file %s holds an odd number of reads\n", f.path.c_str());
+                pack_arena(j->a, f.path);
+                if (f.paired) pack_arena(j->b, mates[fi].path);
                 {
-                    std::lock_guard<std::mutex> lk(mu);
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return order.size() < max_in_flight; });
                     order.push_back(j);
                     q[seqno % (size_t)gpus].push_back(j);
                 }
                 ++seqno;
                 cv.notify_all();
-                drain(false);
             }
         }
     }
-    drain(true);
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        reader_done = true;
+    }
+    cv.notify_all();
+    writer.join();
     {
         std::lock_guard<std::mutex> lk(mu);
         closing = true;
@@ -475,14 +680,17 @@ int main(int argc, char **argv)
     cv.notify_all();
     for (auto &t : workers) t.join();
 
-    for (size_t fi = 0; fi < rd.files.size(); ++fi) {
-        for (ReadFile *f : {&rd.files[fi], &rd.mates[fi]}) {
+    for (size_t fi = 0; fi < files.size(); ++fi) {
+        for (ReadFile *f : {&files[fi], &mates[fi]}) {
             if (f->outz) gzclose(f->outz);
             if (f->out && f->out != stdout) fclose(f->out);
-            if (f->in) gzclose(f->in);
+            f->src.close();
         }
     }
     for (int g = 0; g < gpus; ++g) rc_destroy(ctx[g]);
+    if (g_timing)
+        fprintf(stderr, "[rc timing] start-up (dump load, table build, ERROR_RATE, bad quality) %.2f s; correction loop (read, correct, write) %.2f s; %d host threads\n",
+                t_setup - t_start, now_s() - t_setup, g_threads);
     fprintf(stderr, "Processed %llu reads\n\tCorrected %llu bases.\n", (unsigned long long)total_reads, (unsigned long long)total_cor);
     return 0;
 }

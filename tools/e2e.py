@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""End-to-end timing of the `rcorrector` CLI (FASTQ in -> *.cor.fq out) on synthetic data.
+Generates reads on the GPU (bench.synth_reads_gpu), writes FASTQ + a jf_dump-format k-mer dump
+(counted on the GPU, exported through the C ABI), then times the CLI.  Dev/measurement tool."""
+import argparse
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import bench  # noqa: E402
+import rcorrector_amd  # noqa: E402
+import synth  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reads", type=int, default=2_000_000)
+    ap.add_argument("--len", type=int, default=100)
+    ap.add_argument("-k", type=int, default=23)
+    ap.add_argument("--n-tx", type=int, default=2000)
+    ap.add_argument("--dir", default="/tmp/rc_e2e")
+    ap.add_argument("--cli-args", default="")
+    a = ap.parse_args()
+    os.makedirs(a.dir, exist_ok=True)
+    dev = torch.device("cuda", 0)
+    n, L, k = a.reads, a.len, a.k
+    seq, qual = bench.synth_reads_gpu(77000, n, L, a.n_tx, 1500, 0.8, 0.005, dev)
+    ctx = rcorrector_amd.Context(k=k)
+    nk = ctx.count_reads_device(seq, seq.numel(), 2)
+    codes, counts = ctx.table_export()
+    o = np.argsort(codes)
+    codes, counts = codes[o], counts[o]
+    t0 = time.time()
+    txt = synth.decode_kmers(codes, k)
+    with open(os.path.join(a.dir, "x.jf"), "wb") as f:
+        parts = []
+        for i in range(len(codes)):
+            parts.append(b">%d\n%s\n" % (counts[i], txt[i].tobytes()))
+            if len(parts) >= 1 << 16:
+                f.write(b"".join(parts))
+                parts = []
+        f.write(b"".join(parts))
+    # FASTQ with fixed-width ids: one numpy 2-D array
+    s = seq.view(n, L + 1)[:, :L].cpu().numpy()
+    q = qual.view(n, L + 1)[:, :L].cpu().numpy()
+    ids = np.char.zfill(np.arange(n).astype(str), 9)
+    idb = np.frombuffer("".join(ids.tolist()).encode(), dtype=np.uint8).reshape(n, 9)
+    rec = np.empty((n, 2 + 9 + 1 + L + 1 + 2 + L + 1), dtype=np.uint8)
+    c = 0
+    rec[:, 0] = ord('@'); rec[:, 1] = ord('r'); c = 2
+    rec[:, c:c + 9] = idb; c += 9
+    rec[:, c] = 10; c += 1
+    rec[:, c:c + L] = s; c += L
+    rec[:, c] = 10; c += 1
+    rec[:, c] = ord('+'); rec[:, c + 1] = 10; c += 2
+    rec[:, c:c + L] = q; c += L
+    rec[:, c] = 10
+    rec.tofile(os.path.join(a.dir, "x.fq"))
+    print("generated %d reads, %d k-mers in %.1f s (fq %.0f MB, dump %.0f MB)" % (
+        n, nk, time.time() - t0, os.path.getsize(os.path.join(a.dir, "x.fq")) / 1e6,
+        os.path.getsize(os.path.join(a.dir, "x.jf")) / 1e6), file=sys.stderr)
+    del ctx
+    cli = os.path.join(ROOT, "rcorrector_amd", "rcorrector")
+    env = dict(os.environ, RC_TIMING="1")
+    t0 = time.time()
+    p = subprocess.run([cli, "-r", "x.fq", "-k", str(k), "-c", "x.jf", "-od", a.dir + "/out"] + a.cli_args.split(),
+                       cwd=a.dir, env=env, stderr=subprocess.PIPE)
+    dt = time.time() - t0
+    sys.stderr.write(p.stderr.decode())
+    print("CLI wall %.2f s -> %.2f M reads/s end to end" % (dt, n / dt / 1e6))
+
+
+if __name__ == "__main__":
+    main()
