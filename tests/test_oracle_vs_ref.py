@@ -1,0 +1,28 @@
+"""CPU (build container only): the oracle's CLI against the UNMODIFIED reference binary on the same
+random inputs the GPU fuzz test uses -- this is what makes `oracle_cli` a valid stand-in for the
+reference on the GPU box.  Skipped where oracle/_ref was not built (no /root/reference)."""
+import os
+import subprocess
+
+import pytest
+
+from test_gpu_fuzz import _random_case
+
+
+@pytest.mark.parametrize("seed", list(range(900, 940)))
+def test_oracle_cli_equals_reference_on_random_inputs(oracle, seed, tmp_path):
+    if not os.path.exists(oracle.REF_BIN):
+        pytest.skip("oracle/_ref not built here (no /root/reference)")
+    d = str(tmp_path)
+    args = _random_case(seed, d)
+    outs = {}
+    for name, binary, more in (("ref", oracle.REF_BIN, ["-t", "3"] if seed % 2 else []), ("cpu", oracle.CLI_BIN, ["-t", "2"])):
+        od = os.path.join(d, name)
+        os.makedirs(od)
+        p = subprocess.run([binary] + args + ["-od", od] + more, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert p.returncode == 0, p.stderr.decode()
+        outs[name] = (p.stderr, {f: open(os.path.join(od, f), "rb").read() for f in sorted(os.listdir(od))})
+    assert outs["ref"][1].keys() == outs["cpu"][1].keys() and outs["ref"][1]
+    for f in outs["ref"][1]:
+        assert outs["ref"][1][f] == outs["cpu"][1][f], "%s differs (seed %d, args %s)" % (f, seed, args)
+    assert outs["ref"][0] == outs["cpu"][0], "stderr differs (seed %d)" % seed
