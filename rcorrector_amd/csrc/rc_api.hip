@@ -148,18 +148,14 @@ int rc_table_build(rc_ctx *ctx, const uint64_t *codes, const int32_t *counts, si
 {
     if (!ctx || (n && (!codes || !counts))) return RC_ERR_ARG;
     RC_CHECK_HIP(ctx, hipSetDevice(ctx->device));
-    uint64_t *d_codes = nullptr;
-    int32_t *d_counts = nullptr;
+    rc_dev_tmp b_codes, b_counts;
     if (n) {
-        RC_CHECK_HIP(ctx, hipMalloc(&d_codes, n * 8));
-        RC_CHECK_HIP(ctx, hipMalloc(&d_counts, n * 4));
-        RC_CHECK_HIP(ctx, hipMemcpyAsync(d_codes, codes, n * 8, hipMemcpyHostToDevice, ctx->stream));
-        RC_CHECK_HIP(ctx, hipMemcpyAsync(d_counts, counts, n * 4, hipMemcpyHostToDevice, ctx->stream));
+        RC_CHECK_HIP(ctx, b_codes.alloc(n * 8));
+        RC_CHECK_HIP(ctx, b_counts.alloc(n * 4));
+        RC_CHECK_HIP(ctx, hipMemcpyAsync(b_codes.p, codes, n * 8, hipMemcpyHostToDevice, ctx->stream));
+        RC_CHECK_HIP(ctx, hipMemcpyAsync(b_counts.p, counts, n * 4, hipMemcpyHostToDevice, ctx->stream));
     }
-    int rc = rc_table_build_device(ctx, d_codes, d_counts, n);
-    if (d_codes) (void)hipFree(d_codes);
-    if (d_counts) (void)hipFree(d_counts);
-    return rc;
+    return rc_table_build_device(ctx, b_codes.as<uint64_t>(), b_counts.as<int32_t>(), n);
 }
 
 // main.cpp:294-308.  Tokens are whitespace separated (fscanf "%s"); the first of a pair is
@@ -326,19 +322,15 @@ int rc_table_lookup(rc_ctx *ctx, const uint64_t *codes, size_t n, int32_t *out)
     }
     if (n == 0) return RC_OK;
     RC_CHECK_HIP(ctx, hipSetDevice(ctx->device));
-    uint64_t *d_codes = nullptr;
-    int32_t *d_out = nullptr;
-    RC_CHECK_HIP(ctx, hipMalloc(&d_codes, n * 8));
-    RC_CHECK_HIP(ctx, hipMalloc(&d_out, n * 4));
-    RC_CHECK_HIP(ctx, hipMemcpyAsync(d_codes, codes, n * 8, hipMemcpyHostToDevice, ctx->stream));
-    int rc = rc_launch_lookup(ctx, d_codes, n, d_out);
-    if (rc == RC_OK) {
-        RC_CHECK_HIP(ctx, hipMemcpyAsync(out, d_out, n * 4, hipMemcpyDeviceToHost, ctx->stream));
-        RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    }
-    (void)hipFree(d_codes);
-    (void)hipFree(d_out);
-    return rc;
+    rc_dev_tmp b_codes, b_out;
+    RC_CHECK_HIP(ctx, b_codes.alloc(n * 8));
+    RC_CHECK_HIP(ctx, b_out.alloc(n * 4));
+    RC_CHECK_HIP(ctx, hipMemcpyAsync(b_codes.p, codes, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    int rc = rc_launch_lookup(ctx, b_codes.as<uint64_t>(), n, b_out.as<int32_t>());
+    if (rc) return rc;
+    RC_CHECK_HIP(ctx, hipMemcpyAsync(out, b_out.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RC_OK;
 }
 
 int rc_table_export(rc_ctx *ctx, uint64_t *codes, int32_t *counts, size_t cap, size_t *n_out)
@@ -349,28 +341,23 @@ int rc_table_export(rc_ctx *ctx, uint64_t *codes, int32_t *counts, size_t cap, s
         return RC_ERR_STATE;
     }
     RC_CHECK_HIP(ctx, hipSetDevice(ctx->device));
-    uint64_t *d_codes = nullptr;
-    int32_t *d_counts = nullptr;
-    unsigned long long *d_n = nullptr, n = 0;
-    RC_CHECK_HIP(ctx, hipMalloc(&d_codes, (cap + 1) * 8));
-    RC_CHECK_HIP(ctx, hipMalloc(&d_counts, (cap + 1) * 4));
-    RC_CHECK_HIP(ctx, hipMalloc(&d_n, 8));
-    RC_CHECK_HIP(ctx, hipMemsetAsync(d_n, 0, 8, ctx->stream));
-    int rc = rc_launch_export(ctx, d_codes, d_counts, d_n, cap);
-    if (rc == RC_OK) {
-        RC_CHECK_HIP(ctx, hipMemcpyAsync(&n, d_n, 8, hipMemcpyDeviceToHost, ctx->stream));
-        RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        const size_t m = n < cap ? (size_t)n : cap;
-        if (m) {
-            RC_CHECK_HIP(ctx, hipMemcpy(codes, d_codes, m * 8, hipMemcpyDeviceToHost));
-            RC_CHECK_HIP(ctx, hipMemcpy(counts, d_counts, m * 4, hipMemcpyDeviceToHost));
-        }
-        *n_out = (size_t)n;
+    rc_dev_tmp b_codes, b_counts, b_n;
+    unsigned long long n = 0;
+    RC_CHECK_HIP(ctx, b_codes.alloc((cap + 1) * 8));
+    RC_CHECK_HIP(ctx, b_counts.alloc((cap + 1) * 4));
+    RC_CHECK_HIP(ctx, b_n.alloc(8));
+    RC_CHECK_HIP(ctx, hipMemsetAsync(b_n.p, 0, 8, ctx->stream));
+    int rc = rc_launch_export(ctx, b_codes.as<uint64_t>(), b_counts.as<int32_t>(), b_n.as<unsigned long long>(), cap);
+    if (rc) return rc;
+    RC_CHECK_HIP(ctx, hipMemcpyAsync(&n, b_n.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t m = n < cap ? (size_t)n : cap;
+    if (m) {
+        RC_CHECK_HIP(ctx, hipMemcpy(codes, b_codes.p, m * 8, hipMemcpyDeviceToHost));
+        RC_CHECK_HIP(ctx, hipMemcpy(counts, b_counts.p, m * 4, hipMemcpyDeviceToHost));
     }
-    (void)hipFree(d_codes);
-    (void)hipFree(d_counts);
-    (void)hipFree(d_n);
-    return rc;
+    *n_out = (size_t)n;
+    return RC_OK;
 }
 
 int rc_table_stats(const rc_ctx *ctx, uint64_t *bytes, uint64_t *buckets, uint64_t *entries)
@@ -403,17 +390,14 @@ int rc_estimate_error_rate(rc_ctx *c, double wk, double *rate_out)
     const size_t n = D.codes.size();
     std::vector<int32_t> mx2(2 * n);
     if (n) {
-        uint64_t *d_codes = nullptr;
-        int32_t *d_out = nullptr;
-        RC_CHECK_HIP(ctx, hipMalloc(&d_codes, n * 8));
-        RC_CHECK_HIP(ctx, hipMalloc(&d_out, n * 8));
-        RC_CHECK_HIP(ctx, hipMemcpyAsync(d_codes, D.codes.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
-        int rc = rc_launch_last_base_variants(ctx, d_codes, n, d_out);
+        rc_dev_tmp b_codes, b_out;
+        RC_CHECK_HIP(ctx, b_codes.alloc(n * 8));
+        RC_CHECK_HIP(ctx, b_out.alloc(n * 8));
+        RC_CHECK_HIP(ctx, hipMemcpyAsync(b_codes.p, D.codes.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
+        int rc = rc_launch_last_base_variants(ctx, b_codes.as<uint64_t>(), n, b_out.as<int32_t>());
         if (rc) return rc;
-        RC_CHECK_HIP(ctx, hipMemcpyAsync(mx2.data(), d_out, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        RC_CHECK_HIP(ctx, hipMemcpyAsync(mx2.data(), b_out.p, n * 8, hipMemcpyDeviceToHost, ctx->stream));
         RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        (void)hipFree(d_codes);
-        (void)hipFree(d_out);
     }
     const int rate_size = 100000;
     std::vector<double> store((size_t)rate_size + 2, 0.0);

@@ -18,6 +18,27 @@
 
 enum { RC_OK = 0, RC_ERR_ARG = -1, RC_ERR_HIP = -2, RC_ERR_IO = -3, RC_ERR_STATE = -4, RC_ERR_NOMEM = -5 };
 
+// scoped device allocation: freed on every exit path of the function that owns it
+struct rc_dev_tmp {
+    void *p = nullptr;
+    rc_dev_tmp() = default;
+    rc_dev_tmp(const rc_dev_tmp &) = delete;
+    rc_dev_tmp &operator=(const rc_dev_tmp &) = delete;
+    ~rc_dev_tmp() { reset(); }
+    void reset()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+    }
+    hipError_t alloc(size_t bytes)
+    {
+        reset();
+        return hipMalloc(&p, bytes ? bytes : 1);
+    }
+    template <class T>
+    T *as() const { return static_cast<T *>(p); }
+};
+
 // grow-only device buffer
 struct rc_dbuf {
     void *p = nullptr;

@@ -85,27 +85,27 @@ int rc_build_table_from_device_pairs(rc_ctx *ctx, const uint64_t *d_canon, const
     while ((1ull << bits) < (uint64_t)nb_home) ++bits;
 
     long long p_last = -1;
-    uint32_t *home = nullptr, *home_s = nullptr, *idx = nullptr, *idx_s = nullptr;
-    long long *q = nullptr, *qm = nullptr;
-    void *tmp = nullptr;
-    int rc = RC_OK;
+    rc_dev_tmp b_home, b_home_s, b_idx, b_idx_s, b_q, b_qm, b_tmp;
     const unsigned B = 256;
     const unsigned G = (unsigned)((n + B - 1) / B);
     if (n > 0) {
         size_t tmp_sort = 0, tmp_scan = 0;
-        RC_CHECK_HIP(ctx, hipMalloc(&home, n * 4));
-        RC_CHECK_HIP(ctx, hipMalloc(&home_s, n * 4));
-        RC_CHECK_HIP(ctx, hipMalloc(&idx, n * 4));
-        RC_CHECK_HIP(ctx, hipMalloc(&idx_s, n * 4));
-        RC_CHECK_HIP(ctx, hipMalloc(&q, n * 8));
-        RC_CHECK_HIP(ctx, hipMalloc(&qm, n * 8));
+        RC_CHECK_HIP(ctx, b_home.alloc(n * 4));
+        RC_CHECK_HIP(ctx, b_home_s.alloc(n * 4));
+        RC_CHECK_HIP(ctx, b_idx.alloc(n * 4));
+        RC_CHECK_HIP(ctx, b_idx_s.alloc(n * 4));
+        RC_CHECK_HIP(ctx, b_q.alloc(n * 8));
+        RC_CHECK_HIP(ctx, b_qm.alloc(n * 8));
+        uint32_t *home = b_home.as<uint32_t>(), *home_s = b_home_s.as<uint32_t>();
+        uint32_t *idx = b_idx.as<uint32_t>(), *idx_s = b_idx_s.as<uint32_t>();
+        long long *q = b_q.as<long long>(), *qm = b_qm.as<long long>();
         hipLaunchKernelGGL(k_home_and_index, dim3(G), dim3(B), 0, ctx->stream, d_canon, home, idx, n, ctx->nb_home);
         RC_CHECK_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp_sort, home, home_s, idx, idx_s, n, 0, bits > 0 ? bits : 1, ctx->stream));
         RC_CHECK_HIP(ctx, rocprim::inclusive_scan(nullptr, tmp_scan, q, qm, n, rocprim::maximum<long long>(), ctx->stream));
-        RC_CHECK_HIP(ctx, hipMalloc(&tmp, tmp_sort > tmp_scan ? tmp_sort : tmp_scan));
-        RC_CHECK_HIP(ctx, rocprim::radix_sort_pairs(tmp, tmp_sort, home, home_s, idx, idx_s, n, 0, bits > 0 ? bits : 1, ctx->stream));
+        RC_CHECK_HIP(ctx, b_tmp.alloc(tmp_sort > tmp_scan ? tmp_sort : tmp_scan));
+        RC_CHECK_HIP(ctx, rocprim::radix_sort_pairs(b_tmp.p, tmp_sort, home, home_s, idx, idx_s, n, 0, bits > 0 ? bits : 1, ctx->stream));
         hipLaunchKernelGGL(k_slot_seed, dim3(G), dim3(B), 0, ctx->stream, home_s, q, n);
-        RC_CHECK_HIP(ctx, rocprim::inclusive_scan(tmp, tmp_scan, q, qm, n, rocprim::maximum<long long>(), ctx->stream));
+        RC_CHECK_HIP(ctx, rocprim::inclusive_scan(b_tmp.p, tmp_scan, q, qm, n, rocprim::maximum<long long>(), ctx->stream));
         long long q_last = 0;
         RC_CHECK_HIP(ctx, hipMemcpyAsync(&q_last, qm + (n - 1), 8, hipMemcpyDeviceToHost, ctx->stream));
         RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -122,19 +122,13 @@ int rc_build_table_from_device_pairs(rc_ctx *ctx, const uint64_t *d_canon, const
     RC_CHECK_HIP(ctx, hipMalloc((void **)&ctx->d_buckets, ctx->table_bytes));
     RC_CHECK_HIP(ctx, hipMemsetAsync(ctx->d_buckets, 0, ctx->table_bytes, ctx->stream));
     if (n > 0) {
-        hipLaunchKernelGGL(k_scatter, dim3(G), dim3(B), 0, ctx->stream, home_s, idx_s, qm, d_canon, d_counts, ctx->d_buckets, n);
+        hipLaunchKernelGGL(k_scatter, dim3(G), dim3(B), 0, ctx->stream, b_home_s.as<uint32_t>(), b_idx_s.as<uint32_t>(),
+                           b_qm.as<long long>(), d_canon, d_counts, ctx->d_buckets, n);
         RC_CHECK_HIP(ctx, hipGetLastError());
     }
     RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    (void)hipFree(home);
-    (void)hipFree(home_s);
-    (void)hipFree(idx);
-    (void)hipFree(idx_s);
-    (void)hipFree(q);
-    (void)hipFree(qm);
-    (void)hipFree(tmp);
     ctx->n_entries = n;
-    return rc;
+    return RC_OK;
 }
 
 // forward (or canonical) reference codes -> canonical, in place
@@ -377,55 +371,50 @@ int rc_count_reads(rc_ctx *ctx, const uint8_t *d_seq, size_t nbytes, int min_cou
         return RC_ERR_ARG;
     }
     const int k = ctx->k;
-    uint64_t *keys = nullptr, *keys_s = nullptr, *uniq = nullptr, *sel_k = nullptr;
-    uint32_t *cnt = nullptr, *sel_c = nullptr;
-    uint8_t *keep = nullptr;
-    size_t *d_runs = nullptr, *d_nsel = nullptr;
-    void *tmp = nullptr;
+    rc_dev_tmp b_keys, b_keys_s, b_cnt, b_keep, b_selc, b_runs, b_tmp;
     size_t t_sort = 0, t_rle = 0, t_sel = 0;
-    RC_CHECK_HIP(ctx, hipMalloc(&keys, nbytes * 8));
-    RC_CHECK_HIP(ctx, hipMalloc(&keys_s, nbytes * 8));
-    RC_CHECK_HIP(ctx, hipMalloc(&d_runs, sizeof(size_t) * 2));
-    d_nsel = d_runs + 1;
+    RC_CHECK_HIP(ctx, b_keys.alloc(nbytes * 8));
+    RC_CHECK_HIP(ctx, b_keys_s.alloc(nbytes * 8));
+    RC_CHECK_HIP(ctx, b_runs.alloc(sizeof(size_t) * 2));
+    uint64_t *keys = b_keys.as<uint64_t>(), *keys_s = b_keys_s.as<uint64_t>();
+    size_t *d_runs = b_runs.as<size_t>(), *d_nsel = d_runs + 1;
     const unsigned G = (unsigned)((nbytes + RC_PROBE_TILE - 1) / RC_PROBE_TILE);
     hipLaunchKernelGGL(k_emit_kmers, dim3(G), dim3(RC_PROBE_THREADS), 0, ctx->stream, d_seq, nbytes, k, keys);
     RC_CHECK_HIP(ctx, hipGetLastError());
     RC_CHECK_HIP(ctx, rocprim::radix_sort_keys(nullptr, t_sort, keys, keys_s, nbytes, 0, 64, ctx->stream));
-    RC_CHECK_HIP(ctx, hipMalloc(&tmp, t_sort));
-    RC_CHECK_HIP(ctx, rocprim::radix_sort_keys(tmp, t_sort, keys, keys_s, nbytes, 0, 64, ctx->stream));
-    (void)hipFree(tmp);
-    tmp = nullptr;
+    RC_CHECK_HIP(ctx, b_tmp.alloc(t_sort));
+    RC_CHECK_HIP(ctx, rocprim::radix_sort_keys(b_tmp.p, t_sort, keys, keys_s, nbytes, 0, 64, ctx->stream));
     // run-length encode; unique keys reuse `keys`
-    uniq = keys;
-    RC_CHECK_HIP(ctx, hipMalloc(&cnt, nbytes * 4));
+    uint64_t *uniq = keys;
+    RC_CHECK_HIP(ctx, b_cnt.alloc(nbytes * 4));
+    uint32_t *cnt = b_cnt.as<uint32_t>();
     RC_CHECK_HIP(ctx, rocprim::run_length_encode(nullptr, t_rle, keys_s, (unsigned int)nbytes, uniq, cnt, d_runs, ctx->stream));
-    RC_CHECK_HIP(ctx, hipMalloc(&tmp, t_rle));
-    RC_CHECK_HIP(ctx, rocprim::run_length_encode(tmp, t_rle, keys_s, (unsigned int)nbytes, uniq, cnt, d_runs, ctx->stream));
+    RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    RC_CHECK_HIP(ctx, b_tmp.alloc(t_rle));
+    RC_CHECK_HIP(ctx, rocprim::run_length_encode(b_tmp.p, t_rle, keys_s, (unsigned int)nbytes, uniq, cnt, d_runs, ctx->stream));
     size_t runs = 0;
     RC_CHECK_HIP(ctx, hipMemcpyAsync(&runs, d_runs, sizeof(size_t), hipMemcpyDeviceToHost, ctx->stream));
     RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    (void)hipFree(tmp);
-    tmp = nullptr;
     // keep count >= min_count (and drop the sentinel run)
-    RC_CHECK_HIP(ctx, hipMalloc(&keep, runs + 1));
+    RC_CHECK_HIP(ctx, b_keep.alloc(runs + 1));
+    uint8_t *keep = b_keep.as<uint8_t>();
     hipLaunchKernelGGL(k_flag_keep, dim3((unsigned)((runs + 255) / 256)), dim3(256), 0, ctx->stream, uniq, cnt, runs, min_count, keep);
-    sel_k = keys_s;  // sorted keys no longer needed
-    RC_CHECK_HIP(ctx, hipMalloc(&sel_c, (runs + 1) * 4));
+    uint64_t *sel_k = keys_s;  // sorted keys no longer needed
+    RC_CHECK_HIP(ctx, b_selc.alloc((runs + 1) * 4));
+    uint32_t *sel_c = b_selc.as<uint32_t>();
     RC_CHECK_HIP(ctx, rocprim::select(nullptr, t_sel, uniq, keep, sel_k, d_nsel, runs, ctx->stream));
-    RC_CHECK_HIP(ctx, hipMalloc(&tmp, t_sel));
-    RC_CHECK_HIP(ctx, rocprim::select(tmp, t_sel, uniq, keep, sel_k, d_nsel, runs, ctx->stream));
-    RC_CHECK_HIP(ctx, rocprim::select(tmp, t_sel, cnt, keep, sel_c, d_nsel, runs, ctx->stream));
+    RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    RC_CHECK_HIP(ctx, b_tmp.alloc(t_sel));
+    RC_CHECK_HIP(ctx, rocprim::select(b_tmp.p, t_sel, uniq, keep, sel_k, d_nsel, runs, ctx->stream));
+    RC_CHECK_HIP(ctx, rocprim::select(b_tmp.p, t_sel, cnt, keep, sel_c, d_nsel, runs, ctx->stream));
     size_t nsel = 0;
     RC_CHECK_HIP(ctx, hipMemcpyAsync(&nsel, d_nsel, sizeof(size_t), hipMemcpyDeviceToHost, ctx->stream));
     RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    (void)hipFree(tmp);
-    (void)hipFree(keep);
-    (void)hipFree(cnt);
+    b_tmp.reset();
+    b_keep.reset();
+    b_cnt.reset();
+    b_keys.reset();  // `uniq`: consumed by the select above
     int rc = rc_build_table_from_device_pairs(ctx, sel_k, reinterpret_cast<const int32_t *>(sel_c), nsel);
-    (void)hipFree(sel_c);
-    (void)hipFree(keys);
-    (void)hipFree(keys_s);
-    (void)hipFree(d_runs);
     if (n_kmers) *n_kmers = (int64_t)nsel;
     return rc;
 }
