@@ -132,6 +132,12 @@ int rc_profile_enable(rc_ctx *ctx, int on);
 int rc_profile_get(rc_ctx *ctx, int kernel, double *total_ms, uint64_t *launches);
 int rc_profile_reset(rc_ctx *ctx);
 
+/* diagnostic: GetBound(c) (ErrorCorrection.cpp:139-142) exactly as the kernels evaluate it, for n
+ * counts and one error rate: out_int = the implicit double->int conversion (cvttsd2si semantics),
+ * out_dbl = the double itself (NaN for c < 0).  Lets a test compare the device arithmetic with the
+ * host's bit for bit. */
+int rc_selftest_get_bound(rc_ctx *ctx, const int32_t *c, size_t n, double error_rate, int32_t *out_int, double *out_dbl);
+
 /* summary counters, struct _summary main.cpp:32-36,73-79 */
 int rc_summary(const rc_ctx *ctx, uint64_t *total_reads, uint64_t *total_corrections);
 

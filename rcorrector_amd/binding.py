@@ -15,7 +15,7 @@ ABI_SYMBOLS = [
     "rc_table_count_reads_device", "rc_table_lookup", "rc_table_export", "rc_table_stats",
     "rc_estimate_error_rate", "rc_bad_quality_from_hist", "rc_set_run_params",
     "rc_correct_batch", "rc_correct_device", "rc_probe_device", "rc_sync",
-    "rc_profile_enable", "rc_profile_get", "rc_profile_reset", "rc_summary",
+    "rc_profile_enable", "rc_profile_get", "rc_profile_reset", "rc_selftest_get_bound", "rc_summary",
 ]
 
 
@@ -101,6 +101,7 @@ def load_library():
     L.rc_profile_enable.argtypes = [vp, C.c_int]
     L.rc_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.rc_profile_reset.argtypes = [vp]
+    L.rc_selftest_get_bound.argtypes = [vp, vp, sz, C.c_double, vp, vp]
     L.rc_summary.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     _lib = L
     return L
@@ -257,6 +258,14 @@ class Context:
         ms, n = C.c_double(0), C.c_uint64(0)
         self._ck(self._L.rc_profile_get(self._h, kernel, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def selftest_get_bound(self, c, error_rate):
+        """GetBound(c) as the kernels evaluate it: (int32 array, float64 array)."""
+        c = np.ascontiguousarray(c, dtype=np.int32)
+        oi = np.zeros(len(c), dtype=np.int32)
+        od = np.zeros(len(c), dtype=np.float64)
+        self._ck(self._L.rc_selftest_get_bound(self._h, c.ctypes.data, len(c), error_rate, oi.ctypes.data, od.ctypes.data))
+        return oi, od
 
     def summary(self):
         a, b = C.c_uint64(0), C.c_uint64(0)

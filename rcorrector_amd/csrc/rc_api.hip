@@ -588,6 +588,24 @@ int rc_profile_reset(rc_ctx *ctx)
     return RC_OK;
 }
 
+int rc_selftest_get_bound(rc_ctx *ctx, const int32_t *c, size_t n, double error_rate, int32_t *out_int, double *out_dbl)
+{
+    if (!ctx || (n && (!c || !out_int || !out_dbl))) return RC_ERR_ARG;
+    if (n == 0) return RC_OK;
+    RC_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    rc_dev_tmp b_c, b_i, b_d;
+    RC_CHECK_HIP(ctx, b_c.alloc(n * 4));
+    RC_CHECK_HIP(ctx, b_i.alloc(n * 4));
+    RC_CHECK_HIP(ctx, b_d.alloc(n * 8));
+    RC_CHECK_HIP(ctx, hipMemcpyAsync(b_c.p, c, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    int rc = rc_launch_selftest_bound(ctx, b_c.as<int32_t>(), n, error_rate, b_i.as<int32_t>(), b_d.as<double>());
+    if (rc) return rc;
+    RC_CHECK_HIP(ctx, hipMemcpyAsync(out_int, b_i.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    RC_CHECK_HIP(ctx, hipMemcpyAsync(out_dbl, b_d.p, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RC_OK;
+}
+
 int rc_summary(const rc_ctx *c, uint64_t *total_reads, uint64_t *total_corrections)
 {
     if (!c) return RC_ERR_ARG;

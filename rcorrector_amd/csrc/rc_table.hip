@@ -213,6 +213,22 @@ int rc_launch_export(rc_ctx *ctx, uint64_t *d_codes, int32_t *d_counts, unsigned
     return RC_OK;
 }
 
+__global__ void k_selftest_bound(const int32_t *__restrict__ c, size_t n, double e, int32_t *__restrict__ oi, double *__restrict__ od)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    oi[i] = rc_bound_i(c[i], e);
+    od[i] = rc_bound_d(c[i], e);
+}
+
+int rc_launch_selftest_bound(rc_ctx *ctx, const int32_t *d_c, size_t n, double e, int32_t *d_oi, double *d_od)
+{
+    if (n == 0) return RC_OK;
+    hipLaunchKernelGGL(k_selftest_bound, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_c, n, e, d_oi, d_od);
+    RC_CHECK_HIP(ctx, hipGetLastError());
+    return RC_OK;
+}
+
 // ---- K1: probe kernel ----------------------------------------------------------------------
 // counts[a] = GetCount(k-mer starting at arena byte a) for every a whose k-window lies inside one
 // read (reads are NUL-terminated inside the arena, so "inside one read" == "no NUL in the

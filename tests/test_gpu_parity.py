@@ -222,3 +222,33 @@ def test_full_scale_properties(gpu_ctx_factory):
     rows_a = a.view(n, L + 1)[clean]
     rows_c = c.view(n, L + 1)[clean]
     assert torch.equal(rows_a, rows_c)
+
+
+@pytest.mark.parametrize("rate", [0.01, 0.004046, 0.001362, 0.007897, 0.010297, 0.25, 1.0, 1e-9])
+def test_get_bound_device_equals_x86(gpu_ctx_factory, oracle, rate):
+    """GetBound (ErrorCorrection.cpp:139-142) is the only floating-point arithmetic on the path.  The
+    device evaluates it in IEEE double with explicitly rounded mul / sqrt / add; it must give the
+    bits the reference's x86-64 SSE2 code gives: the doubles themselves and the cvttsd2si
+    conversions (INT_MIN for NaN and for out-of-range values)."""
+    import ctypes as C
+    rng = np.random.Generator(np.random.PCG64(int(rate * 1e9) % 2**31))
+    c = np.concatenate([np.arange(-3, 300000, dtype=np.int64),
+                        rng.integers(0, 2**31 - 1, size=300000),
+                        np.array([2**31 - 1, 2**31 - 2, 2**30, 1000000000, -1, -2147483648])]).astype(np.int32)
+    ctx = gpu_ctx_factory(23)
+    gi, gd = ctx.selftest_get_bound(c, rate)
+    P = oracle.make_params(23, 4, rate, b"H")
+    L = oracle.lib()
+    wi = np.array([L.rco_get_bound_int(C.byref(P), int(x)) for x in c[:5000].tolist() + c[-20006::400].tolist()], dtype=np.int32)
+    sel = np.concatenate([np.arange(5000), np.arange(len(c))[-20006::400]])
+    assert np.array_equal(gi[sel], wi)
+    # the doubles: numpy float64 ops are the same IEEE operations (mul, sqrt, add; no FMA)
+    cf = c.astype(np.float64)
+    with np.errstate(invalid="ignore"):
+        ce = cf * rate
+        want_d = (ce + 6.0 * np.sqrt(ce)) + 1.0
+    ok = c >= 0
+    assert np.array_equal(gd[ok].view(np.uint64), want_d[ok].view(np.uint64))
+    assert np.isnan(gd[~ok]).all() and (gi[~ok] == -2147483648).all()
+    want_i = np.where(want_d[ok] < 2147483648.0, np.trunc(np.minimum(want_d[ok], 2147483647.0)), -2147483648.0).astype(np.int64)
+    assert np.array_equal(gi[ok].astype(np.int64), want_i)
