@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--err", type=float, default=0.005)
     ap.add_argument("--alpha", type=float, default=0.8)
     ap.add_argument("--seed", type=int, default=1001000)
+    ap.add_argument("--maxcork", type=int, default=4, help="-maxcorK (MAX_FIX_PER_K)")
     ap.add_argument("--paired", action="store_true", help="paired-end batch (mode 1): --reads counts both mates")
     ap.add_argument("--host-path", action="store_true",
                     help="also time the host-buffer entry point rc_correct_batch (PCIe inclusive; reported, never `value`)")
@@ -112,7 +113,7 @@ def main():
     mode = 1 if a.paired else 0
     if a.paired and n % 2:
         raise SystemExit('--paired needs an even --reads')
-    ctx = rcorrector_amd.Context(k=k, max_fix_per_k=4, device=local)
+    ctx = rcorrector_amd.Context(k=k, max_fix_per_k=a.maxcork, device=local)
 
     # the replicated table: every rank counts the k-mers of the rank-0 shard (same seed => same
     # table everywhere, no communication), then generates its own shard of reads
@@ -199,7 +200,7 @@ def main():
 
         cpu = None
         if a.cpu_sample > 0 and not a.paired:
-            cpu = cpu_baseline(ctx, seq0, qual0, n, L, k, error_rate, bad_q, a.cpu_sample, ret, work)
+            cpu = cpu_baseline(ctx, seq0, qual0, n, L, k, error_rate, bad_q, a.cpu_sample, ret, work, a.maxcork)
 
         out = {
             "metric": "corrected reads/sec (%d bp, k=%d)" % (L, k),
@@ -228,7 +229,7 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(ctx, seq0, qual0, n, L, k, error_rate, bad_q, sample, ret_gpu, work_gpu):
+def cpu_baseline(ctx, seq0, qual0, n, L, k, error_rate, bad_q, sample, ret_gpu, work_gpu, maxcork=4):
     """The CPU oracle on the first `sample` reads with the same table, all host cores; also checks
     the GPU results of those reads against it (the oracle is the checker here, never the product)."""
     from oracle import pyoracle as po
@@ -237,7 +238,7 @@ def cpu_baseline(ctx, seq0, qual0, n, L, k, error_rate, bad_q, sample, ret_gpu, 
     codes, counts = ctx.table_export()
     T = po.Table(k, len(codes))
     T.put_many(codes, counts)
-    P = po.make_params(k, 4, error_rate, bad_q)
+    P = po.make_params(k, maxcork, error_rate, bad_q)
     nb = sample * (L + 1)
     arena = seq0[:nb].cpu().numpy().copy()
     qa = qual0[:nb].cpu().numpy().copy()

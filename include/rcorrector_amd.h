@@ -63,6 +63,10 @@ int rc_table_load_jfdump(rc_ctx *ctx, const char *path, int64_t *stored);
  * NUL bytes), entries with count >= min_count kept. */
 int rc_table_count_reads_device(rc_ctx *ctx, const uint8_t *d_seq, size_t nbytes, int min_count,
                                 int64_t *n_kmers);
+/* dst uses src's table (same device; src must outlive dst and must not rebuild its table meanwhile).
+ * The reference shares one Store between all worker threads (main.cpp:451); this lets several
+ * contexts -- several batches in flight on one GPU -- do the same instead of replicating it. */
+int rc_table_share(rc_ctx *dst, const rc_ctx *src);
 /* Store::GetCount (Store.h:59-66) for n valid k-mer codes (host arrays) */
 int rc_table_lookup(rc_ctx *ctx, const uint64_t *codes, size_t n, int32_t *counts_out);
 /* every stored (canonical code, count) pair, unspecified order -- what `jellyfish dump` would

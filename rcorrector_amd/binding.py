@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 ABI_SYMBOLS = [
     "rc_create", "rc_destroy", "rc_last_error",
     "rc_table_build", "rc_table_build_device", "rc_table_load_jfdump",
-    "rc_table_count_reads_device", "rc_table_lookup", "rc_table_export", "rc_table_stats",
+    "rc_table_count_reads_device", "rc_table_share", "rc_table_lookup", "rc_table_export", "rc_table_stats",
     "rc_estimate_error_rate", "rc_bad_quality_from_hist", "rc_set_run_params",
     "rc_correct_batch", "rc_correct_device", "rc_probe_device", "rc_sync",
     "rc_profile_enable", "rc_profile_get", "rc_profile_reset", "rc_selftest_get_bound", "rc_summary",
@@ -87,6 +87,7 @@ def load_library():
     L.rc_table_build_device.argtypes = [vp, vp, vp, sz]
     L.rc_table_load_jfdump.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64)]
     L.rc_table_count_reads_device.argtypes = [vp, vp, sz, C.c_int, C.POINTER(C.c_int64)]
+    L.rc_table_share.argtypes = [vp, vp]
     L.rc_table_lookup.argtypes = [vp, vp, sz, vp]
     L.rc_table_export.argtypes = [vp, vp, vp, sz, C.POINTER(C.c_size_t)]
     L.rc_table_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
@@ -183,6 +184,11 @@ class Context:
         n = C.c_int64(0)
         self._ck(self._L.rc_table_count_reads_device(self._h, _ptr(d_seq), nbytes, min_count, C.byref(n)))
         return n.value
+
+    def share_table_of(self, other):
+        """Use `other`'s table (same device) instead of an own copy; keeps `other` alive."""
+        self._ck(self._L.rc_table_share(self._h, other._h))
+        self._table_owner = other
 
     def lookup(self, codes):
         codes = np.ascontiguousarray(codes, dtype=np.uint64)

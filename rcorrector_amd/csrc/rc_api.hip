@@ -125,7 +125,7 @@ void rc_destroy(rc_ctx *c)
                        &ctx->h_seq, &ctx->h_qual, &ctx->h_off, &ctx->h_res};
     for (rc_dbuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
-    if (ctx->d_buckets) (void)hipFree(ctx->d_buckets);
+    if (ctx->d_buckets && !ctx->buckets_borrowed) (void)hipFree(ctx->d_buckets);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -304,6 +304,30 @@ int rc_table_load_jfdump(rc_ctx *c, const char *path, int64_t *stored)
     D.valid = true;
     if (stored) *stored = accepted;
     return rc_table_build(ctx, put_codes.data(), put_counts.data(), put_codes.size());
+}
+
+int rc_table_share(rc_ctx *dst, const rc_ctx *src)
+{
+    if (!dst || !src || dst == src) return RC_ERR_ARG;
+    if (dst->device != src->device || dst->k != src->k) {
+        rc_set_error(dst, "table_share: contexts must be on the same device with the same k");
+        return RC_ERR_ARG;
+    }
+    if (!src->d_buckets) {
+        rc_set_error(dst, "table_share: the source context has no table");
+        return RC_ERR_STATE;
+    }
+    if (dst->d_buckets && !dst->buckets_borrowed) {
+        RC_CHECK_HIP(dst, hipSetDevice(dst->device));
+        (void)hipFree(dst->d_buckets);
+    }
+    dst->d_buckets = src->d_buckets;
+    dst->buckets_borrowed = true;
+    dst->nb_home = src->nb_home;
+    dst->nb_alloc = src->nb_alloc;
+    dst->n_entries = src->n_entries;
+    dst->table_bytes = src->table_bytes;
+    return RC_OK;
 }
 
 int rc_table_count_reads_device(rc_ctx *ctx, const uint8_t *d_seq, size_t nbytes, int min_count, int64_t *n_kmers)

@@ -67,6 +67,7 @@ struct rc_ctx {
 
     // k-mer table in HBM
     uint32_t *d_buckets = nullptr;
+    bool buckets_borrowed = false;  // rc_table_share: another context owns d_buckets
     uint32_t nb_home = 0;
     double table_load = 0.50;  // target slot load factor of the next build
     uint32_t nb_alloc = 0;

@@ -13,7 +13,9 @@
 // per GPU runs rc_correct_batch, one writer thread formats in parallel and writes in input order.
 //
 // Extra flags (not in the reference): -gpus N shards batches over N GPUs (table replicated),
-// -batch N sets the reads per batch.  -t sets the host threads used for packing / formatting.
+// -batch N sets the reads per batch, -inflight N the batches in flight per GPU (contexts sharing one
+// table; keeps the GPU busy while a batch's slowest reads finish).  -t sets the host threads used
+// for packing / formatting.
 // -verbose (per-read trace on stdout) is not provided by the GPU path and is refused loudly.
 #include <fcntl.h>
 #include <stdarg.h>
@@ -386,12 +388,13 @@ static void print_help()
             "\t-verbose: output some correction information to stdout (default: not used)\n"
             "MI355X build only:\n"
             "\t-gpus INT: number of GPUs to shard the reads over, k-mer table replicated (default: 1)\n"
-            "\t-batch INT: reads per GPU batch (default: 1048576)\n");
+            "\t-batch INT: reads per GPU batch (default: 1048576)\n"
+            "\t-inflight INT: batches in flight per GPU (default: 2)\n");
 }
 
 int main(int argc, char **argv)
 {
-    int k = 23, max_fix_per_k = 4, gpus = 1, i;
+    int k = 23, max_fix_per_k = 4, gpus = 1, inflight = 2, i;
     double wk = 0.95;
     const char *dump = nullptr;
     std::string od = "./";
@@ -433,6 +436,8 @@ int main(int argc, char **argv)
             gpus = atoi(argv[++i]);
         else if (!strcmp("-batch", argv[i]))
             batch_reads = (size_t)atol(argv[++i]);
+        else if (!strcmp("-inflight", argv[i]))
+            inflight = atoi(argv[++i]);
         else if (!strcmp("-h", argv[i])) {
             print_help();
             return 0;
@@ -444,6 +449,8 @@ int main(int argc, char **argv)
     if (verbose) die("-verbose (per-read trace) is not available on the GPU path; use the CPU reference for traces\n");
     if (!dump) die("Could not open file %s\n", "(no -c given)");
     if (gpus < 1) gpus = 1;
+    if (inflight < 1) inflight = 1;
+    if (inflight > 8) inflight = 8;
     if (batch_reads < 2) batch_reads = 2;
     batch_reads &= ~(size_t)1;
     {
@@ -475,18 +482,21 @@ int main(int argc, char **argv)
         }
     }
 
-    // contexts: one per GPU, table replicated
-    std::vector<rc_ctx *> ctx((size_t)gpus, nullptr);
+    // contexts: `inflight` per GPU; the table is replicated across GPUs and shared within one
+    const int nctx = gpus * inflight;
+    std::vector<rc_ctx *> ctx((size_t)nctx, nullptr);
     char err[512];
-    for (int g = 0; g < gpus; ++g) {
-        rc_config cfg = {g, k, max_fix_per_k};
-        ctx[g] = rc_create(&cfg, err, sizeof err);
-        if (!ctx[g]) die("rcorrector: %s\n", err);
+    for (int c = 0; c < nctx; ++c) {
+        rc_config cfg = {c % gpus, k, max_fix_per_k};
+        ctx[c] = rc_create(&cfg, err, sizeof err);
+        if (!ctx[c]) die("rcorrector: %s\n", err);
     }
     const double t_start = now_s();
     int64_t stored = 0;
     for (int g = 0; g < gpus; ++g)
         if (rc_table_load_jfdump(ctx[g], dump, &stored)) die("rcorrector: %s\n", rc_last_error(ctx[g]));
+    for (int c = gpus; c < nctx; ++c)
+        if (rc_table_share(ctx[c], ctx[c % gpus])) die("rcorrector: %s\n", rc_last_error(ctx[c]));
     fprintf(stderr, "Stored %d kmers\n", (int)stored);
     double rate = 0.01;
     if (rc_estimate_error_rate(ctx[0], wk, &rate)) die("rcorrector: %s\n", rc_last_error(ctx[0]));
@@ -523,19 +533,19 @@ int main(int argc, char **argv)
         bad_q = rc_bad_quality_from_hist(fh.data(), lh.data(), total);
     }
     fprintf(stderr, "Bad quality threshold is '%c'\n", bad_q);
-    for (int g = 0; g < gpus; ++g) rc_set_run_params(ctx[g], rate, bad_q);
+    for (int c = 0; c < nctx; ++c) rc_set_run_params(ctx[c], rate, bad_q);
     const double t_setup = now_s();
 
     // pipeline: reader (this thread) -> one worker per GPU -> writer thread (input order)
     std::mutex mu;
     std::condition_variable cv;
     std::deque<std::shared_ptr<Job>> order;  // submission order, for the writer
-    std::vector<std::deque<std::shared_ptr<Job>>> q((size_t)gpus);
+    std::vector<std::deque<std::shared_ptr<Job>>> q((size_t)nctx);
     bool closing = false, reader_done = false;
-    const size_t max_in_flight = (size_t)(2 * gpus + 2);
+    const size_t max_in_flight = (size_t)(nctx + 2);
 
     std::vector<std::thread> workers;
-    for (int g = 0; g < gpus; ++g) {
+    for (int g = 0; g < nctx; ++g) {
         workers.emplace_back([&, g]() {
             for (;;) {
                 std::shared_ptr<Job> j;
@@ -660,7 +670,7 @@ int main(int argc, char **argv)
                     std::unique_lock<std::mutex> lk(mu);
                     cv.wait(lk, [&] { return order.size() < max_in_flight; });
                     order.push_back(j);
-                    q[seqno % (size_t)gpus].push_back(j);
+                    q[seqno % (size_t)nctx].push_back(j);
                 }
                 ++seqno;
                 cv.notify_all();
@@ -687,7 +697,7 @@ int main(int argc, char **argv)
             f->src.close();
         }
     }
-    for (int g = 0; g < gpus; ++g) rc_destroy(ctx[g]);
+    for (int c = nctx - 1; c >= 0; --c) rc_destroy(ctx[c]);  // borrowers first, owners last
     if (g_timing)
         fprintf(stderr, "[rc timing] start-up (dump load, table build, ERROR_RATE, bad quality) %.2f s; correction loop (read, correct, write) %.2f s; %d host threads\n",
                 t_setup - t_start, now_s() - t_setup, g_threads);

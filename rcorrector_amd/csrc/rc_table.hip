@@ -64,10 +64,9 @@ int rc_build_table_from_device_pairs(rc_ctx *ctx, const uint64_t *d_canon, const
         rc_set_error(ctx, "table build: %zu entries exceed the 2^31 limit", n);
         return RC_ERR_ARG;
     }
-    if (ctx->d_buckets) {
-        (void)hipFree(ctx->d_buckets);
-        ctx->d_buckets = nullptr;
-    }
+    if (ctx->d_buckets && !ctx->buckets_borrowed) (void)hipFree(ctx->d_buckets);
+    ctx->d_buckets = nullptr;
+    ctx->buckets_borrowed = false;
     // home buckets: n / (slots * load).  Random 64-byte gathers on MI355X are request-rate bound
     // (~55 G/s, tools/microbench_gather.hip) and fall off a cliff once the table outgrows the TLB
     // reach (~2 GiB), so a dense table wins: fewer bytes => more MALL/L2 hits per probe.

@@ -24,13 +24,14 @@ def main():
     ap.add_argument("--len", type=int, default=100)
     ap.add_argument("-k", type=int, default=23)
     ap.add_argument("--n-tx", type=int, default=2000)
+    ap.add_argument("--err", type=float, default=0.005)
     ap.add_argument("--dir", default="/tmp/rc_e2e")
     ap.add_argument("--cli-args", default="")
     a = ap.parse_args()
     os.makedirs(a.dir, exist_ok=True)
     dev = torch.device("cuda", 0)
     n, L, k = a.reads, a.len, a.k
-    seq, qual = bench.synth_reads_gpu(77000, n, L, a.n_tx, 1500, 0.8, 0.005, dev)
+    seq, qual = bench.synth_reads_gpu(77000, n, L, a.n_tx, 1500, 0.8, a.err, dev)
     ctx = rcorrector_amd.Context(k=k)
     nk = ctx.count_reads_device(seq, seq.numel(), 2)
     codes, counts = ctx.table_export()
@@ -68,12 +69,13 @@ def main():
     del ctx
     cli = os.path.join(ROOT, "rcorrector_amd", "rcorrector")
     env = dict(os.environ, RC_TIMING="1")
-    t0 = time.time()
-    p = subprocess.run([cli, "-r", "x.fq", "-k", str(k), "-c", "x.jf", "-od", a.dir + "/out"] + a.cli_args.split(),
-                       cwd=a.dir, env=env, stderr=subprocess.PIPE)
-    dt = time.time() - t0
-    sys.stderr.write(p.stderr.decode())
-    print("CLI wall %.2f s -> %.2f M reads/s end to end" % (dt, n / dt / 1e6))
+    for variant in a.cli_args.split(";"):
+        t0 = time.time()
+        p = subprocess.run([cli, "-r", "x.fq", "-k", str(k), "-c", "x.jf", "-od", a.dir + "/out"] + variant.split(),
+                           cwd=a.dir, env=env, stderr=subprocess.PIPE)
+        dt = time.time() - t0
+        sys.stderr.write(p.stderr.decode())
+        print("CLI [%s] wall %.2f s -> %.2f M reads/s end to end" % (variant, dt, n / dt / 1e6))
 
 
 if __name__ == "__main__":
