@@ -307,7 +307,7 @@ __global__ __launch_bounds__(RC_PROBE_THREADS) void k_probe(rc_table_view T, con
             const uint64_t code = x >> (64 - 2 * k);
             cnt = rc_table_lookup(T, rc_canonical(code, k));
         }
-        counts[g] = cnt;
+        __builtin_nontemporal_store(cnt, &counts[g]);  // streamed once: keep it out of the caches the table lives in
     }
 }
 
