@@ -176,7 +176,7 @@ struct ReadFile {
     bool paired = false, interleaved = false, fastq = true, out_gz = false;
     Source src;
     FILE *out = nullptr;
-    gzFile outz = nullptr;
+    bool wrote = false;
 };
 
 // Reads.h:39-75
@@ -226,9 +226,11 @@ static void open_file(ReadFile &f, const char *path, bool paired, bool interleav
         f.out = stdout;
         f.out_gz = false;
     } else if (f.out_gz) {
-        f.outz = gzopen(outp.c_str(), "w1");  // compressLevel 1, Reads.h:84, File.h:62-66
-        if (!f.outz) die("ERROR: Could not access file %s\n", outp.c_str());
-        gzbuffer(f.outz, 1 << 20);
+        // compressLevel 1 (Reads.h:84, File.h:62-66).  The formatted slices of a batch are deflated
+        // in parallel, each into its own gzip member; a .gz file is a concatenation of members, so
+        // gunzip / gzopen read back exactly the bytes the reference's single-stream file holds.
+        f.out = fopen(outp.c_str(), "wb");
+        if (!f.out) die("ERROR: Could not access file %s\n", outp.c_str());
     } else {
         f.out = fopen(outp.c_str(), "w");
         if (!f.out) die("ERROR: Could not access file %s\n", outp.c_str());
@@ -237,15 +239,26 @@ static void open_file(ReadFile &f, const char *path, bool paired, bool interleav
 
 static void emit(ReadFile &f, const char *s, size_t n)
 {
-    if (n == 0) return;
-    if (f.out_gz) {
-        for (size_t o = 0; o < n;) {
-            unsigned c = (unsigned)std::min<size_t>(n - o, (size_t)1 << 30);
-            gzwrite(f.outz, s + o, c);
-            o += c;
-        }
-    } else
+    if (n) {
         fwrite(s, 1, n, f.out);
+        f.wrote = true;
+    }
+}
+
+// one gzip member (RFC 1952) holding `in`, deflate level 1
+static void gzip_member(const std::vector<char> &in, std::vector<char> &out)
+{
+    z_stream z;
+    memset(&z, 0, sizeof z);
+    if (deflateInit2(&z, 1, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) die("ERROR: zlib deflateInit2 failed\n");
+    out.resize(deflateBound(&z, (uLong)in.size()) + 64);
+    z.next_in = (Bytef *)in.data();
+    z.avail_in = (uInt)in.size();
+    z.next_out = (Bytef *)out.data();
+    z.avail_out = (uInt)out.size();
+    if (deflate(&z, Z_FINISH) != Z_STREAM_END) die("ERROR: zlib deflate failed\n");
+    out.resize(z.total_out);
+    deflateEnd(&z);
 }
 
 // ---- one batch travelling through the pipeline -------------------------------------------------
@@ -629,6 +642,18 @@ int main(int argc, char **argv)
                 for (size_t s = 0; s < S; ++s) th.emplace_back([&, s]() { fmt(s, s + 1); });
                 for (auto &x : th) x.join();
             }
+            if (f.out_gz && !g_stdout) {  // deflate every slice into its own gzip member, in parallel
+                std::vector<std::vector<char>> z1(S), z2(S);
+                std::vector<std::thread> th;
+                for (size_t s = 0; s < S; ++s)
+                    th.emplace_back([&, s]() {
+                        if (!o1[s].empty()) gzip_member(o1[s], z1[s]);
+                        if (!o2[s].empty()) gzip_member(o2[s], z2[s]);
+                    });
+                for (auto &x : th) x.join();
+                o1.swap(z1);
+                o2.swap(z2);
+            }
             for (size_t s = 0; s < S; ++s) emit(f, o1[s].data(), o1[s].size());
             if (j->mode == 1 && !alternate)
                 for (size_t s = 0; s < S; ++s) emit(g2, o2[s].data(), o2[s].size());
@@ -692,7 +717,11 @@ int main(int argc, char **argv)
 
     for (size_t fi = 0; fi < files.size(); ++fi) {
         for (ReadFile *f : {&files[fi], &mates[fi]}) {
-            if (f->outz) gzclose(f->outz);
+            if (f->out && f->out_gz && !f->wrote) {  // an empty .gz is still one (empty) gzip member
+                std::vector<char> none, z;
+                gzip_member(none, z);
+                fwrite(z.data(), 1, z.size(), f->out);
+            }
             if (f->out && f->out != stdout) fclose(f->out);
             f->src.close();
         }

@@ -58,3 +58,22 @@ def test_cli_multiple_files_in_one_run(tmp_path):
     want = open(os.path.join(a, "ref", "reads.cor.fq"), "rb").read()
     assert open(tmp_path / "reads.cor.fq", "rb").read() == want  # second -r truncates and rewrites the same name
     assert b"Processed 800 reads" in p.stderr
+
+
+def test_cli_gz_paired_multi_member_output(tmp_path):
+    """.gz in -> .gz out for a pair (Reads.h:140-147 naming); the output is written as parallel gzip
+    members, which must decompress to exactly the reference's records."""
+    src = os.path.join(gu.GOLDEN, "fx_pe_k23")
+    work = tmp_path / "in"
+    work.mkdir()
+    for n in ("reads_1.fq", "reads_2.fq"):
+        with open(os.path.join(src, n), "rb") as f, gzip.open(work / (n + ".gz"), "wb") as g:
+            shutil.copyfileobj(f, g)
+    out = tmp_path / "out"
+    gu.run_fixture(CLI, "fx_pe_k23", out, args_override=["-p", str(work / "reads_1.fq.gz"), str(work / "reads_2.fq.gz"),
+                                                          "-k", "23", "-c", os.path.join(src, "dump.jf"), "-batch", "100"])
+    for n in ("reads_1", "reads_2"):
+        got = gzip.open(out / (n + ".cor.fq.gz"), "rb").read()
+        assert got == open(os.path.join(src, "ref", n + ".cor.fq"), "rb").read()
+    import subprocess
+    assert subprocess.run(["gzip", "-t", str(out / "reads_1.cor.fq.gz")]).returncode == 0
