@@ -14,6 +14,10 @@ CONFIGS = {
     "varlen": dict(k=23, mfk=4, rate=0.01, mode=0, kw=dict(seed=108, n=3000, length=100, e=0.02, var_len=True)),
     "k15": dict(k=15, mfk=4, rate=0.01, mode=0, kw=dict(seed=109, n=2000, length=75, e=0.01, n_tx=50)),
     "k32": dict(k=32, mfk=4, rate=0.01, mode=0, kw=dict(seed=110, n=2000, length=150, e=0.01)),
+    "long300": dict(k=23, mfk=4, rate=0.01, mode=0, kw=dict(seed=112, n=400, length=300, e=0.01, n_tx=20, l_tx=1500)),
+    "long600_k31": dict(k=31, mfk=4, rate=0.01, mode=1, kw=dict(seed=113, n=150, length=600, e=0.01, n_tx=10, l_tx=1500, paired=True)),
+    "max1023": dict(k=23, mfk=4, rate=0.01, mode=0, kw=dict(seed=114, n=80, length=1023, e=0.008, n_tx=4, l_tx=1500, var_len=True)),
+    "k11": dict(k=11, mfk=4, rate=0.01, mode=0, kw=dict(seed=115, n=1500, length=60, e=0.01, n_tx=6, l_tx=300)),
     "pe_var": dict(k=23, mfk=4, rate=0.02, mode=1, kw=dict(seed=111, n=1500, length=120, e=0.03, paired=True, var_len=True, p_n=0.005)),
 }
 

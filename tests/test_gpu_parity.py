@@ -65,7 +65,7 @@ def test_table_empty_and_tiny(gpu_ctx_factory):
     assert ctx.lookup(np.array([0, 1], dtype=np.uint64)).tolist() == [7, 0]
 
 
-@pytest.mark.parametrize("name", ["se_k23", "k31_mc8", "nrich", "varlen", "k15", "k32", "edge"])
+@pytest.mark.parametrize("name", ["se_k23", "k31_mc8", "nrich", "varlen", "k15", "k32", "edge", "max1023", "k11"])
 def test_probe_kernel_counts(gpu_ctx_factory, oracle, name):
     import torch
     d = datasets.make(name)
@@ -87,7 +87,8 @@ def test_probe_kernel_counts(gpu_ctx_factory, oracle, name):
         assert (got[o + len(want):int(off[i + 1])] == -7).all()
 
 
-@pytest.mark.parametrize("name", ["se_k23", "pe_k23", "il_k23", "k31_mc8", "skew", "nrich", "varlen", "k15", "k32", "pe_var", "edge"])
+@pytest.mark.parametrize("name", ["se_k23", "pe_k23", "il_k23", "k31_mc8", "skew", "nrich", "varlen", "k15", "k32", "pe_var", "edge",
+                                  "long300", "long600_k31", "max1023", "k11"])
 def test_correct_batch_matches_oracle(gpu_ctx_factory, oracle, name):
     d = datasets.make(name)
     want = datasets.run_oracle(oracle, d)

@@ -39,6 +39,8 @@ def make_reads(seed, n, length, n_tx=200, l_tx=1500, alpha=0.8, e=0.01, p_n=0.0,
     w = (np.arange(n_tx) + 1.0) ** (-alpha)
     w /= w.sum()
     tid = rng.choice(n_tx, size=n, p=w)
+    if paired and frag_len < length:
+        frag_len = min(l_tx, 2 * length)
     span = frag_len if paired else length
     if span > l_tx:
         raise ValueError("transcripts shorter than fragment")
