@@ -58,11 +58,23 @@ int rc_table_build_device(rc_ctx *ctx, uint64_t *d_codes, const int32_t *d_count
 /* replaces main.cpp:294-308 including the parse: reads a `jellyfish dump` text file
  * (">COUNT\nKMER\n"), drops count <= 1, builds the table.  *stored = the "Stored %d kmers" value. */
 int rc_table_load_jfdump(rc_ctx *ctx, const char *path, int64_t *stored);
-/* replaces stages 0-2 (run_rcorrector.pl:262-281: jellyfish bc / count / dump -L 2) when the reads
- * are already in HBM: exact canonical k-mer counts of every read in the arena (reads separated by
- * NUL bytes), entries with count >= min_count kept. */
+/* replace stages 0-2 (run_rcorrector.pl:262-281: jellyfish bc / count -C / dump -L 2): exact
+ * canonical k-mer counts over any number of arenas of reads (reads separated by NUL bytes, each
+ * arena < 2^32 bytes; k-mers holding a letter outside ACGT are skipped), then the table from the
+ * entries with count >= min_count.  count_add takes a host arena, count_add_device one already in
+ * HBM.  *n_kmers = entries kept (the "Stored %d kmers" value). */
+int rc_table_count_begin(rc_ctx *ctx);
+int rc_table_count_add(rc_ctx *ctx, const char *seq, size_t nbytes);
+int rc_table_count_add_device(rc_ctx *ctx, const uint8_t *d_seq, size_t nbytes);
+int rc_table_count_finish(rc_ctx *ctx, int min_count, int64_t *n_kmers);
+/* begin + add_device + finish for one arena */
 int rc_table_count_reads_device(rc_ctx *ctx, const uint8_t *d_seq, size_t nbytes, int min_count,
                                 int64_t *n_kmers);
+/* the table as the text `jellyfish dump` writes (">COUNT\nKMER\n", canonical k-mers) -- the file
+ * main.cpp:295-307 parses -- so a table counted here can be handed to the reference binary.
+ * Entries are written in "dump order" (ascending splitmix64 of the code: pseudo-random like
+ * Jellyfish's hash order, but reproducible). */
+int rc_table_write_jfdump(rc_ctx *ctx, const char *path, int64_t *n_written);
 /* dst uses src's table (same device; src must outlive dst and must not rebuild its table meanwhile).
  * The reference shares one Store between all worker threads (main.cpp:451); this lets several
  * contexts -- several batches in flight on one GPU -- do the same instead of replicating it. */
@@ -77,8 +89,10 @@ int rc_table_stats(const rc_ctx *ctx, uint64_t *bytes, uint64_t *buckets, uint64
 
 /* ---- run parameters (globals of main.cpp:17-30) ----------------------------------------------- */
 /* replaces main.cpp:310-358 (ERROR_RATE estimation).  Uses the entries parsed by the last
- * rc_table_load_jfdump() in file order; the probes run on the GPU, the <=100000 divisions and
- * the sort on the host in IEEE double exactly as the reference does. */
+ * rc_table_load_jfdump() in file order -- or, for a table that was counted here or built from
+ * arrays, the table's entries in dump order (what the reference would scan if given
+ * rc_table_write_jfdump's file); the probes run on the GPU, the <=100000 divisions and the sort
+ * on the host in IEEE double exactly as the reference does. */
 int rc_estimate_error_rate(rc_ctx *ctx, double wk, double *rate_out);
 /* replaces GetBadQuality's arithmetic (main.cpp:108-127) given the two histograms gathered over
  * the first <= 1,000,000 records (first_hist[q] = #reads whose first quality char is q,

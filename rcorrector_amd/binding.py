@@ -12,7 +12,8 @@ CSRC = os.path.join(HERE, "csrc")
 ABI_SYMBOLS = [
     "rc_create", "rc_destroy", "rc_last_error",
     "rc_table_build", "rc_table_build_device", "rc_table_load_jfdump",
-    "rc_table_count_reads_device", "rc_table_share", "rc_table_lookup", "rc_table_export", "rc_table_stats",
+    "rc_table_count_begin", "rc_table_count_add", "rc_table_count_add_device", "rc_table_count_finish",
+    "rc_table_count_reads_device", "rc_table_write_jfdump", "rc_table_share", "rc_table_lookup", "rc_table_export", "rc_table_stats",
     "rc_estimate_error_rate", "rc_bad_quality_from_hist", "rc_set_run_params",
     "rc_correct_batch", "rc_correct_device", "rc_probe_device", "rc_sync",
     "rc_profile_enable", "rc_profile_get", "rc_profile_reset", "rc_selftest_get_bound", "rc_summary",
@@ -87,6 +88,11 @@ def load_library():
     L.rc_table_build_device.argtypes = [vp, vp, vp, sz]
     L.rc_table_load_jfdump.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64)]
     L.rc_table_count_reads_device.argtypes = [vp, vp, sz, C.c_int, C.POINTER(C.c_int64)]
+    L.rc_table_count_begin.argtypes = [vp]
+    L.rc_table_count_add.argtypes = [vp, vp, sz]
+    L.rc_table_count_add_device.argtypes = [vp, vp, sz]
+    L.rc_table_count_finish.argtypes = [vp, C.c_int, C.POINTER(C.c_int64)]
+    L.rc_table_write_jfdump.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64)]
     L.rc_table_share.argtypes = [vp, vp]
     L.rc_table_lookup.argtypes = [vp, vp, sz, vp]
     L.rc_table_export.argtypes = [vp, vp, vp, sz, C.POINTER(C.c_size_t)]
@@ -183,6 +189,27 @@ class Context:
     def count_reads_device(self, d_seq, nbytes, min_count=2):
         n = C.c_int64(0)
         self._ck(self._L.rc_table_count_reads_device(self._h, _ptr(d_seq), nbytes, min_count, C.byref(n)))
+        return n.value
+
+    def count_begin(self):
+        self._ck(self._L.rc_table_count_begin(self._h))
+
+    def count_add(self, arena):
+        """arena: bytes / uint8 array of NUL-separated reads in host memory"""
+        a = np.frombuffer(arena, dtype=np.uint8) if isinstance(arena, (bytes, bytearray)) else np.ascontiguousarray(arena, dtype=np.uint8)
+        self._ck(self._L.rc_table_count_add(self._h, a.ctypes.data, a.size))
+
+    def count_add_device(self, d_seq, nbytes):
+        self._ck(self._L.rc_table_count_add_device(self._h, _ptr(d_seq), nbytes))
+
+    def count_finish(self, min_count=2):
+        n = C.c_int64(0)
+        self._ck(self._L.rc_table_count_finish(self._h, min_count, C.byref(n)))
+        return n.value
+
+    def write_jfdump(self, path):
+        n = C.c_int64(0)
+        self._ck(self._L.rc_table_write_jfdump(self._h, os.fsencode(path), C.byref(n)))
         return n.value
 
     def share_table_of(self, other):

@@ -139,6 +139,7 @@ int rc_table_build_device(rc_ctx *ctx, uint64_t *d_codes, const int32_t *d_count
 {
     if (!ctx) return RC_ERR_ARG;
     RC_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    static_cast<rc_ctx_full *>(ctx)->dump.valid = false;
     int rc = rc_launch_canonicalize(ctx, d_codes, n);
     if (rc) return rc;
     return rc_build_table_from_device_pairs(ctx, d_codes, d_counts, n);
@@ -301,9 +302,10 @@ int rc_table_load_jfdump(rc_ctx *c, const char *path, int64_t *stored)
             P = piece();
         }
     }
-    D.valid = true;
     if (stored) *stored = accepted;
-    return rc_table_build(ctx, put_codes.data(), put_counts.data(), put_codes.size());
+    int rc = rc_table_build(ctx, put_codes.data(), put_counts.data(), put_codes.size());
+    D.valid = rc == RC_OK;  // (rc_table_build drops the cache of an earlier dump)
+    return rc;
 }
 
 int rc_table_share(rc_ctx *dst, const rc_ctx *src)
@@ -334,7 +336,107 @@ int rc_table_count_reads_device(rc_ctx *ctx, const uint8_t *d_seq, size_t nbytes
 {
     if (!ctx || !d_seq) return RC_ERR_ARG;
     RC_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    static_cast<rc_ctx_full *>(ctx)->dump.valid = false;
     return rc_count_reads(ctx, d_seq, nbytes, min_count, n_kmers);
+}
+
+int rc_table_count_begin(rc_ctx *ctx)
+{
+    if (!ctx) return RC_ERR_ARG;
+    RC_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    return rc_count_begin(ctx);
+}
+
+int rc_table_count_add_device(rc_ctx *ctx, const uint8_t *d_seq, size_t nbytes)
+{
+    if (!ctx || (nbytes && !d_seq)) return RC_ERR_ARG;
+    RC_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    return rc_count_add(ctx, d_seq, nbytes);
+}
+
+int rc_table_count_add(rc_ctx *ctx, const char *seq, size_t nbytes)
+{
+    if (!ctx || (nbytes && !seq)) return RC_ERR_ARG;
+    if (nbytes == 0) return RC_OK;
+    RC_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    rc_dev_tmp b;
+    RC_CHECK_HIP(ctx, b.alloc(nbytes));
+    RC_CHECK_HIP(ctx, hipMemcpyAsync(b.p, seq, nbytes, hipMemcpyHostToDevice, ctx->stream));
+    return rc_count_add(ctx, b.as<uint8_t>(), nbytes);
+}
+
+int rc_table_count_finish(rc_ctx *ctx, int min_count, int64_t *n_kmers)
+{
+    if (!ctx) return RC_ERR_ARG;
+    RC_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    static_cast<rc_ctx_full *>(ctx)->dump.valid = false;
+    return rc_count_finish(ctx, min_count, n_kmers);
+}
+
+// the table as `jellyfish dump` text (">COUNT\nKMER\n" per entry, canonical k-mer), in dump order
+int rc_table_write_jfdump(rc_ctx *ctx, const char *path, int64_t *n_written)
+{
+    if (!ctx || !path) return RC_ERR_ARG;
+    if (!ctx->d_buckets) {
+        rc_set_error(ctx, "write_jfdump: no k-mer table loaded");
+        return RC_ERR_STATE;
+    }
+    RC_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<uint64_t> codes;
+    std::vector<int32_t> counts;
+    int rc = rc_table_entries_in_dump_order(ctx, &codes, &counts);
+    if (rc) return rc;
+    FILE *fp = fopen(path, "wb");
+    if (!fp) {
+        rc_set_error(ctx, "could not open %s for writing", path);
+        return RC_ERR_IO;
+    }
+    const int k = ctx->k;
+    const size_t n = codes.size();
+    unsigned T = std::thread::hardware_concurrency();
+    if (T == 0) T = 4;
+    if (T > 32) T = 32;
+    const size_t CH = 1u << 20;  // entries formatted per round and thread
+    std::vector<std::vector<char>> out(T);
+    bool ok = true;
+    for (size_t base = 0; base < n && ok; base += CH * T) {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < T; ++t) {
+            const size_t lo = std::min(n, base + (size_t)t * CH), hi = std::min(n, lo + CH);
+            out[t].clear();
+            if (lo >= hi) continue;
+            th.emplace_back([&, t, lo, hi]() {
+                std::vector<char> &o = out[t];
+                o.resize((hi - lo) * (size_t)(k + 14));
+                char *w = o.data();
+                for (size_t i = lo; i < hi; ++i) {
+                    *w++ = '>';
+                    char tmp[12];
+                    int nd = 0;
+                    uint32_t v = (uint32_t)counts[i];
+                    do {
+                        tmp[nd++] = (char)('0' + v % 10);
+                        v /= 10;
+                    } while (v);
+                    while (nd) *w++ = tmp[--nd];
+                    *w++ = '\n';
+                    for (int j = k - 1; j >= 0; --j) *w++ = "ACGT"[(codes[i] >> (2 * j)) & 3];
+                    *w++ = '\n';
+                }
+                o.resize((size_t)(w - o.data()));
+            });
+        }
+        for (auto &x : th) x.join();
+        for (unsigned t = 0; t < T && ok; ++t)
+            if (!out[t].empty() && fwrite(out[t].data(), 1, out[t].size(), fp) != out[t].size()) ok = false;
+    }
+    if (fclose(fp) != 0) ok = false;
+    if (!ok) {
+        rc_set_error(ctx, "short write on %s", path);
+        return RC_ERR_IO;
+    }
+    if (n_written) *n_written = (int64_t)n;
+    return RC_OK;
 }
 
 int rc_table_lookup(rc_ctx *ctx, const uint64_t *codes, size_t n, int32_t *out)
@@ -405,11 +507,21 @@ int rc_estimate_error_rate(rc_ctx *c, double wk, double *rate_out)
 {
     if (!c || !rate_out) return RC_ERR_ARG;
     rc_ctx_full *ctx = static_cast<rc_ctx_full *>(c);
-    if (!ctx->dump.valid || !ctx->d_buckets) {
-        rc_set_error(ctx, "estimate_error_rate: call rc_table_load_jfdump first");
+    if (!ctx->d_buckets) {
+        rc_set_error(ctx, "estimate_error_rate: no k-mer table loaded");
         return RC_ERR_STATE;
     }
     RC_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->dump.valid) {
+        // no dump file was read (the table was counted here or handed over as arrays): scan the
+        // entries in the order rc_table_write_jfdump would write them -- what the reference would
+        // see if it were given that dump
+        int rc = rc_table_entries_in_dump_order(ctx, &ctx->dump.codes, nullptr);
+        if (rc) return rc;
+        ctx->dump.inv_mid.assign(ctx->dump.codes.size(), 0);
+        ctx->dump.load_state_invalid = 0;
+        ctx->dump.valid = true;
+    }
     const rc_dump_cache &D = ctx->dump;
     const size_t n = D.codes.size();
     std::vector<int32_t> mx2(2 * n);

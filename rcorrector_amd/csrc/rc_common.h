@@ -78,6 +78,20 @@ RC_HD uint64_t rc_canonical(uint64_t code, int k)
     return rc < code ? rc : code;
 }
 
+// "dump order" of a table this library counted or writes out: ascending rc_dump_order_key(code).
+// Jellyfish writes its dump in hash-table order, i.e. pseudo-random with respect to the k-mer
+// text, and the ERROR_RATE pass (main.cpp:310-358) samples the first 100000 qualifying entries of
+// that order; a bijective 64-bit mix (the splitmix64 finaliser) keeps that sample unbiased.
+RC_HD uint64_t rc_dump_order_key(uint64_t z)
+{
+    z ^= z >> 30;
+    z *= 0xbf58476d1ce4e5b9ull;
+    z ^= z >> 27;
+    z *= 0x94d049bb133111ebull;
+    z ^= z >> 31;
+    return z;
+}
+
 // 32-bit bucket hash of a canonical code (free choice: results do not depend on it)
 RC_HD uint32_t rc_hash(uint64_t key)
 {

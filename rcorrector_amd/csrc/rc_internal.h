@@ -4,6 +4,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <vector>
+
 #include "rc_correct_core.h"
 
 #define RC_CHECK_HIP(ctx, expr)                                                                  \
@@ -74,6 +76,12 @@ struct rc_ctx {
     size_t n_entries = 0;   // accepted entries (duplicates included)
     size_t table_bytes = 0;
 
+    // streaming k-mer counter (rc_table_count_begin/add/finish): sorted (code, count) accumulator
+    uint64_t *cnt_keys = nullptr;
+    uint32_t *cnt_vals = nullptr;
+    size_t cnt_n = 0;
+    bool cnt_active = false;
+
     // batch scratch
     rc_dbuf counts;   // int32 per arena byte
     rc_dbuf strong;   // int32 per read
@@ -97,9 +105,13 @@ int rc_build_table_from_device_pairs(rc_ctx *ctx, const uint64_t *d_canon, const
 int rc_launch_canonicalize(rc_ctx *ctx, uint64_t *d_codes, size_t n);
 int rc_launch_lookup(rc_ctx *ctx, const uint64_t *d_codes, size_t n, int32_t *d_out);
 int rc_launch_probe(rc_ctx *ctx, const uint8_t *d_seq, size_t nbytes, int32_t *d_counts);
+int rc_count_begin(rc_ctx *ctx);
+int rc_count_add(rc_ctx *ctx, const uint8_t *d_seq, size_t nbytes);
+int rc_count_finish(rc_ctx *ctx, int min_count, int64_t *n_kmers);
 int rc_count_reads(rc_ctx *ctx, const uint8_t *d_seq, size_t nbytes, int min_count, int64_t *n_kmers);
 int rc_launch_selftest_bound(rc_ctx *ctx, const int32_t *d_c, size_t n, double e, int32_t *d_oi, double *d_od);
 int rc_launch_export(rc_ctx *ctx, uint64_t *d_codes, int32_t *d_counts, unsigned long long *d_n, size_t cap);
+int rc_table_entries_in_dump_order(rc_ctx *ctx, std::vector<uint64_t> *codes, std::vector<int32_t> *counts);
 int rc_launch_last_base_variants(rc_ctx *ctx, const uint64_t *d_codes, size_t n, int32_t *d_max2);
 
 // rc_correct.hip

@@ -380,6 +380,68 @@ static inline void put_record(std::vector<char> &out, const Arena &A, size_t r, 
     out.resize((size_t)(p - out.data()));
 }
 
+// ---- k-mer counting pass (only without -c) ----------------------------------------------------
+// A reader thread cuts each input into blocks of whole records and packs the sequence lines into a
+// NUL-separated arena; this thread hands the arenas to the streaming counter.
+static void count_inputs(rc_ctx *ctx, const std::vector<std::pair<std::string, bool>> &inputs, int64_t *stored)
+{
+    const size_t BLOCK = (size_t)4 << 20;  // records per arena
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::vector<char>> q;
+    bool done = false;
+    std::thread reader([&]() {
+        for (const auto &in : inputs) {
+            Source s;
+            s.open(in.first);
+            const int lpr = in.second ? 4 : 2;
+            Block b;
+            for (;;) {
+                take_records(s, BLOCK, lpr, b);
+                if (b.records == 0) break;
+                std::vector<uint64_t> off(b.records + 1, 0);
+                for (size_t r = 0; r < b.records; ++r) {
+                    const size_t li = r * (size_t)lpr + 1;
+                    off[r + 1] = off[r] + (b.line[li + 1] - b.line[li]);  // bases + the NUL
+                }
+                std::vector<char> arena(off[b.records]);
+                parallel_for(b.records, [&](size_t lo, size_t hi) {
+                    for (size_t r = lo; r < hi; ++r) {
+                        const size_t li = r * (size_t)lpr + 1;
+                        const uint32_t sl = b.line[li + 1] - b.line[li] - 1;
+                        char *d = arena.data() + off[r];
+                        memcpy(d, b.text.data() + b.line[li], sl);
+                        d[sl] = 0;
+                    }
+                });
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return q.size() < 2; });
+                q.emplace_back(std::move(arena));
+                cv.notify_all();
+            }
+            s.close();
+        }
+        std::lock_guard<std::mutex> lk(mu);
+        done = true;
+        cv.notify_all();
+    });
+    if (rc_table_count_begin(ctx)) die("rcorrector: %s\n", rc_last_error(ctx));
+    for (;;) {
+        std::vector<char> arena;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return done || !q.empty(); });
+            if (q.empty()) break;
+            arena.swap(q.front());
+            q.pop_front();
+            cv.notify_all();
+        }
+        if (rc_table_count_add(ctx, arena.data(), arena.size())) die("rcorrector: %s\n", rc_last_error(ctx));
+    }
+    reader.join();
+    if (rc_table_count_finish(ctx, 2, stored)) die("rcorrector: %s\n", rc_last_error(ctx));
+}
+
 static void print_help()
 {
     fprintf(stderr,
@@ -389,7 +451,7 @@ static void print_help()
             "\t-r seq_file: seq_file is the path to the sequence file. Can use multiple -r to specifiy multiple sequence files\n"
             "\t-p seq_file_left seq_file_right: the paths to the paired-end data set. Can use multiple -p to specifiy multiple sequence files\n"
             "\t-i seq_file: seq_file is the path to the interleaved mate-pair sequence file. Can use multiple -i\n"
-            "\t-c jf_dump: the kmer counts dumped by JellyFish\n"
+            "\t-c jf_dump: the kmer counts dumped by JellyFish (without -c the k-mers of the input files are counted on the GPU)\n"
             "\t-k kmer_length\n"
             "Other parameters:\n"
             "\t-od output_file_directory (default: ./)\n"
@@ -402,14 +464,15 @@ static void print_help()
             "MI355X build only:\n"
             "\t-gpus INT: number of GPUs to shard the reads over, k-mer table replicated (default: 1)\n"
             "\t-batch INT: reads per GPU batch (default: 1048576)\n"
-            "\t-inflight INT: batches in flight per GPU (default: 2)\n");
+            "\t-inflight INT: batches in flight per GPU (default: 2)\n"
+            "\t-write-dump STRING: also write the k-mer table as a jellyfish-dump text file\n");
 }
 
 int main(int argc, char **argv)
 {
     int k = 23, max_fix_per_k = 4, gpus = 1, inflight = 2, i;
     double wk = 0.95;
-    const char *dump = nullptr;
+    const char *dump = nullptr, *write_dump = nullptr;
     std::string od = "./";
     size_t batch_reads = 1 << 20;
     bool verbose = false;
@@ -451,6 +514,8 @@ int main(int argc, char **argv)
             batch_reads = (size_t)atol(argv[++i]);
         else if (!strcmp("-inflight", argv[i]))
             inflight = atoi(argv[++i]);
+        else if (!strcmp("-write-dump", argv[i]))
+            write_dump = argv[++i];
         else if (!strcmp("-h", argv[i])) {
             print_help();
             return 0;
@@ -460,7 +525,6 @@ int main(int argc, char **argv)
         }
     }
     if (verbose) die("-verbose (per-read trace) is not available on the GPU path; use the CPU reference for traces\n");
-    if (!dump) die("Could not open file %s\n", "(no -c given)");
     if (gpus < 1) gpus = 1;
     if (inflight < 1) inflight = 1;
     if (inflight > 8) inflight = 8;
@@ -506,8 +570,28 @@ int main(int argc, char **argv)
     }
     const double t_start = now_s();
     int64_t stored = 0;
-    for (int g = 0; g < gpus; ++g)
-        if (rc_table_load_jfdump(ctx[g], dump, &stored)) die("rcorrector: %s\n", rc_last_error(ctx[g]));
+    if (dump) {
+        for (int g = 0; g < gpus; ++g)
+            if (rc_table_load_jfdump(ctx[g], dump, &stored)) die("rcorrector: %s\n", rc_last_error(ctx[g]));
+    } else {
+        // no -c: stages 0-2 of run_rcorrector.pl:262-281 on the GPU -- count the canonical k-mers of
+        // every input file (mates included), keep count >= 2, build the table
+        std::vector<std::pair<std::string, bool>> inputs;  // path, fastq
+        for (size_t fi = 0; fi < files.size(); ++fi) {
+            inputs.emplace_back(files[fi].path, files[fi].fastq);
+            if (files[fi].paired) inputs.emplace_back(mates[fi].path, mates[fi].fastq);
+        }
+        count_inputs(ctx[0], inputs, &stored);
+        if (gpus > 1) {  // replicate: one export, one build per further GPU
+            std::vector<uint64_t> codes((size_t)stored + 1);
+            std::vector<int32_t> counts((size_t)stored + 1);
+            size_t n = 0;
+            if (rc_table_export(ctx[0], codes.data(), counts.data(), codes.size(), &n)) die("rcorrector: %s\n", rc_last_error(ctx[0]));
+            for (int g = 1; g < gpus; ++g)
+                if (rc_table_build(ctx[g], codes.data(), counts.data(), n)) die("rcorrector: %s\n", rc_last_error(ctx[g]));
+        }
+    }
+    if (write_dump && rc_table_write_jfdump(ctx[0], write_dump, nullptr)) die("rcorrector: %s\n", rc_last_error(ctx[0]));
     for (int c = gpus; c < nctx; ++c)
         if (rc_table_share(ctx[c], ctx[c % gpus])) die("rcorrector: %s\n", rc_last_error(ctx[c]));
     fprintf(stderr, "Stored %d kmers\n", (int)stored);

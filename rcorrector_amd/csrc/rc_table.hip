@@ -17,6 +17,7 @@
 // p_j = max(5*home_j, p_{j-1}+1), and a scatter writes the buckets.  The layout is therefore a
 // pure function of the input, independent of thread timing.
 #include <cstring>
+#include <vector>
 
 #include <rocprim/rocprim.hpp>
 
@@ -212,6 +213,59 @@ int rc_launch_export(rc_ctx *ctx, uint64_t *d_codes, int32_t *d_counts, unsigned
     return RC_OK;
 }
 
+__global__ void k_dump_order_keys(const uint64_t *__restrict__ codes, size_t n, uint64_t *__restrict__ keys)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) keys[i] = rc_dump_order_key(codes[i]);
+}
+
+// every (canonical code, count) of the table in dump order (rc_common.h: rc_dump_order_key), to host
+int rc_table_entries_in_dump_order(rc_ctx *ctx, std::vector<uint64_t> *codes, std::vector<int32_t> *counts)
+{
+    const size_t cap = (size_t)ctx->n_entries;  // upper bound (duplicates were counted in)
+    codes->clear();
+    if (counts) counts->clear();
+    if (cap == 0) return RC_OK;
+    rc_dev_tmp b_codes, b_counts, b_n, b_keys, b_keys_s, b_codes_s, b_counts_s, b_tmp;
+    unsigned long long n64 = 0;
+    RC_CHECK_HIP(ctx, b_codes.alloc(cap * 8));
+    RC_CHECK_HIP(ctx, b_counts.alloc(cap * 4));
+    RC_CHECK_HIP(ctx, b_n.alloc(8));
+    RC_CHECK_HIP(ctx, hipMemsetAsync(b_n.p, 0, 8, ctx->stream));
+    int rc = rc_launch_export(ctx, b_codes.as<uint64_t>(), b_counts.as<int32_t>(), b_n.as<unsigned long long>(), cap);
+    if (rc) return rc;
+    RC_CHECK_HIP(ctx, hipMemcpyAsync(&n64, b_n.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (n64 > cap) {
+        rc_set_error(ctx, "table export: %llu entries found, at most %zu expected", n64, cap);
+        return RC_ERR_STATE;
+    }
+    const size_t n = (size_t)n64;
+    codes->resize(n);
+    if (counts) counts->resize(n);
+    if (n == 0) return RC_OK;
+    RC_CHECK_HIP(ctx, b_keys.alloc(n * 8));
+    RC_CHECK_HIP(ctx, b_keys_s.alloc(n * 8));
+    RC_CHECK_HIP(ctx, b_codes_s.alloc(n * 8));
+    hipLaunchKernelGGL(k_dump_order_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, b_codes.as<uint64_t>(), n, b_keys.as<uint64_t>());
+    RC_CHECK_HIP(ctx, hipGetLastError());
+    size_t t1 = 0, t2 = 0;
+    RC_CHECK_HIP(ctx, rocprim::radix_sort_pairs(nullptr, t1, b_keys.as<uint64_t>(), b_keys_s.as<uint64_t>(), b_codes.as<uint64_t>(), b_codes_s.as<uint64_t>(), n, 0, 64, ctx->stream));
+    RC_CHECK_HIP(ctx, b_tmp.alloc(t1));
+    RC_CHECK_HIP(ctx, rocprim::radix_sort_pairs(b_tmp.p, t1, b_keys.as<uint64_t>(), b_keys_s.as<uint64_t>(), b_codes.as<uint64_t>(), b_codes_s.as<uint64_t>(), n, 0, 64, ctx->stream));
+    RC_CHECK_HIP(ctx, hipMemcpyAsync(codes->data(), b_codes_s.p, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (counts) {
+        RC_CHECK_HIP(ctx, b_counts_s.alloc(n * 4));
+        RC_CHECK_HIP(ctx, rocprim::radix_sort_pairs(nullptr, t2, b_keys.as<uint64_t>(), b_keys_s.as<uint64_t>(), b_counts.as<int32_t>(), b_counts_s.as<int32_t>(), n, 0, 64, ctx->stream));
+        RC_CHECK_HIP(ctx, b_tmp.alloc(t2));
+        RC_CHECK_HIP(ctx, rocprim::radix_sort_pairs(b_tmp.p, t2, b_keys.as<uint64_t>(), b_keys_s.as<uint64_t>(), b_counts.as<int32_t>(), b_counts_s.as<int32_t>(), n, 0, 64, ctx->stream));
+        RC_CHECK_HIP(ctx, hipMemcpyAsync(counts->data(), b_counts_s.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return RC_OK;
+}
+
 __global__ void k_selftest_bound(const int32_t *__restrict__ c, size_t n, double e, int32_t *__restrict__ oi, double *__restrict__ od)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -379,28 +433,54 @@ __global__ void k_flag_keep(const uint64_t *__restrict__ uniq, const uint32_t *_
     if (i < n) keep[i] = (uniq[i] != ~0ull && cnt[i] >= (uint32_t)min_count) ? 1 : 0;
 }
 
-int rc_count_reads(rc_ctx *ctx, const uint8_t *d_seq, size_t nbytes, int min_count, int64_t *n_kmers)
+// ---- streaming exact k-mer counter (stages 0-2 of run_rcorrector.pl:262-281 for reads that are, or
+// pass through, HBM).  The accumulator is a sorted array of (canonical code, count); every added
+// arena is reduced to such an array (emit -> radix sort -> run-length encode) and merged into it
+// (concatenate -> sort pairs -> reduce by key).  finish keeps count >= min_count -- what
+// `jellyfish count -C` + `dump -L 2` hands to the reference -- and builds the table.
+__global__ void k_u32_to_i32_clamped(const uint32_t *in, int32_t *out, size_t n)
 {
-    if (nbytes == 0 || nbytes >= (1ull << 32)) {
-        rc_set_error(ctx, "count: arena must be 1..2^32-1 bytes");
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i] > 0x7fffffffu ? 0x7fffffff : (int32_t)in[i];
+}
+
+int rc_count_begin(rc_ctx *ctx)
+{
+    if (ctx->cnt_keys) (void)hipFree(ctx->cnt_keys);
+    if (ctx->cnt_vals) (void)hipFree(ctx->cnt_vals);
+    ctx->cnt_keys = nullptr;
+    ctx->cnt_vals = nullptr;
+    ctx->cnt_n = 0;
+    ctx->cnt_active = true;
+    return RC_OK;
+}
+
+int rc_count_add(rc_ctx *ctx, const uint8_t *d_seq, size_t nbytes)
+{
+    if (!ctx->cnt_active) {
+        rc_set_error(ctx, "count_add: call rc_table_count_begin first");
+        return RC_ERR_STATE;
+    }
+    if (nbytes == 0) return RC_OK;
+    if (nbytes >= (1ull << 32)) {
+        rc_set_error(ctx, "count: an arena must be below 2^32 bytes (add it in pieces)");
         return RC_ERR_ARG;
     }
     const int k = ctx->k;
-    rc_dev_tmp b_keys, b_keys_s, b_cnt, b_keep, b_selc, b_runs, b_tmp;
-    size_t t_sort = 0, t_rle = 0, t_sel = 0;
+    rc_dev_tmp b_keys, b_keys_s, b_cnt, b_runs, b_tmp;
+    size_t t_sort = 0, t_rle = 0;
     RC_CHECK_HIP(ctx, b_keys.alloc(nbytes * 8));
     RC_CHECK_HIP(ctx, b_keys_s.alloc(nbytes * 8));
     RC_CHECK_HIP(ctx, b_runs.alloc(sizeof(size_t) * 2));
     uint64_t *keys = b_keys.as<uint64_t>(), *keys_s = b_keys_s.as<uint64_t>();
-    size_t *d_runs = b_runs.as<size_t>(), *d_nsel = d_runs + 1;
+    size_t *d_runs = b_runs.as<size_t>();
     const unsigned G = (unsigned)((nbytes + RC_PROBE_TILE - 1) / RC_PROBE_TILE);
     hipLaunchKernelGGL(k_emit_kmers, dim3(G), dim3(RC_PROBE_THREADS), 0, ctx->stream, d_seq, nbytes, k, keys);
     RC_CHECK_HIP(ctx, hipGetLastError());
     RC_CHECK_HIP(ctx, rocprim::radix_sort_keys(nullptr, t_sort, keys, keys_s, nbytes, 0, 64, ctx->stream));
     RC_CHECK_HIP(ctx, b_tmp.alloc(t_sort));
     RC_CHECK_HIP(ctx, rocprim::radix_sort_keys(b_tmp.p, t_sort, keys, keys_s, nbytes, 0, 64, ctx->stream));
-    // run-length encode; unique keys reuse `keys`
-    uint64_t *uniq = keys;
+    uint64_t *uniq = keys;  // unique keys reuse `keys`
     RC_CHECK_HIP(ctx, b_cnt.alloc(nbytes * 4));
     uint32_t *cnt = b_cnt.as<uint32_t>();
     RC_CHECK_HIP(ctx, rocprim::run_length_encode(nullptr, t_rle, keys_s, (unsigned int)nbytes, uniq, cnt, d_runs, ctx->stream));
@@ -408,28 +488,117 @@ int rc_count_reads(rc_ctx *ctx, const uint8_t *d_seq, size_t nbytes, int min_cou
     RC_CHECK_HIP(ctx, b_tmp.alloc(t_rle));
     RC_CHECK_HIP(ctx, rocprim::run_length_encode(b_tmp.p, t_rle, keys_s, (unsigned int)nbytes, uniq, cnt, d_runs, ctx->stream));
     size_t runs = 0;
+    uint64_t last_key = 0;
     RC_CHECK_HIP(ctx, hipMemcpyAsync(&runs, d_runs, sizeof(size_t), hipMemcpyDeviceToHost, ctx->stream));
     RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    // keep count >= min_count (and drop the sentinel run)
-    RC_CHECK_HIP(ctx, b_keep.alloc(runs + 1));
-    uint8_t *keep = b_keep.as<uint8_t>();
-    hipLaunchKernelGGL(k_flag_keep, dim3((unsigned)((runs + 255) / 256)), dim3(256), 0, ctx->stream, uniq, cnt, runs, min_count, keep);
-    uint64_t *sel_k = keys_s;  // sorted keys no longer needed
-    RC_CHECK_HIP(ctx, b_selc.alloc((runs + 1) * 4));
-    uint32_t *sel_c = b_selc.as<uint32_t>();
-    RC_CHECK_HIP(ctx, rocprim::select(nullptr, t_sel, uniq, keep, sel_k, d_nsel, runs, ctx->stream));
-    RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    RC_CHECK_HIP(ctx, b_tmp.alloc(t_sel));
-    RC_CHECK_HIP(ctx, rocprim::select(b_tmp.p, t_sel, uniq, keep, sel_k, d_nsel, runs, ctx->stream));
-    RC_CHECK_HIP(ctx, rocprim::select(b_tmp.p, t_sel, cnt, keep, sel_c, d_nsel, runs, ctx->stream));
-    size_t nsel = 0;
-    RC_CHECK_HIP(ctx, hipMemcpyAsync(&nsel, d_nsel, sizeof(size_t), hipMemcpyDeviceToHost, ctx->stream));
-    RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (runs) {
+        RC_CHECK_HIP(ctx, hipMemcpy(&last_key, uniq + (runs - 1), 8, hipMemcpyDeviceToHost));
+        if (last_key == ~0ull) --runs;  // the run of "no k-mer here" sentinels sorts last
+    }
     b_tmp.reset();
-    b_keep.reset();
+    b_keys_s.reset();
+    if (runs == 0) return RC_OK;
+    // merge into the accumulator
+    const size_t total = ctx->cnt_n + runs;
+    rc_dev_tmp m_k, m_v, m_ks, m_vs, m_uk, m_uv;
+    RC_CHECK_HIP(ctx, m_k.alloc(total * 8));
+    RC_CHECK_HIP(ctx, m_v.alloc(total * 4));
+    if (ctx->cnt_n) {
+        RC_CHECK_HIP(ctx, hipMemcpyAsync(m_k.p, ctx->cnt_keys, ctx->cnt_n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        RC_CHECK_HIP(ctx, hipMemcpyAsync(m_v.p, ctx->cnt_vals, ctx->cnt_n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    RC_CHECK_HIP(ctx, hipMemcpyAsync(m_k.as<uint64_t>() + ctx->cnt_n, uniq, runs * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    RC_CHECK_HIP(ctx, hipMemcpyAsync(m_v.as<uint32_t>() + ctx->cnt_n, cnt, runs * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    b_keys.reset();
     b_cnt.reset();
-    b_keys.reset();  // `uniq`: consumed by the select above
-    int rc = rc_build_table_from_device_pairs(ctx, sel_k, reinterpret_cast<const int32_t *>(sel_c), nsel);
+    if (ctx->cnt_n == 0) {  // first arena: it IS the accumulator
+        if (ctx->cnt_keys) (void)hipFree(ctx->cnt_keys);
+        if (ctx->cnt_vals) (void)hipFree(ctx->cnt_vals);
+        ctx->cnt_keys = m_k.as<uint64_t>();
+        ctx->cnt_vals = m_v.as<uint32_t>();
+        m_k.p = nullptr;
+        m_v.p = nullptr;
+        ctx->cnt_n = runs;
+        return RC_OK;
+    }
+    size_t t_sp = 0, t_rk = 0;
+    RC_CHECK_HIP(ctx, m_ks.alloc(total * 8));
+    RC_CHECK_HIP(ctx, m_vs.alloc(total * 4));
+    RC_CHECK_HIP(ctx, rocprim::radix_sort_pairs(nullptr, t_sp, m_k.as<uint64_t>(), m_ks.as<uint64_t>(), m_v.as<uint32_t>(), m_vs.as<uint32_t>(), total, 0, 64, ctx->stream));
+    RC_CHECK_HIP(ctx, b_tmp.alloc(t_sp));
+    RC_CHECK_HIP(ctx, rocprim::radix_sort_pairs(b_tmp.p, t_sp, m_k.as<uint64_t>(), m_ks.as<uint64_t>(), m_v.as<uint32_t>(), m_vs.as<uint32_t>(), total, 0, 64, ctx->stream));
+    RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    m_k.reset();
+    m_v.reset();
+    RC_CHECK_HIP(ctx, m_uk.alloc(total * 8));
+    RC_CHECK_HIP(ctx, m_uv.alloc(total * 4));
+    RC_CHECK_HIP(ctx, rocprim::reduce_by_key(nullptr, t_rk, m_ks.as<uint64_t>(), m_vs.as<uint32_t>(), total, m_uk.as<uint64_t>(), m_uv.as<uint32_t>(), d_runs,
+                                             rocprim::plus<uint32_t>(), rocprim::equal_to<uint64_t>(), ctx->stream));
+    RC_CHECK_HIP(ctx, b_tmp.alloc(t_rk));
+    RC_CHECK_HIP(ctx, rocprim::reduce_by_key(b_tmp.p, t_rk, m_ks.as<uint64_t>(), m_vs.as<uint32_t>(), total, m_uk.as<uint64_t>(), m_uv.as<uint32_t>(), d_runs,
+                                             rocprim::plus<uint32_t>(), rocprim::equal_to<uint64_t>(), ctx->stream));
+    size_t nuniq = 0;
+    RC_CHECK_HIP(ctx, hipMemcpyAsync(&nuniq, d_runs, sizeof(size_t), hipMemcpyDeviceToHost, ctx->stream));
+    RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(ctx->cnt_keys);
+    (void)hipFree(ctx->cnt_vals);
+    ctx->cnt_keys = m_uk.as<uint64_t>();
+    ctx->cnt_vals = m_uv.as<uint32_t>();
+    m_uk.p = nullptr;
+    m_uv.p = nullptr;
+    ctx->cnt_n = nuniq;
+    return RC_OK;
+}
+
+int rc_count_finish(rc_ctx *ctx, int min_count, int64_t *n_kmers)
+{
+    if (!ctx->cnt_active) {
+        rc_set_error(ctx, "count_finish: call rc_table_count_begin first");
+        return RC_ERR_STATE;
+    }
+    ctx->cnt_active = false;
+    const size_t runs = ctx->cnt_n;
+    rc_dev_tmp b_keep, b_selk, b_selc, b_seli, b_n, b_tmp;
+    size_t nsel = 0, t_sel = 0;
+    RC_CHECK_HIP(ctx, b_selk.alloc((runs + 1) * 8));
+    RC_CHECK_HIP(ctx, b_selc.alloc((runs + 1) * 4));
+    RC_CHECK_HIP(ctx, b_seli.alloc((runs + 1) * 4));
+    if (runs) {
+        RC_CHECK_HIP(ctx, b_keep.alloc(runs + 1));
+        RC_CHECK_HIP(ctx, b_n.alloc(sizeof(size_t)));
+        uint8_t *keep = b_keep.as<uint8_t>();
+        size_t *d_nsel = b_n.as<size_t>();
+        hipLaunchKernelGGL(k_flag_keep, dim3((unsigned)((runs + 255) / 256)), dim3(256), 0, ctx->stream, ctx->cnt_keys, ctx->cnt_vals, runs, min_count, keep);
+        RC_CHECK_HIP(ctx, rocprim::select(nullptr, t_sel, ctx->cnt_keys, keep, b_selk.as<uint64_t>(), d_nsel, runs, ctx->stream));
+        RC_CHECK_HIP(ctx, b_tmp.alloc(t_sel));
+        RC_CHECK_HIP(ctx, rocprim::select(b_tmp.p, t_sel, ctx->cnt_keys, keep, b_selk.as<uint64_t>(), d_nsel, runs, ctx->stream));
+        RC_CHECK_HIP(ctx, rocprim::select(b_tmp.p, t_sel, ctx->cnt_vals, keep, b_selc.as<uint32_t>(), d_nsel, runs, ctx->stream));
+        RC_CHECK_HIP(ctx, hipMemcpyAsync(&nsel, d_nsel, sizeof(size_t), hipMemcpyDeviceToHost, ctx->stream));
+        RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (nsel) {
+            hipLaunchKernelGGL(k_u32_to_i32_clamped, dim3((unsigned)((nsel + 255) / 256)), dim3(256), 0, ctx->stream, b_selc.as<uint32_t>(), b_seli.as<int32_t>(), nsel);
+            RC_CHECK_HIP(ctx, hipGetLastError());
+        }
+    }
+    (void)hipFree(ctx->cnt_keys);
+    (void)hipFree(ctx->cnt_vals);
+    ctx->cnt_keys = nullptr;
+    ctx->cnt_vals = nullptr;
+    ctx->cnt_n = 0;
+    int rc = rc_build_table_from_device_pairs(ctx, b_selk.as<uint64_t>(), b_seli.as<int32_t>(), nsel);
     if (n_kmers) *n_kmers = (int64_t)nsel;
+    return rc;
+}
+
+int rc_count_reads(rc_ctx *ctx, const uint8_t *d_seq, size_t nbytes, int min_count, int64_t *n_kmers)
+{
+    if (nbytes == 0 || nbytes >= (1ull << 32)) {
+        rc_set_error(ctx, "count: arena must be 1..2^32-1 bytes");
+        return RC_ERR_ARG;
+    }
+    int rc = rc_count_begin(ctx);
+    if (rc == RC_OK) rc = rc_count_add(ctx, d_seq, nbytes);
+    if (rc == RC_OK) rc = rc_count_finish(ctx, min_count, n_kmers);
     return rc;
 }

@@ -1,0 +1,209 @@
+"""GPU: stages 0-2 replacement (run_rcorrector.pl:262-281) -- the streaming k-mer counter, the
+jellyfish-dump writer and `rcorrector` without -c.
+
+  * counts over several arenas (host and device, ragged, with N) == exact numpy counts
+  * the written dump holds the table's entries in dump order and loads back to the same table
+  * ERROR_RATE from a counted table == ERROR_RATE the reference-pinned file-order path gives on
+    the written dump (with > 100000 qualifying entries, so the order matters)
+  * `rcorrector` without -c reproduces the reference's golden outputs for every fixture whose
+    dump.jf is the exact count of its own reads
+  * `rcorrector` without -c == the pinned CPU oracle CLI (and the reference binary when built)
+    given the dump `-write-dump` wrote, on inputs whose ERROR_RATE is not the 0.01 default
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+import synth
+
+
+@pytest.fixture(scope="module")
+def rc():
+    import rcorrector_amd
+    return rcorrector_amd
+
+pytestmark = pytest.mark.gpu
+CLI = os.path.join(gu.ROOT, "rcorrector_amd", "rcorrector")
+M64 = (1 << 64) - 1
+
+
+def dump_order_key(z):
+    z = np.asarray(z, dtype=np.uint64).copy()   # rc_common.h: rc_dump_order_key (splitmix64 finaliser)
+    z ^= z >> np.uint64(30)
+    z *= np.uint64(0xbf58476d1ce4e5b9)
+    z ^= z >> np.uint64(27)
+    z *= np.uint64(0x94d049bb133111eb)
+    z ^= z >> np.uint64(31)
+    return z
+
+
+def arena_of(rows):
+    return b"".join(bytes(r) + b"\0" for r in rows)
+
+
+def parse_dump(path, k):
+    toks = open(path, "rb").read().split()
+    cnt = np.array([int(t[1:]) for t in toks[0::2]], dtype=np.int64)
+    kmers = toks[1::2]
+    assert all(len(x) == k for x in kmers)
+    a = np.frombuffer(b"".join(kmers), dtype=np.uint8).reshape(-1, k) if kmers else np.zeros((0, k), np.uint8)
+    code = np.zeros(len(kmers), dtype=np.uint64)
+    for j in range(k):
+        code = (code << np.uint64(2)) | synth.CODE[a[:, j]].astype(np.uint64)
+    return code, cnt
+
+
+def sorted_pairs(codes, counts):
+    o = np.argsort(codes, kind="stable")
+    return np.asarray(codes)[o], np.asarray(counts)[o]
+
+
+@pytest.mark.parametrize("k", [15, 23, 32])
+def test_streaming_count_equals_exact_counts(rc, k):
+    import torch
+    s1, _, s2, _, lens = synth.make_reads(77 + k, 3000, 120, n_tx=8, l_tx=600, e=0.01, p_n=0.003, paired=True, var_len=True)
+    rows = [s1[i, :lens[i]] for i in range(len(s1))] + [s2[i, :lens[i]] for i in range(len(s2))]
+    want_k, want_c = synth.count_kmers([s1, s2], k, [lens, lens])
+    ctx = rc.Context(k=k)
+    ctx.count_begin()
+    cuts = [0, 1, 1, 700, 2500, 2501, len(rows)]          # uneven pieces, one empty
+    for i, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+        ar = arena_of(rows[a:b])
+        if i % 2:
+            t = torch.frombuffer(bytearray(ar), dtype=torch.uint8).cuda() if ar else torch.zeros(0, dtype=torch.uint8, device="cuda")
+            ctx.count_add_device(t, len(ar))
+            torch.cuda.synchronize()
+        else:
+            ctx.count_add(ar)
+    n = ctx.count_finish(2)
+    assert n == len(want_k)
+    got_k, got_c = sorted_pairs(*ctx.table_export())
+    assert np.array_equal(got_k, want_k) and np.array_equal(got_c, want_c)
+    # min_count other than 2, and a second use of the same context
+    ctx.count_begin()
+    ctx.count_add(arena_of(rows))
+    n5 = ctx.count_finish(5)
+    keep = want_c >= 5
+    got_k, got_c = sorted_pairs(*ctx.table_export())
+    assert n5 == keep.sum() and np.array_equal(got_k, want_k[keep]) and np.array_equal(got_c, want_c[keep])
+
+
+def test_count_sequence_errors(rc):
+    ctx = rc.Context(k=23)
+    with pytest.raises(rc.RcorrectorError):
+        ctx.count_add(b"ACGT\0")
+    with pytest.raises(rc.RcorrectorError):
+        ctx.count_finish(2)
+    ctx.count_begin()
+    assert ctx.count_finish(2) == 0            # nothing added: an empty table
+    assert ctx.lookup(np.array([5], dtype=np.uint64))[0] == 0
+
+
+def test_write_jfdump_order_and_reload(rc, tmp_path):
+    k = 23
+    s1, _, _, _, _ = synth.make_reads(5, 4000, 100, n_tx=10, l_tx=800, e=0.01)
+    want_k, want_c = synth.count_kmers([s1], k)
+    ctx = rc.Context(k=k)
+    ctx.count_begin()
+    ctx.count_add(arena_of(s1))
+    ctx.count_finish(2)
+    path = str(tmp_path / "out.jf")
+    assert ctx.write_jfdump(path) == len(want_k)
+    code, cnt = parse_dump(path, k)
+    keys = dump_order_key(code)
+    assert np.all(keys[1:] > keys[:-1]), "entries must be in ascending rc_dump_order_key order"
+    a, b = sorted_pairs(code, cnt)
+    assert np.array_equal(a, want_k) and np.array_equal(b, want_c)
+    ctx2 = rc.Context(k=k)
+    assert ctx2.load_jfdump(path) == len(want_k)
+    a2, b2 = sorted_pairs(*ctx2.table_export())
+    assert np.array_equal(a2, want_k) and np.array_equal(b2, want_c)
+
+
+def test_error_rate_of_counted_table_equals_file_order_path(rc, tmp_path):
+    """> 100000 entries qualify (max of the 4 last-base variants >= 1000), so which 100000 are
+    sampled depends on the scan order: the in-memory dump-order path must equal the file-order
+    path (pinned to the reference by test_gpu_parity/test_golden_*) run on the written dump."""
+    k = 25
+    rng = np.random.Generator(np.random.PCG64(31))
+    n = 160000
+    base = rng.integers(0, 1 << 62, size=n, dtype=np.uint64) & np.uint64((1 << (2 * k)) - 1)
+    base &= ~np.uint64(3)
+    base = np.unique(base)
+    codes, counts = [], []
+    hi = rng.integers(1000, 6000, size=len(base))
+    frac = rng.random(len(base)) * 0.05
+    for v in range(4):
+        codes.append(base | np.uint64(v))
+        counts.append(hi if v == 0 else np.maximum(2, (hi * frac * rng.random(len(base))).astype(np.int64)))
+    codes = np.concatenate(codes)
+    counts = np.concatenate(counts).astype(np.int32)
+    ctx = rc.Context(k=k)
+    ctx.table_build(codes, counts)
+    r_mem = ctx.estimate_error_rate(0.95)
+    path = str(tmp_path / "t.jf")
+    ctx.write_jfdump(path)
+    ctx2 = rc.Context(k=k)
+    ctx2.load_jfdump(path)
+    r_file = ctx2.estimate_error_rate(0.95)
+    assert r_mem == r_file and 0 < r_mem < 0.05 and r_mem != 0.01
+    # and a different order gives a different sample (so the test can tell)
+    code, cnt = parse_dump(path, k)
+    synth.write_dump(str(tmp_path / "asc.jf"), *sorted_pairs(code, cnt), k)
+    ctx3 = rc.Context(k=k)
+    ctx3.load_jfdump(str(tmp_path / "asc.jf"))
+    assert ctx3.estimate_error_rate(0.95) != r_file
+
+
+EXACT_DUMP_FIXTURES = ["fx_sample", "fx_se_k23", "fx_pe_k23", "fx_il_k23", "fx_k31_mc8", "fx_skew", "fx_k32", "fx_k15", "fx_varlen_n"]
+
+
+@pytest.mark.parametrize("name", EXACT_DUMP_FIXTURES)
+def test_cli_without_c_reproduces_reference_outputs(name, tmp_path):
+    """These fixtures' dump.jf is the exact k-mer count (>= 2) of the fixture's own reads, i.e. what
+    stages 0-2 produce; counting on the GPU instead must give the reference's bytes."""
+    args = open(os.path.join(gu.GOLDEN, name, "cmd.txt")).read().split()
+    i = args.index("-c")
+    del args[i:i + 2]
+    p = gu.run_fixture(CLI, name, tmp_path, args_override=args)
+    gu.assert_same_as_reference(name, tmp_path, p.stderr)
+
+
+def _run(binary, args, cwd, od, more=()):
+    os.makedirs(od)
+    p = subprocess.run([binary] + args + ["-od", od] + list(more), cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr.decode()
+    return p.stderr, {f: open(os.path.join(od, f), "rb").read() for f in sorted(os.listdir(od))}
+
+
+@pytest.mark.parametrize("paired", [False, True])
+def test_cli_without_c_equals_cpu_given_the_written_dump(oracle, paired, tmp_path):
+    """High coverage of one short transcript: > 100 entries reach count 1000, so ERROR_RATE is
+    estimated rather than defaulted -- the whole chain count -> dump order -> ERROR_RATE ->
+    correction must agree with the CPU implementations reading our dump."""
+    d = str(tmp_path)
+    s1, q1, s2, q2, _ = synth.make_reads(4242, 30000, 100, n_tx=1, l_tx=400, alpha=0.0, e=0.004, paired=paired)
+    if paired:
+        synth.write_fastq(os.path.join(d, "a_1.fq"), s1, q1, "/1")
+        synth.write_fastq(os.path.join(d, "a_2.fq"), s2, q2, "/2")
+        inp = ["-p", "a_1.fq", "a_2.fq"]
+    else:
+        synth.write_fastq(os.path.join(d, "a.fq"), s1, q1)
+        inp = ["-r", "a.fq"]
+    dump = os.path.join(d, "gpu.jf")
+    err_g, out_g = _run(CLI, inp + ["-k", "23", "-write-dump", dump, "-batch", "4096"], d, os.path.join(d, "g"))
+    assert b"Weak kmer threshold rate: 0.01000" not in err_g
+    code, cnt = parse_dump(dump, 23)
+    wk, wc = synth.count_kmers([s1, s2], 23)
+    a, b = sorted_pairs(code, cnt)
+    assert np.array_equal(a, wk) and np.array_equal(b, wc)
+    binaries = [oracle.CLI_BIN] + ([oracle.REF_BIN] if os.path.exists(oracle.REF_BIN) else [])
+    for j, binary in enumerate(binaries):
+        err_c, out_c = _run(binary, inp + ["-k", "23", "-c", dump, "-t", "8"], d, os.path.join(d, "c%d" % j))
+        assert out_c.keys() == out_g.keys() and out_c
+        for f in out_c:
+            assert out_g[f] == out_c[f], "%s differs from %s" % (f, binary)
+        assert err_g == err_c
