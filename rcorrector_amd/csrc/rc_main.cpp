@@ -582,6 +582,7 @@ int main(int argc, char **argv)
             if (files[fi].paired) inputs.emplace_back(mates[fi].path, mates[fi].fastq);
         }
         count_inputs(ctx[0], inputs, &stored);
+        if (g_timing) fprintf(stderr, "[rc timing] k-mer counting pass over %zu file(s): %.2f s\n", inputs.size(), now_s() - t_start);
         if (gpus > 1) {  // replicate: one export, one build per further GPU
             std::vector<uint64_t> codes((size_t)stored + 1);
             std::vector<int32_t> counts((size_t)stored + 1);

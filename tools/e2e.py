@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--err", type=float, default=0.005)
     ap.add_argument("--dir", default="/tmp/rc_e2e")
     ap.add_argument("--cli-args", default="")
+    ap.add_argument("--count", action="store_true", help="also run every variant without -c (k-mers counted by the CLI)")
     a = ap.parse_args()
     os.makedirs(a.dir, exist_ok=True)
     dev = torch.device("cuda", 0)
@@ -69,13 +70,17 @@ def main():
     del ctx
     cli = os.path.join(ROOT, "rcorrector_amd", "rcorrector")
     env = dict(os.environ, RC_TIMING="1")
+    import hashlib
     for variant in a.cli_args.split(";"):
-        t0 = time.time()
-        p = subprocess.run([cli, "-r", "x.fq", "-k", str(k), "-c", "x.jf", "-od", a.dir + "/out"] + variant.split(),
-                           cwd=a.dir, env=env, stderr=subprocess.PIPE)
-        dt = time.time() - t0
-        sys.stderr.write(p.stderr.decode())
-        print("CLI [%s] wall %.2f s -> %.2f M reads/s end to end" % (variant, dt, n / dt / 1e6))
+        for dump in ([["-c", "x.jf"], []] if a.count else [["-c", "x.jf"]]):
+            t0 = time.time()
+            p = subprocess.run([cli, "-r", "x.fq", "-k", str(k), "-od", a.dir + "/out"] + dump + variant.split(),
+                               cwd=a.dir, env=env, stderr=subprocess.PIPE)
+            dt = time.time() - t0
+            sys.stderr.write(p.stderr.decode())
+            md5 = hashlib.md5(open(a.dir + "/out/x.cor.fq", "rb").read()).hexdigest()
+            print("CLI [%s %s] wall %.2f s -> %.2f M reads/s end to end, output md5 %s" % (
+                " ".join(dump) or "(counting)", variant, dt, n / dt / 1e6, md5))
 
 
 if __name__ == "__main__":
