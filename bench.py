@@ -3,10 +3,16 @@
 
 Contract: `python bench.py --gpus N --steps K --warmup W` (N>1 under torch.distributed.run, one
 rank per GPU).  A step = one pass of the whole hot path (probe K1 -> threshold K2 -> correct K3,
-rc_correct_device) over one batch of synthetic reads already resident in HBM.  Default workload
-= BASELINE.json configs[1]: 10 M synthetic 100 bp single-end reads, k=23, k-mer table counted
-from those reads (~50 M k-mers), 1 GPU.  Reads shard across ranks with the table replicated
-(no data-path collective); `value` = reads all ranks corrected / max-over-ranks wall time.
+rc_correct_device) over one batch of synthetic reads already resident in HBM.
+
+Default workload (`--config 2`) = the configuration BASELINE.json's metric ("corrected reads/sec
+(150 bp, k=23) at 1/2/4/8 MI355X") is quoted on, configs[2]: 200 M synthetic 150 bp paired-end
+reads on 8 GPUs, read-sharded with the table replicated -- i.e. 25 M reads (12.5 M pairs) per GPU,
+weak scaling, so `--gpus 8` is configs[2] itself.  `--config 1` = configs[1]: 10 M synthetic
+100 bp single-end reads, 1 GPU.  Both: k=23, synth-v1 transcriptome of 30 000 x 1 500 bp, 0.5 %
+substitutions, k-mer table counted on the GPU from rank 0's shard (~50 M k-mers), ERROR_RATE
+estimated from that table as the reference does from its dump (main.cpp:310-358).  No data-path
+collective; `value` = reads all ranks corrected / max-over-ranks wall time.
 
 The JSON line also carries
   roofline     : the hash-probe kernel (K1) timed with HIP events on the library's stream inside
@@ -80,8 +86,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step")
-    ap.add_argument("--len", type=int, default=100)
+    ap.add_argument("--config", type=int, default=2, choices=[1, 2],
+                    help="BASELINE.json configs[i]: 2 = 150 bp paired-end, 25 M reads per GPU (default); 1 = 10 M x 100 bp single-end")
+    ap.add_argument("--reads", type=int, default=None, help="reads per GPU per step (overrides the config's)")
+    ap.add_argument("--len", type=int, default=None, help="read length (overrides the config's)")
     ap.add_argument("-k", type=int, default=23)
     ap.add_argument("--n-tx", type=int, default=30000)
     ap.add_argument("--l-tx", type=int, default=1500)
@@ -89,11 +97,21 @@ def main():
     ap.add_argument("--alpha", type=float, default=0.8)
     ap.add_argument("--seed", type=int, default=1001000)
     ap.add_argument("--maxcork", type=int, default=4, help="-maxcorK (MAX_FIX_PER_K)")
-    ap.add_argument("--paired", action="store_true", help="paired-end batch (mode 1): --reads counts both mates")
+    ap.add_argument("--paired", action="store_true", default=None, help="paired-end batch (mode 1): --reads counts both mates")
+    ap.add_argument("--single", dest="paired", action="store_false", help="single-end batch (mode 0)")
+    ap.add_argument("--fixed-error-rate", type=float, default=None, help="use this ERROR_RATE instead of estimating it from the table")
     ap.add_argument("--host-path", action="store_true",
                     help="also time the host-buffer entry point rc_correct_batch (PCIe inclusive; reported, never `value`)")
     ap.add_argument("--cpu-sample", type=int, default=3000000, help="reads of the CPU-baseline sample (0 = skip)")
     a = ap.parse_args()
+    preset = {1: (10_000_000, 100, False), 2: (25_000_000, 150, True)}[a.config]
+    if a.reads is None:
+        a.reads = preset[0]
+    if a.len is None:
+        a.len = preset[1]
+    if a.paired is None:
+        a.paired = preset[2]
+    is_preset = (a.reads, a.len, a.paired) == preset and a.k == 23 and a.maxcork == 4
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -108,6 +126,12 @@ def main():
     def barrier():
         if world > 1:
             dist.barrier()
+
+    t_prog = time.time()
+
+    def progress(what):
+        if rank == 0 and os.environ.get("RC_BENCH_PROGRESS"):
+            print("[bench %6.1f s] %s" % (time.time() - t_prog, what), file=sys.stderr, flush=True)
 
     L, k, n = a.len, a.k, a.reads
     mode = 1 if a.paired else 0
@@ -124,6 +148,7 @@ def main():
     t0 = time.time()
     n_kmers = ctx.count_reads_device(seq0, seq0.numel(), 2)
     t_count = time.time() - t0
+    progress("synth %.2f s, count+table %.2f s, %d k-mers" % (t_gen, t_count, n_kmers))
     if rank != 0:
         del seq0, qual0
         seq0, qual0 = synth_reads_gpu(a.seed + rank, n, L, a.n_tx, a.l_tx, a.alpha, a.err, dev, paired=a.paired)
@@ -134,8 +159,11 @@ def main():
     fh = torch.bincount(first_q.long(), minlength=300)[:300].cpu().numpy().astype(np.int32)
     lh = torch.bincount(last_q.long(), minlength=300)[:300].cpu().numpy().astype(np.int32)
     bad_q = ctx.bad_quality_from_hist(fh, lh, int(first_q.numel()))
-    error_rate = 0.01  # the reference's fallback (main.cpp:355-356); the estimate needs a dump file order
+    # ERROR_RATE as the reference derives it from its dump (main.cpp:310-358), here from the table
+    # counted above (scanned in the library's dump order); every rank gets the same value
+    error_rate = a.fixed_error_rate if a.fixed_error_rate is not None else ctx.estimate_error_rate(0.95)
     ctx.set_run_params(error_rate, bad_q)
+    progress("ERROR_RATE %.6f, bad quality %r" % (error_rate, bad_q))
 
     work = seq0.clone()
     ret = torch.zeros(n, dtype=torch.int32, device=dev)
@@ -151,6 +179,7 @@ def main():
 
     for _ in range(a.warmup):
         step()
+        progress("warm-up step done")
     ctx.profile(True)
     ctx.profile_reset()
     barrier()
@@ -163,6 +192,7 @@ def main():
     ctx.sync()
     barrier()
     dt = time.perf_counter() - t0
+    progress("timed steps done: %.1f ms per step" % (dt / a.steps * 1e3))
     ctx.profile(False)
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -199,8 +229,8 @@ def main():
             host_rate = hn / (time.perf_counter() - th)
 
         cpu = None
-        if a.cpu_sample > 0 and not a.paired:
-            cpu = cpu_baseline(ctx, seq0, qual0, n, L, k, error_rate, bad_q, a.cpu_sample, ret, work, a.maxcork)
+        if a.cpu_sample > 0:
+            cpu = cpu_baseline(ctx, seq0, qual0, n, L, k, error_rate, bad_q, a.cpu_sample, ret, work, a.maxcork, a.paired)
 
         out = {
             "metric": "corrected reads/sec (%d bp, k=%d)" % (L, k),
@@ -209,7 +239,8 @@ def main():
             "vs_baseline": None, "dtype": "u8/int32/u64", "data": "synthetic",
             "config": {"workload": "%d synthetic %d bp %s reads per GPU, k=%d, %d-k-mer table%s"
                        % (n, L, "paired-end" if a.paired else "single-end", k, n_kmers,
-                          " (BASELINE.json configs[1])" if (not a.paired and L == 100 and n == 10_000_000) else ""),
+                          (" (BASELINE.json configs[1])" if a.config == 1 else
+                           " (BASELINE.json configs[2]: 200 M reads on 8 GPUs = 25 M per GPU, read-sharded)") if is_preset else ""),
                        "reads_per_gpu": n, "read_len": L, "k": k, "table_kmers": n_kmers,
                        "table_bytes": ts["bytes"], "sub_rate": a.err, "error_rate_param": error_rate,
                        "bad_quality": bad_q.decode("latin1"), "parallelism": "reads sharded x%d, table replicated" % world,
@@ -229,9 +260,10 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(ctx, seq0, qual0, n, L, k, error_rate, bad_q, sample, ret_gpu, work_gpu, maxcork=4):
-    """The CPU oracle on the first `sample` reads with the same table, all host cores; also checks
-    the GPU results of those reads against it (the oracle is the checker here, never the product)."""
+def cpu_baseline(ctx, seq0, qual0, n, L, k, error_rate, bad_q, sample, ret_gpu, work_gpu, maxcork=4, paired=False):
+    """The CPU oracle on the first `sample` reads (paired: the first sample/2 pairs) with the same
+    table, all host cores; also checks the GPU results of those reads against it (the oracle is
+    the checker here, never the product)."""
     from oracle import pyoracle as po
     po.build()
     sample = min(sample, n)
@@ -239,18 +271,39 @@ def cpu_baseline(ctx, seq0, qual0, n, L, k, error_rate, bad_q, sample, ret_gpu, 
     T = po.Table(k, len(codes))
     T.put_many(codes, counts)
     P = po.make_params(k, maxcork, error_rate, bad_q)
-    nb = sample * (L + 1)
-    arena = seq0[:nb].cpu().numpy().copy()
-    qa = qual0[:nb].cpu().numpy().copy()
-    off = (np.arange(sample + 1, dtype=np.int64) * (L + 1)).astype(np.uint32)
     cores = os.cpu_count() or 1
-    t0 = time.perf_counter()
-    r, _, _, _ = po.correct_batch(P, T, 0, arena, qa, off, threads=cores)
-    dt = time.perf_counter() - t0
-    same = bool(np.array_equal(r, ret_gpu[:sample].cpu().numpy()) and
-                np.array_equal(arena, work_gpu[:nb].cpu().numpy()))
+    if not paired:
+        nb = sample * (L + 1)
+        arena = seq0[:nb].cpu().numpy().copy()
+        qa = qual0[:nb].cpu().numpy().copy()
+        off = (np.arange(sample + 1, dtype=np.int64) * (L + 1)).astype(np.uint32)
+        t0 = time.perf_counter()
+        r, _, _, _ = po.correct_batch(P, T, 0, arena, qa, off, threads=cores)
+        dt = time.perf_counter() - t0
+        same = bool(np.array_equal(r, ret_gpu[:sample].cpu().numpy()) and
+                    np.array_equal(arena, work_gpu[:nb].cpu().numpy()))
+        what = "first %d reads" % sample
+    else:
+        # device layout (mode 1): all first mates, then all second mates
+        half, sp = n // 2, sample // 2
+        sample = 2 * sp
+        nb = sp * (L + 1)
+        b2 = half * (L + 1)
+        a1 = seq0[:nb].cpu().numpy().copy()
+        q1 = qual0[:nb].cpu().numpy().copy()
+        a2 = seq0[b2:b2 + nb].cpu().numpy().copy()
+        q2 = qual0[b2:b2 + nb].cpu().numpy().copy()
+        off = (np.arange(sp + 1, dtype=np.int64) * (L + 1)).astype(np.uint32)
+        t0 = time.perf_counter()
+        r, _, _, _ = po.correct_batch(P, T, 1, a1, q1, off, a2, q2, off, threads=cores)
+        dt = time.perf_counter() - t0
+        rg = ret_gpu.cpu().numpy()
+        same = bool(np.array_equal(r[:sp], rg[:sp]) and np.array_equal(r[sp:], rg[half:half + sp]) and
+                    np.array_equal(a1, work_gpu[:nb].cpu().numpy()) and
+                    np.array_equal(a2, work_gpu[b2:b2 + nb].cpu().numpy()))
+        what = "first %d pairs (%d reads)" % (sp, sample)
     return {"value": sample / dt, "unit": "reads/s", "cores": cores, "kind": "port",
-            "sample": "first %d reads of the same batch, same table, %d pthreads, %.1f s" % (sample, cores, dt),
+            "sample": "%s of the same batch, same table, %d pthreads, %.1f s" % (what, cores, dt),
             "gpu_matches_oracle_on_sample": same}
 
 
