@@ -229,7 +229,7 @@ def main():
             host_rate = hn / (time.perf_counter() - th)
 
         cpu = None
-        if a.cpu_sample > 0:
+        if a.cpu_sample > 0 and world == 1:   # rank 0 at N=1 only
             cpu = cpu_baseline(ctx, seq0, qual0, n, L, k, error_rate, bad_q, a.cpu_sample, ret, work, a.maxcork, a.paired)
 
         out = {
