@@ -125,6 +125,26 @@ typedef struct {
 } rc_batch;
 int rc_correct_batch(rc_ctx *ctx, rc_batch *b);
 
+/* rc_correct_batch plus everything the reference prints per read under -verbose (VERBOSE,
+ * ErrorCorrection.cpp:15,686-689,759-770,856-857,1088-1094,1590-1597), as data; the caller formats
+ * it (rc_main.cpp does, byte for byte).  Reads are indexed like ret/l/m/h (mode 1: arena 2's reads
+ * at [n, 2n)); arena bytes are arena 1's followed by arena 2's.
+ *   counts_before/after[a] = GetCount of the k-mer starting at arena byte a, before / after the
+ *     correction (0 where the window holds a non-ACGT letter or runs past the read);
+ *   flags[r] bit 0: read r passed the screens, i.e. "Before correction" is printed;
+ *   n_iter[r]: threshold iterations of read r (may exceed max_iter: only the first max_iter are
+ *     recorded);  iter + (r*max_iter + i)*RC_TRACE_ITER_WORDS: iteration i = {strong trust
+ *     threshold, threshold, 1 if the bitmap was reached, 0, 32 words of the "Is corresponding base
+ *     strong trusted?" bitmap (bit b of word w = base 32w+b)}. */
+#define RC_TRACE_ITER_WORDS 36
+typedef struct {
+    int32_t max_iter;
+    int32_t *counts_before, *counts_after; /* [arena bytes] */
+    int32_t *flags, *n_iter;               /* [reads] */
+    int32_t *iter;                         /* [reads * max_iter * RC_TRACE_ITER_WORDS] */
+} rc_trace;
+int rc_correct_batch_traced(rc_ctx *ctx, rc_batch *b, rc_trace *t);
+
 /* Batch already resident in HBM (asynchronous on the context's stream; rc_sync() to wait).
  * In mode 1 the arena holds the n/2 first mates followed by the n/2 second mates. */
 typedef struct {

@@ -122,9 +122,11 @@ void rc_destroy(rc_ctx *c)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     rc_dbuf *bufs[] = {&ctx->counts, &ctx->strong, &ctx->info, &ctx->stack, &ctx->work,
-                       &ctx->h_seq, &ctx->h_qual, &ctx->h_off, &ctx->h_res};
+                       &ctx->h_seq, &ctx->h_qual, &ctx->h_off, &ctx->h_res, &ctx->trace};
     for (rc_dbuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
+    if (ctx->cnt_keys) (void)hipFree(ctx->cnt_keys);
+    if (ctx->cnt_vals) (void)hipFree(ctx->cnt_vals);
     if (ctx->d_buckets && !ctx->buckets_borrowed) (void)hipFree(ctx->d_buckets);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -633,7 +635,28 @@ int rc_sync(rc_ctx *ctx)
     return RC_OK;
 }
 
-int rc_correct_batch(rc_ctx *c, rc_batch *b)
+static int correct_batch_impl(rc_ctx *c, rc_batch *b, rc_trace *t);
+
+int rc_correct_batch(rc_ctx *c, rc_batch *b) { return correct_batch_impl(c, b, nullptr); }
+
+// rc_correct_batch + what the reference prints under -verbose (VERBOSE, ErrorCorrection.cpp:15):
+// the counts before (:759-770) and after (:1590-1597) come from two extra runs of the probe
+// kernel, the per-iteration thresholds and bitmaps (:856-857, :1088-1094) from the TRACE build of
+// k_correct
+int rc_correct_batch_traced(rc_ctx *c, rc_batch *b, rc_trace *t)
+{
+    if (!c || !b || !t) return RC_ERR_ARG;
+    if (t->max_iter < 1 || !t->counts_before || !t->counts_after || !t->flags || !t->n_iter || !t->iter) {
+        rc_set_error(c, "correct_batch_traced: bad trace descriptor");
+        return RC_ERR_ARG;
+    }
+    c->trace_cap = t->max_iter;
+    int rc = correct_batch_impl(c, b, t);
+    c->trace_cap = 0;
+    return rc;
+}
+
+static int correct_batch_impl(rc_ctx *c, rc_batch *b, rc_trace *t)
 {
     if (!c || !b) return RC_ERR_ARG;
     rc_ctx_full *ctx = static_cast<rc_ctx_full *>(c);
@@ -693,6 +716,22 @@ int rc_correct_batch(rc_ctx *c, rc_batch *b)
     RC_CHECK_HIP(ctx, hipMemcpyAsync(b->l, db.d_l, total_reads * 4, hipMemcpyDeviceToHost, ctx->stream));
     RC_CHECK_HIP(ctx, hipMemcpyAsync(b->m, db.d_m, total_reads * 4, hipMemcpyDeviceToHost, ctx->stream));
     RC_CHECK_HIP(ctx, hipMemcpyAsync(b->h, db.d_h, total_reads * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (t) {
+        // before: K1's output is still in ctx->counts; after: probe the corrected arena once more
+        RC_CHECK_HIP(ctx, hipMemcpyAsync(t->counts_before, ctx->counts.p, nbytes * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if ((rc = rc_launch_probe(ctx, d_seq, nbytes, (int32_t *)ctx->counts.p))) return rc;
+        RC_CHECK_HIP(ctx, hipMemcpyAsync(t->counts_after, ctx->counts.p, nbytes * 4, hipMemcpyDeviceToHost, ctx->stream));
+        const size_t rec = 2 + (size_t)t->max_iter * RC_TRACE_WORDS;
+        std::vector<int32_t> raw(total_reads * rec);
+        RC_CHECK_HIP(ctx, hipMemcpyAsync(raw.data(), ctx->trace.p, raw.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+        RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (size_t i = 0; i < total_reads; ++i) {
+            const int32_t *r = raw.data() + i * rec;
+            t->flags[i] = r[0];
+            t->n_iter[i] = r[1];
+            memcpy(t->iter + i * (size_t)t->max_iter * RC_TRACE_WORDS, r + 2, (size_t)t->max_iter * RC_TRACE_WORDS * 4);
+        }
+    }
     RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (size_t i = 0; i < total_reads; ++i) {  // UpdateSummary, main.cpp:73-79
         ++ctx->total_reads;

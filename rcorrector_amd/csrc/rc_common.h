@@ -22,6 +22,7 @@
 #endif
 
 #define RC_MAX_READ_LENGTH 1024  // utils.h:7 (reads hold <=1023 bases)
+#define RC_TRACE_WORDS 36         // int32 words per recorded iteration (rcorrector_amd.h: RC_TRACE_ITER_WORDS)
 #define RC_MAX_TRIAL 1025        // ErrorCorrection.cpp:7
 #define RC_INF 1000000000        // utils.h:10
 #define RC_INT_MIN (-2147483647 - 1)

@@ -11,7 +11,9 @@
 #include "rc_device.h"
 
 // PROF = per-phase s_memtime accounting (dev aid, RC_PHASE_PROF=1); compiled out otherwise
-template <bool PROF>
+// TRACE = record what the reference prints under -verbose for every threshold iteration
+//         (ErrorCorrection.cpp:856-857, :1088-1094) into a per-read record; compiled out otherwise
+template <bool PROF, bool TRACE = false>
 struct DevWaveT {
     static const int STRIDE = 64;
     int lane;
@@ -19,6 +21,50 @@ struct DevWaveT {
     int cur_phase = 0;
     unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     __device__ __forceinline__ void stat(int, int) {}
+    // trace record of the current read: [0] flags (bit 0: passed the screens, i.e. "Before
+    // correction" is printed), [1] iterations seen, then RC_TRACE_WORDS per recorded iteration:
+    // strong, trust, has_bitmap, 0, 32 words of the per-base "strong trusted" bitmap
+    int32_t *tr = nullptr;
+    int tr_cap = 0;
+    __device__ __forceinline__ void trace_passed()
+    {
+        if (TRACE && lane == 0) tr[0] |= 1;
+    }
+    __device__ __forceinline__ void trace_iter(int strong, int trust)
+    {
+        if (TRACE) {
+            const int it = uni(tr[1]);
+            if (lane == 0) {
+                if (it < tr_cap) {
+                    int32_t *e = tr + 2 + (size_t)it * RC_TRACE_WORDS;
+                    e[0] = strong;
+                    e[1] = trust;
+                    e[2] = 0;
+                    e[3] = 0;
+                }
+                tr[1] = it + 1;
+            }
+            sync();
+        }
+    }
+    __device__ __forceinline__ void trace_strong(const unsigned char *strongb, int len)
+    {
+        if (TRACE) {
+            const int it = uni(tr[1]) - 1;
+            if (it >= 0 && it < tr_cap) {
+                int32_t *e = tr + 2 + (size_t)it * RC_TRACE_WORDS;
+                for (int c = 0; c < RC_MAX_READ_LENGTH / 64; ++c) {
+                    const uint64_t m = ballot64(c << 6, len, [&](int q) { return strongb[q] != 0; });
+                    if (lane == 0) {
+                        e[4 + 2 * c] = (int32_t)(uint32_t)m;
+                        e[5 + 2 * c] = (int32_t)(uint32_t)(m >> 32);
+                    }
+                }
+                if (lane == 0) e[2] = 1;
+            }
+            sync();
+        }
+    }
     __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
     __device__ __forceinline__ uint64_t uni64(uint64_t x)
     {
@@ -287,6 +333,8 @@ struct rc_kernel_args {
     uint32_t *work;
     int cap;
     unsigned long long *phase_cycles;  // [8], PROF builds only
+    int32_t *trace;                    // TRACE builds only: n x (2 + trace_cap * RC_TRACE_WORDS) words
+    int trace_cap;
 };
 
 template <class W>
@@ -335,15 +383,16 @@ __global__ __launch_bounds__(64) void k_threshold(rc_kernel_args A)
 #define RC_K3_WAVES 6  // waves per SIMD the register allocation of k_correct is held to
 #endif
 
-template <bool PROF>
+template <bool PROF, bool TRACE>
 __global__ __launch_bounds__(64, RC_K3_WAVES) void k_correct(rc_kernel_args A)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const rc_lds_layout L = rc_layout(A.cap);
     rc_read_state S;
     rc_carve(lds, L, S);
-    DevWaveT<PROF> w;
+    DevWaveT<PROF, TRACE> w;
     w.lane = threadIdx.x;
+    w.tr_cap = A.trace_cap;
     if (PROF) w.t_last = __builtin_readcyclecounter();
     w.T = A.T;
     w.k = A.P.k;
@@ -362,6 +411,11 @@ __global__ __launch_bounds__(64, RC_K3_WAVES) void k_correct(rc_kernel_args A)
         }
         const uint32_t r = chunk_lo++;
         w.phase(0);
+        if (TRACE) {
+            w.tr = A.trace + (size_t)r * (2 + (size_t)A.trace_cap * RC_TRACE_WORDS);
+            if (w.lane == 0) w.tr[0] = w.tr[1] = 0;
+            w.sync();
+        }
         rc_load_read(w, A, S, r, w.lane, true);
         const uint32_t o = A.off[r];
         int strong0, info0;
@@ -460,6 +514,8 @@ static int fill_args(rc_ctx *ctx, const rc_device_batch_args &a, rc_kernel_args 
     A.work = (uint32_t *)ctx->work.p;
     A.cap = rc_cap_for(a.max_len);
     A.phase_cycles = nullptr;
+    A.trace = nullptr;
+    A.trace_cap = 0;
     return RC_OK;
 }
 
@@ -494,11 +550,19 @@ int rc_launch_correct(rc_ctx *ctx, const rc_device_batch_args &a)
     A.stack = (rc_frame *)ctx->stack.p;
     RC_CHECK_HIP(ctx, hipMemsetAsync(ctx->work.p, 0, 128, ctx->stream));
     A.phase_cycles = (unsigned long long *)((char *)ctx->work.p + 64);
+    if (ctx->trace_cap > 0) {
+        rc = rc_dbuf_reserve(ctx, &ctx->trace, (size_t)a.n * (2 + (size_t)ctx->trace_cap * RC_TRACE_WORDS) * 4);
+        if (rc) return rc;
+        A.trace = (int32_t *)ctx->trace.p;
+        A.trace_cap = ctx->trace_cap;
+    }
     rc_timer_begin(ctx);
-    if (ctx->phase_prof)
-        hipLaunchKernelGGL(k_correct<true>, dim3(grid), dim3(64), L.total, ctx->stream, A);
+    if (ctx->trace_cap > 0)
+        hipLaunchKernelGGL((k_correct<false, true>), dim3(grid), dim3(64), L.total, ctx->stream, A);
+    else if (ctx->phase_prof)
+        hipLaunchKernelGGL((k_correct<true, false>), dim3(grid), dim3(64), L.total, ctx->stream, A);
     else
-        hipLaunchKernelGGL(k_correct<false>, dim3(grid), dim3(64), L.total, ctx->stream, A);
+        hipLaunchKernelGGL((k_correct<false, false>), dim3(grid), dim3(64), L.total, ctx->stream, A);
     rc_timer_end(ctx, RC_T_CORRECT);
     if (ctx->phase_prof) {
         unsigned long long pc[8];

@@ -22,6 +22,7 @@
 //   w.sort(a, n)                  ascending in-LDS sort
 //   w.stack_push/top/set_mask     search stack frames (HBM scratch)
 //   w.phase(id) / w.stat(i, v)    optional accounting hooks
+//   w.trace_passed/iter/strong    optional -verbose recording hooks
 // The device back end is DevWaveT in rc_correct.hip; tests/hostsim has a lane-serial one
 // (STRIDE = 1) that lets the CPU test-suite diff this exact control flow against the oracle.
 #pragma once
@@ -733,6 +734,7 @@ RC_HD int rc_correct_read(W &w, rc_read_state &S, const rc_run_params &P, int pa
     const int len = S.len, kcnt = S.kcnt;
     if (len < k) return -1;   // :713
     if (info0 & 4) return -1; // screens, :735-755
+    w.trace_passed();         // -verbose prints "Before correction" from here on, :759-770
 
     // initial thresholds, :793-842
     int strong = strong0, trust;
@@ -754,6 +756,7 @@ RC_HD int rc_correct_read(W &w, rc_read_state &S, const rc_run_params &P, int pa
     int tstart = 0, tend = 0;
     for (;;) {  // :854-1291
         w.phase(2);
+        w.trace_iter(strong, trust);  // :856-857
         const int allowed_fix = len;
         total_fix = 0;
         bool unfixable = false, force_next = false;
@@ -896,6 +899,7 @@ RC_HD int rc_correct_read(W &w, rc_read_state &S, const rc_run_params &P, int pa
             for (i = 0; i < seg_cnt; ++i) S.seg[i].top2[0] = S.seg[i].top2[1] = -1;
         }
         w.sync();
+        w.trace_strong(S.strongb, len);  // :1088-1094
 
         if (longest == -1) return -1;  // :1107
         if (longest == kcnt) return 0; // :1110

@@ -76,6 +76,10 @@ struct rc_ctx {
     size_t n_entries = 0;   // accepted entries (duplicates included)
     size_t table_bytes = 0;
 
+    // -verbose support: iterations recorded per read by k_correct (0 = off) and the record buffer
+    int trace_cap = 0;
+    rc_dbuf trace;
+
     // streaming k-mer counter (rc_table_count_begin/add/finish): sorted (code, count) accumulator
     uint64_t *cnt_keys = nullptr;
     uint32_t *cnt_vals = nullptr;

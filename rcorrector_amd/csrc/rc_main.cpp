@@ -16,7 +16,8 @@
 // -batch N sets the reads per batch, -inflight N the batches in flight per GPU (contexts sharing one
 // table; keeps the GPU busy while a batch's slowest reads finish).  -t sets the host threads used
 // for packing / formatting.
-// -verbose (per-read trace on stdout) is not provided by the GPU path and is refused loudly.
+// -verbose prints the reference's per-read transcript (the -t 1 order) from rc_correct_batch_traced;
+// -write-dump FILE keeps the k-mer table as jellyfish-dump text; without -c the k-mers are counted here.
 #include <fcntl.h>
 #include <stdarg.h>
 #include <stdint.h>
@@ -44,6 +45,8 @@
 #define MAX_ID_LENGTH 2048   // utils.h:8
 
 static bool g_stdout = false;
+static bool g_verbose = false;   // -verbose: the reference's per-read transcript on stdout
+static int g_trace_iter = 64;    // threshold iterations recorded per read under -verbose
 static bool g_timing = false;  // RC_TIMING=1: phase timings on stderr (off by default: stderr is part of the contract)
 static int g_threads = 8;
 
@@ -282,6 +285,7 @@ struct Job {
     bool fastq = true;
     Arena a, b;
     std::vector<int32_t> ret, l, m, h;
+    std::vector<int32_t> tr_before, tr_after, tr_flags, tr_niter, tr_iter;  // -verbose only
     bool done = false;
     int rc = 0;
     std::string err;
@@ -380,6 +384,81 @@ static inline void put_record(std::vector<char> &out, const Arena &A, size_t r, 
     out.resize((size_t)(p - out.data()));
 }
 
+// what the reference prints to stdout for one read under -verbose (ErrorCorrection.cpp:686-689,
+// 759-770,856-857,1088-1094 and GetKmerInformation :1590-1597), from the data
+// rc_correct_batch_traced returns.  gi = the read's index in ret/l/m/h order, ab = offset of its
+// arena in the batch's device arena (0, or the size of arena 1 for second mates)
+static void put_transcript(std::vector<char> &out, const Job &J, const Arena &A, size_t r, size_t gi, size_t ab, int k)
+{
+    uint32_t il, ol;
+    const char *id = A.line(r, 0, &il);
+    const char *orig = A.line(r, 1, &ol);
+    const char *seq = A.seq.data() + A.off[r];
+    const int len = (int)(A.off[r + 1] - A.off[r] - 1);
+    const int kcnt = len >= k ? len - k + 1 : 0;
+    const size_t a0 = ab + A.off[r];
+    auto put = [&](const char *p, size_t n) { out.insert(out.end(), p, p + n); };
+    auto puts_ = [&](const char *p) { put(p, strlen(p)); };
+    auto puti = [&](int v) {
+        char tmp[16];
+        char *e = put_int(tmp, v);
+        put(tmp, (size_t)(e - tmp));
+    };
+    put(id, il);
+    puts_("\n");
+    if (J.tr_flags[gi] & 1) {
+        puts_("Before correction:\n");
+        put(orig, (size_t)len);
+        puts_("\n");
+        for (int i = 0; i < kcnt; ++i) {
+            const int c = J.tr_before[a0 + (size_t)i];
+            puti(c != 0 ? c : 1);
+            puts_(" ");
+        }
+        puts_("\n");
+        const int n_it = J.tr_niter[gi];
+        if (n_it > g_trace_iter)
+            die("rcorrector: -verbose: read %.*s went through %d threshold iterations, more than the %d recorded; raise -verbose-iter\n",
+                (int)il, id, n_it, g_trace_iter);
+        for (int it = 0; it < n_it; ++it) {
+            const int32_t *e = J.tr_iter.data() + (gi * (size_t)g_trace_iter + (size_t)it) * RC_TRACE_ITER_WORDS;
+            puts_("strong trust threshold=");
+            puti(e[0]);
+            puts_(" threshold=");
+            puti(e[1]);
+            puts_("\n");
+            if (e[2]) {
+                puts_("Is corresponding base strong trusted?\n");
+                for (int b = 0; b < len; ++b) out.push_back((char)('0' + (((uint32_t)e[4 + (b >> 5)] >> (b & 31)) & 1u)));
+                puts_("\n");
+            }
+        }
+    }
+    // GetKmerInformation: the counts of the k-mers without a non-ACGT letter, 0 shown as 1
+    int bad = 0, n_valid = 0;
+    std::vector<int> cnt;
+    for (int i = 0; i < len; ++i) {
+        const char ch = seq[i];
+        const bool ok = ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T';
+        bad = ok ? (bad > 0 ? bad - 1 : 0) : k;  // windows ending at i are invalid while bad > 0
+        if (i >= k - 1 && bad == 0) {
+            const int c = J.tr_after[a0 + (size_t)(i - k + 1)];
+            cnt.push_back(c != 0 ? c : 1);
+            ++n_valid;
+        }
+    }
+    if (n_valid > 0) {
+        puts_("After coorrection:\n");
+        put(seq, (size_t)len);
+        puts_("\n");
+        for (int c : cnt) {
+            puti(c);
+            puts_(" ");
+        }
+        puts_("\n");
+    }
+}
+
 // ---- k-mer counting pass (only without -c) ----------------------------------------------------
 // A reader thread cuts each input into blocks of whole records and packs the sequence lines into a
 // NUL-separated arena; this thread hands the arenas to the streaming counter.
@@ -465,7 +544,8 @@ static void print_help()
             "\t-gpus INT: number of GPUs to shard the reads over, k-mer table replicated (default: 1)\n"
             "\t-batch INT: reads per GPU batch (default: 1048576)\n"
             "\t-inflight INT: batches in flight per GPU (default: 2)\n"
-            "\t-write-dump STRING: also write the k-mer table as a jellyfish-dump text file\n");
+            "\t-write-dump STRING: also write the k-mer table as a jellyfish-dump text file\n"
+            "\t-verbose-iter INT: threshold iterations recorded per read for -verbose (default: 64)\n");
 }
 
 int main(int argc, char **argv)
@@ -508,6 +588,8 @@ int main(int argc, char **argv)
             g_stdout = true;
         else if (!strcmp("-verbose", argv[i]))
             verbose = true;
+        else if (!strcmp("-verbose-iter", argv[i]))
+            g_trace_iter = atoi(argv[++i]);
         else if (!strcmp("-gpus", argv[i]))
             gpus = atoi(argv[++i]);
         else if (!strcmp("-batch", argv[i]))
@@ -524,7 +606,8 @@ int main(int argc, char **argv)
             return 0;
         }
     }
-    if (verbose) die("-verbose (per-read trace) is not available on the GPU path; use the CPU reference for traces\n");
+    g_verbose = verbose;
+    if (g_trace_iter < 1) g_trace_iter = 1;
     if (gpus < 1) gpus = 1;
     if (inflight < 1) inflight = 1;
     if (inflight > 8) inflight = 8;
@@ -676,7 +759,25 @@ int main(int argc, char **argv)
                 rb.l = j->l.data();
                 rb.m = j->m.data();
                 rb.h = j->h.data();
-                int rc = rc_correct_batch(ctx[g], &rb);
+                int rc;
+                if (g_verbose) {
+                    const size_t nbytes = (size_t)j->a.off[n] + (j->mode == 1 ? (size_t)j->b.off[n] : 0);
+                    j->tr_before.assign(nbytes, 0);
+                    j->tr_after.assign(nbytes, 0);
+                    j->tr_flags.assign(total, 0);
+                    j->tr_niter.assign(total, 0);
+                    j->tr_iter.assign(total * (size_t)g_trace_iter * RC_TRACE_ITER_WORDS, 0);
+                    rc_trace tr;
+                    tr.max_iter = g_trace_iter;
+                    tr.counts_before = j->tr_before.data();
+                    tr.counts_after = j->tr_after.data();
+                    tr.flags = j->tr_flags.data();
+                    tr.n_iter = j->tr_niter.data();
+                    tr.iter = j->tr_iter.data();
+                    rc = rc_correct_batch_traced(ctx[g], &rb, &tr);
+                } else {
+                    rc = rc_correct_batch(ctx[g], &rb);
+                }
                 {
                     std::lock_guard<std::mutex> lk(mu);
                     j->rc = rc;
@@ -702,6 +803,27 @@ int main(int argc, char **argv)
             const size_t n = j->a.n();
             ReadFile &f = files[(size_t)j->file], &g2 = mates[(size_t)j->file];
             const bool alternate = j->mode == 1 && g_stdout;  // main.cpp:487-495
+            if (g_verbose) {
+                // the transcript in the order of the reference's -t 1 loop (main.cpp:368-438): per
+                // unit, mate 1's trace [and record, under -stdout], then mate 2's
+                std::vector<char> vt;
+                const size_t bytes1 = j->a.off[n];
+                auto flush = [&]() {
+                    fwrite(vt.data(), 1, vt.size(), stdout);
+                    vt.clear();
+                };
+                for (size_t r = 0; r < n; ++r) {
+                    put_transcript(vt, *j, j->a, r, r, 0, k);
+                    if (g_stdout) put_record(vt, j->a, r, j->fastq, j->ret[r], j->l[r], j->m[r], j->h[r]);
+                    if (j->mode == 1) {
+                        put_transcript(vt, *j, j->b, r, n + r, bytes1, k);
+                        if (g_stdout) put_record(vt, j->b, r, j->fastq, j->ret[n + r], j->l[n + r], j->m[n + r], j->h[n + r]);
+                    }
+                    if (vt.size() > (1u << 20)) flush();
+                }
+                flush();
+                fflush(stdout);
+            }
             // format slices in parallel, write them in order
             const size_t S = std::max<size_t>(1, std::min<size_t>((size_t)g_threads, (n + 8191) / 8192));
             std::vector<std::vector<char>> o1(S), o2(S);
@@ -739,7 +861,8 @@ int main(int argc, char **argv)
                 o1.swap(z1);
                 o2.swap(z2);
             }
-            for (size_t s = 0; s < S; ++s) emit(f, o1[s].data(), o1[s].size());
+            if (!(g_verbose && g_stdout))
+                for (size_t s = 0; s < S; ++s) emit(f, o1[s].data(), o1[s].size());
             if (j->mode == 1 && !alternate)
                 for (size_t s = 0; s < S; ++s) emit(g2, o2[s].data(), o2[s].size());
             for (size_t r = 0; r < j->ret.size(); ++r) {  // UpdateSummary, main.cpp:73-79

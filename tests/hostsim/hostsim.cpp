@@ -26,6 +26,9 @@ struct HostWave {
 
     void sync() {}
     void phase(int) {}
+    void trace_passed() {}
+    void trace_iter(int, int) {}
+    void trace_strong(const unsigned char *, int) {}
     int uni(int x) { return x; }
     uint64_t uni64(uint64_t x) { return x; }
     long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};

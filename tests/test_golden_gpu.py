@@ -26,6 +26,34 @@ def test_cli_small_batches_and_thread_flag(name, tmp_path):
     gu.assert_same_as_reference(name, tmp_path, p.stderr)
 
 
+@pytest.mark.parametrize("name", gu.FIXTURES)
+def test_cli_verbose_transcript_equals_reference(name, tmp_path):
+    """-verbose: the reference's per-read transcript (original counts, every (strong, trust)
+    iteration, the trusted-base bitmap, post-correction counts; ErrorCorrection.cpp:686-689,759-770,
+    856-857,1088-1094,1590-1597) byte for byte, and the output files unchanged by it."""
+    p = gu.run_fixture(CLI, name, tmp_path, extra=["-verbose", "-batch", "64"])
+    want = gzip.open(os.path.join(gu.GOLDEN, name, "verbose.txt.gz"), "rb").read()
+    assert p.stdout == want
+    gu.assert_same_as_reference(name, tmp_path, p.stderr)
+
+
+def test_cli_verbose_iteration_capacity_is_checked(tmp_path):
+    # one read of fx_pe_k23 lowers its thresholds once (2 iterations): a capacity of 1 must fail
+    # loudly rather than print a truncated transcript, 2 is enough
+    import subprocess
+    d = os.path.join(gu.GOLDEN, "fx_pe_k23")
+    args = open(os.path.join(d, "cmd.txt")).read().split()
+    want = gzip.open(os.path.join(d, "verbose.txt.gz"), "rb").read()
+    assert want.count(b"strong trust threshold=") == want.count(b"Before correction:") + 1
+    for cap, ok in ((1, False), (2, True)):
+        p = subprocess.run([CLI] + args + ["-od", str(tmp_path), "-verbose", "-verbose-iter", str(cap)], cwd=d,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        if ok:
+            assert p.returncode == 0 and p.stdout == want
+        else:
+            assert p.returncode != 0 and b"-verbose-iter" in p.stderr
+
+
 def test_cli_stdout_pairs_alternate(tmp_path):
     p = gu.run_fixture(CLI, "fx_pe_k23", tmp_path, extra=["-stdout"])
     ref = os.path.join(gu.GOLDEN, "fx_pe_k23", "ref")

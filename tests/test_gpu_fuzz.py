@@ -86,13 +86,15 @@ def test_cli_equals_oracle_cli_on_random_inputs(oracle, seed, tmp_path):
     d = str(tmp_path)
     args = _random_case(seed, d)
     outs = {}
+    verbose = ["-verbose"] if seed % 3 == 0 else []   # every third case also compares the -verbose transcript
     for name, binary, more in (("gpu", CLI, ["-batch", "64"] if seed % 2 else []), ("cpu", oracle.CLI_BIN, ["-t", "2"])):
         od = os.path.join(d, name)
         os.makedirs(od)
-        p = subprocess.run([binary] + args + ["-od", od] + more, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        p = subprocess.run([binary] + args + ["-od", od] + more + verbose, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         assert p.returncode == 0, p.stderr.decode()
-        outs[name] = (p.stderr, {f: open(os.path.join(od, f), "rb").read() for f in sorted(os.listdir(od))})
+        outs[name] = (p.stderr, {f: open(os.path.join(od, f), "rb").read() for f in sorted(os.listdir(od))}, p.stdout)
     assert outs["gpu"][1].keys() == outs["cpu"][1].keys() and outs["gpu"][1]
     for f in outs["cpu"][1]:
         assert outs["gpu"][1][f] == outs["cpu"][1][f], "%s differs (seed %d, args %s)" % (f, seed, args)
     assert outs["gpu"][0] == outs["cpu"][0], "stderr differs (seed %d)" % seed
+    assert outs["gpu"][2] == outs["cpu"][2], "-verbose transcript differs (seed %d)" % seed
