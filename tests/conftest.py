@@ -24,6 +24,13 @@ def oracle():
 
 
 @pytest.fixture(scope="session")
+def oracle_cli(oracle):
+    """The oracle's command-line front end (mimics main.cpp); pinned to the reference by test_golden_cpu."""
+    assert os.path.exists(oracle.CLI_BIN)
+    return oracle.CLI_BIN
+
+
+@pytest.fixture(scope="session")
 def hostsim(oracle):
     """Lane-serial build of the kernel control flow (tests/hostsim)."""
     import ctypes as C

@@ -108,3 +108,62 @@ def run_oracle(po, d, threads=4, fn=None):
         return res + (a, a2)
     res = po.correct_batch(P, T, d["mode"], a, qa, off, threads=threads, fn=fn)
     return res + (a,)
+
+
+def mason_style_reads(seed=11, n=300, length=100, n_tx=6, l_tx=500, e=0.02):
+    """Simulated reads whose headers carry the truth the way the Mason simulator writes it and the
+    reference's scorer parses it (verify.cpp:193-232,290-298): haplotype_infix= the true bases on
+    the forward strand, edit_string= one letter per read base (M correct, E substituted),
+    strand=forward|reverse, exp=high|medium|low|<other>, and for some reads trim=<n>.
+    Returns (headers, reads, quals) as lists of bytes; the reads are what a sequencer would give
+    (errors included).  Every transcript is covered deeply enough for the corrector to fix most
+    substitutions."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    tx = synth.NUC[rng.integers(0, 4, size=(n_tx, l_tx), dtype=np.uint8)]
+    heads, reads, quals = [], [], []
+    for i in range(n):
+        t = int(rng.integers(0, n_tx))
+        st = int(rng.integers(0, l_tx - length + 1))
+        fwd = tx[t, st:st + length].copy()
+        rev = bool(rng.integers(0, 2))
+        true_read = synth.COMP[fwd[::-1]] if rev else fwd
+        m = rng.random(length) < e
+        obs = true_read.copy()
+        shift = rng.integers(1, 4, size=length, dtype=np.uint8)
+        obs[m] = synth.NUC[(synth.CODE[true_read[m]] + shift[m]) & 3]
+        edit = np.where(m, ord('E'), ord('M')).astype(np.uint8)
+        q = np.where(m, ord('#'), ord('I')).astype(np.uint8)
+        exp = [b"high", b"medium", b"low", b"none"][int(rng.integers(0, 4))]
+        h = b"@sim.%09d contig=tx%d haplotype=0 length=%d orig_begin=%d strand=%s exp=%s haplotype_infix=%s edit_string=%s" % (
+            i, t, length, st, b"reverse" if rev else b"forward", exp, fwd.tobytes(), edit.tobytes())
+        if i % 17 == 0:
+            h += b" trim=%d" % (i % 5)
+        heads.append(h)
+        reads.append(obs.tobytes())
+        quals.append(q.tobytes())
+    return heads, reads, quals
+
+
+def write_mason_fastq(path, heads, reads, quals):
+    with open(path, "wb") as f:
+        for h, r, q in zip(heads, reads, quals):
+            f.write(h + b"\n" + r + b"\n+\n" + q + b"\n")
+
+
+def mason_indel_variants(heads, reads, quals):
+    """The same reads as a trimming / indel-making corrector could return them: some cut short
+    at the 3' end, some with a base dropped or inserted in the middle -- exercises the scorer's
+    unequal-length alignment (verify.cpp:58-129) and its -noindel switch."""
+    out_r, out_q = [], []
+    for i, (r, q) in enumerate(zip(reads, quals)):
+        if i % 5 == 1:
+            r, q = r[:-3], q[:-3]
+        elif i % 5 == 2:
+            p = 20 + i % 50
+            r, q = r[:p] + r[p + 1:], q[:p] + q[p + 1:]
+        elif i % 5 == 3:
+            p = 10 + i % 60
+            r, q = r[:p] + b"G" + r[p:], q[:p] + b"I" + q[p:]
+        out_r.append(r)
+        out_q.append(q)
+    return heads, out_r, out_q
