@@ -207,3 +207,17 @@ def test_cli_without_c_equals_cpu_given_the_written_dump(oracle, paired, tmp_pat
         for f in out_c:
             assert out_g[f] == out_c[f], "%s differs from %s" % (f, binary)
         assert err_g == err_c
+
+
+def test_simulated_reads_end_to_end_with_accuracy_score(tmp_path):
+    """Whole pipeline on simulated reads with truth headers: count on the GPU, correct, score with
+    `verify` -- the corrected file and the scorer's report must equal what the reference binaries
+    produced for the same reads (tests/golden/verify/)."""
+    g = os.path.join(gu.GOLDEN, "verify")
+    p = subprocess.run([CLI, "-r", os.path.join(g, "raw.fq"), "-k", "23", "-od", str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr.decode()
+    got = open(tmp_path / "raw.cor.fq", "rb").read()
+    assert got == open(os.path.join(g, "cor.fq"), "rb").read()
+    subprocess.run(["make", "-C", os.path.join(gu.ROOT, "rcorrector_amd", "csrc"), "../verify"], check=True, stdout=subprocess.DEVNULL)
+    out = subprocess.run([os.path.join(gu.ROOT, "rcorrector_amd", "verify"), str(tmp_path / "raw.cor.fq")], stdout=subprocess.PIPE, check=True).stdout
+    assert out == open(os.path.join(g, "cor.plain.txt"), "rb").read()
