@@ -353,6 +353,11 @@ __device__ __forceinline__ void rc_load_read(W &w, const rc_kernel_args &A, rc_r
     rc_build_masks(w, S);
 }
 
+// Software-pipelined over the reads of a wave: the kernel has no table probes, so a read costs two
+// dependent HBM round trips (its offsets, then its bases and counts) against a few hundred
+// instructions of work -- the offsets are fetched two reads ahead and the bases / counts one read
+// ahead, into registers, while the current read is processed out of LDS.
+#define RC_K2_PF 4  // 64-base chunks prefetched per read (longer reads load their tail directly)
 __global__ __launch_bounds__(64) void k_threshold(rc_kernel_args A)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -364,15 +369,68 @@ __global__ __launch_bounds__(64) void k_threshold(rc_kernel_args A)
     w.T = A.T;
     w.k = A.P.k;
     w.stack = nullptr;
-    for (uint32_t r = blockIdx.x; r < A.n; r += gridDim.x) {
-        rc_load_read(w, A, S, r, w.lane, false);
+    const int lane = w.lane, k = A.P.k;
+    const uint32_t G = gridDim.x;
+    uint32_t r = blockIdx.x;
+    if (r >= A.n) return;
+    uint32_t o_cur = A.off[r], e_cur = A.off[r + 1];
+    uint32_t o_nxt = 0, e_nxt = 0;
+    if (r + G < A.n) {
+        o_nxt = A.off[r + G];
+        e_nxt = A.off[r + G + 1];
+    }
+    uint8_t pb[RC_K2_PF];
+    int32_t pc[RC_K2_PF];
+    auto fetch = [&](uint32_t o, uint32_t e) {
+        const int len = (int)(e - o) - 1, kcnt = len >= k ? len - k + 1 : 0;
+#pragma unroll
+        for (int c = 0; c < RC_K2_PF; ++c) {
+            const int i = c * 64 + lane;
+            pb[c] = i < len ? A.seq[o + i] : (uint8_t)0;
+            pc[c] = i < kcnt ? A.counts[o + i] : 0;
+        }
+    };
+    fetch(o_cur, e_cur);
+    for (;;) {
+        const uint32_t o = o_cur;
+        const int len = (int)(e_cur - o) - 1;
+        S.len = len;
+        S.kcnt = len >= k ? len - k + 1 : 0;
+#pragma unroll
+        for (int c = 0; c < RC_K2_PF; ++c) {
+            const int i = c * 64 + lane;
+            if (i < len) {
+                S.base[i] = (unsigned char)rc_base_code(pb[c]);
+                S.counts[i] = pc[c];
+            }
+        }
+        for (int i = RC_K2_PF * 64 + lane; i < len; i += 64) {
+            S.base[i] = (unsigned char)rc_base_code(A.seq[o + i]);
+            S.counts[i] = i < S.kcnt ? A.counts[o + i] : 0;
+        }
+        // next read's data and the offsets of the one after it go out now
+        const uint32_t rn = r + G;
+        const bool more = rn < A.n;
+        if (more) {
+            o_cur = o_nxt;
+            e_cur = e_nxt;
+            fetch(o_cur, e_cur);
+            if (rn + G < A.n) {
+                o_nxt = A.off[rn + G];
+                e_nxt = A.off[rn + G + 1];
+            }
+        }
+        w.sync();
+        rc_build_masks(w, S);
         int info;
         const int strong = rc_front_end(w, S, A.P, &info);
-        if (w.lane == 0) {
+        if (lane == 0) {
             A.strong[r] = strong;
             A.info[r] = info;
         }
         w.sync();
+        if (!more) break;
+        r = rn;
     }
 }
 
