@@ -19,6 +19,7 @@
 // -verbose prints the reference's per-read transcript (the -t 1 order) from rc_correct_batch_traced;
 // -write-dump FILE keeps the k-mer table as jellyfish-dump text; without -c the k-mers are counted here.
 #include <fcntl.h>
+#include <malloc.h>
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -50,6 +51,9 @@ static int g_trace_iter = 64;    // threshold iterations recorded per read under
 static bool g_timing = false;  // RC_TIMING=1: phase timings on stderr (off by default: stderr is part of the contract)
 static int g_threads = 8;
 
+static double g_w_reader = 0, g_w_writer = 0, g_w_worker = 0;  // RC_TIMING: time blocked on the neighbouring stage
+static double g_t_read = 0, g_t_pack = 0, g_t_gpu = 0, g_t_format = 0, g_t_write = 0;  // RC_TIMING stage totals (thread-seconds)
+
 static double now_s()
 {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -77,14 +81,44 @@ static void parallel_for(size_t n, F fn)
     for (auto &x : th) x.join();
 }
 
+// growable byte buffer without value-initialisation (a std::vector<char> zero-fills on resize,
+// which at GB/s rates is a pass over memory of its own); contents survive growth
+struct Buf {
+    char *p = nullptr;
+    size_t cap = 0;
+    Buf() = default;
+    Buf(const Buf &) = delete;
+    Buf &operator=(const Buf &) = delete;
+    Buf(Buf &&o) noexcept : p(o.p), cap(o.cap)
+    {
+        o.p = nullptr;
+        o.cap = 0;
+    }
+    ~Buf() { free(p); }
+    char *data() { return p; }
+    const char *data() const { return p; }
+    void need(size_t n)
+    {
+        if (n <= cap) return;
+        const size_t nc = std::max(n, cap + cap / 2);
+        p = (char *)realloc(p, nc);
+        if (!p) {
+            fprintf(stderr, "rcorrector: out of memory (%zu bytes)\n", nc);
+            exit(1);
+        }
+        cap = nc;
+    }
+};
+
 // ---- input: a stream of bytes cut into blocks of whole records --------------------------------
 struct Source {
     std::string path;
-    bool is_gz = false;
+    bool is_gz = false, seekable = false;
     int fd = -1;
     gzFile gz = nullptr;
-    std::vector<char> buf;  // unconsumed bytes [0, have)
-    size_t have = 0;
+    Buf left;  // bytes read from the file but not handed out yet (the tail behind the last block)
+    size_t left_len = 0;
+    off_t pos = 0;  // file offset of the next unread byte (seekable files)
     bool eof = false;
 
     void open(const std::string &p)
@@ -99,8 +133,11 @@ struct Source {
         } else {
             fd = ::open(p.c_str(), O_RDONLY);
             if (fd < 0) die("ERROR: Could not access file %s\n", p.c_str());
+            struct stat st;
+            seekable = fstat(fd, &st) == 0 && S_ISREG(st.st_mode);
         }
-        have = 0;
+        left_len = 0;
+        pos = 0;
         eof = false;
     }
     void close()
@@ -110,75 +147,177 @@ struct Source {
         gz = nullptr;
         fd = -1;
     }
-    void refill()
+    // appends up to `want` bytes of the file at dst; sets eof when the file ends first.  Regular
+    // files are read by several threads at once (pread into disjoint slices: the copy out of the
+    // page cache is what limits a single reader), streams and .gz by this thread alone.
+    size_t fill(char *dst, size_t want)
     {
-        const size_t CH = 32u << 20;
-        if (buf.size() < have + CH + 8) buf.resize(have + CH + 8);
-        long n = is_gz ? gzread(gz, buf.data() + have, (unsigned)CH) : (long)::read(fd, buf.data() + have, CH);
-        if (n <= 0)
-            eof = true;
-        else
-            have += (size_t)n;
+        size_t got = 0;
+        if (is_gz) {
+            while (got < want) {
+                const unsigned ch = (unsigned)std::min<size_t>(want - got, (size_t)1 << 30);
+                const int n = gzread(gz, dst + got, ch);
+                if (n <= 0) {
+                    eof = true;
+                    break;
+                }
+                got += (size_t)n;
+            }
+            return got;
+        }
+        if (!seekable) {
+            while (got < want) {
+                const ssize_t n = ::read(fd, dst + got, want - got);
+                if (n <= 0) {
+                    eof = true;
+                    break;
+                }
+                got += (size_t)n;
+            }
+            return got;
+        }
+        const size_t SL = (size_t)8 << 20;
+        const size_t T = std::max<size_t>(1, std::min<size_t>((size_t)g_threads, (want + SL - 1) / SL));
+        std::vector<size_t> done(T, 0);
+        auto rd = [&](size_t t) {
+            const size_t lo = want * t / T, hi = want * (t + 1) / T;
+            size_t at = lo;
+            while (at < hi) {
+                const ssize_t n = ::pread(fd, dst + at, hi - at, pos + (off_t)at);
+                if (n <= 0) break;
+                at += (size_t)n;
+            }
+            done[t] = at - lo;
+        };
+        if (T == 1) {
+            rd(0);
+        } else {
+            std::vector<std::thread> th;
+            for (size_t t = 0; t < T; ++t) th.emplace_back(rd, t);
+            for (auto &x : th) x.join();
+        }
+        for (size_t t = 0; t < T; ++t) {
+            got += done[t];
+            if (done[t] < want * (t + 1) / T - want * t / T) {  // the file ended inside this slice
+                eof = true;
+                break;
+            }
+        }
+        pos += (off_t)got;
+        return got;
     }
 };
 
 // a batch of raw records: the text plus the start of every line (lines_per_record per record)
 struct Block {
-    std::vector<char> text;
+    Buf text;
     std::vector<uint32_t> line;  // line i = text[line[i] .. line[i+1]-1), without its '\n'
     size_t records = 0;
 };
 
-// up to max_records whole records from the source (fewer only at end of file)
+// positions of the '\n' bytes of p[lo, hi), appended to nl in ascending order
+static void find_newlines(const char *p, size_t lo, size_t hi, std::vector<uint32_t> &nl)
+{
+    const size_t T = std::max<size_t>(1, std::min<size_t>((size_t)g_threads, (hi - lo) >> 22));
+    if (T == 1) {
+        for (size_t at = lo; at < hi;) {
+            const char *q = (const char *)memchr(p + at, '\n', hi - at);
+            if (!q) break;
+            nl.push_back((uint32_t)(q - p));
+            at = (size_t)(q - p) + 1;
+        }
+        return;
+    }
+    std::vector<std::vector<uint32_t>> part(T);
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < T; ++t)
+        th.emplace_back([&, t]() {
+            const size_t a = lo + (hi - lo) * t / T, b = lo + (hi - lo) * (t + 1) / T;
+            part[t].reserve((b - a) / 32 + 16);
+            for (size_t at = a; at < b;) {
+                const char *q = (const char *)memchr(p + at, '\n', b - at);
+                if (!q) break;
+                part[t].push_back((uint32_t)(q - p));
+                at = (size_t)(q - p) + 1;
+            }
+        });
+    for (auto &x : th) x.join();
+    size_t total = nl.size();
+    for (auto &v : part) total += v.size();
+    nl.reserve(total);
+    for (auto &v : part) nl.insert(nl.end(), v.begin(), v.end());
+}
+
+// up to max_records whole records from the source (fewer only at end of file), read straight into
+// the block's own buffer
 static void take_records(Source &s, size_t max_records, int lines_per_record, Block &b)
 {
-    b.text.clear();
     b.line.clear();
     b.records = 0;
     const size_t want_lines = max_records * (size_t)lines_per_record;
-    size_t end = 0;  // one past the '\n' of the last indexed line
-    std::vector<uint32_t> starts;
-    starts.reserve(std::min<size_t>(want_lines, (size_t)1 << 22) + 8);
+    std::vector<uint32_t> nl;  // newline positions found so far
+    nl.reserve(std::min<size_t>(want_lines, (size_t)1 << 23) + 8);
+    size_t have = s.left_len, scanned = 0;
+    b.text.need(have + 64);
+    if (have) memcpy(b.text.p, s.left.p, have);
+    s.left_len = 0;
     for (;;) {
-        while (starts.size() < want_lines && end < s.have) {
-            const char *nl = (const char *)memchr(s.buf.data() + end, '\n', s.have - end);
-            if (!nl) break;
-            starts.push_back((uint32_t)end);
-            end = (size_t)(nl - s.buf.data()) + 1;
+        find_newlines(b.text.p, scanned, have, nl);
+        scanned = have;
+        if (nl.size() >= want_lines) break;
+        if (s.eof) break;
+        if (have >= (1ull << 31)) die("ERROR: %s: a batch exceeds 2 GiB of text; lower -batch\n", s.path.c_str());
+        size_t want = (size_t)32 << 20;
+        if (nl.size() >= 64) {  // bytes per line so far -> what the missing lines should need, plus 2 %
+            const double per_line = (double)have / (double)nl.size();
+            want = (size_t)(per_line * (double)(want_lines - nl.size()) * 1.02) + (1u << 16);
         }
-        if (starts.size() >= want_lines) break;
-        if (s.eof) {
-            if (end < s.have) {  // last line without '\n' (fgets hands it over as it is): add the newline
-                if (s.buf.size() < s.have + 1) s.buf.resize(s.have + 1);
-                s.buf[s.have++] = '\n';
-                continue;
-            }
-            break;
+        want = std::min<size_t>(want, ((size_t)1 << 31) - have + 1);
+        b.text.need(have + want + 64);
+        have += s.fill(b.text.p + have, want);
+    }
+    size_t n_lines = std::min(nl.size(), want_lines), end;
+    if (nl.size() >= want_lines) {
+        end = (size_t)nl[want_lines - 1] + 1;
+    } else {  // end of file
+        end = nl.empty() ? 0 : (size_t)nl.back() + 1;
+        if (end < have) {  // last line without '\n' (fgets hands it over as it is): add the newline
+            b.text.p[have] = '\n';
+            nl.push_back((uint32_t)have);
+            ++have;
+            end = have;
+            ++n_lines;
         }
-        if (s.have >= (1ull << 31)) die("ERROR: %s: a batch exceeds 2 GiB of text; lower -batch\n", s.path.c_str());
-        s.refill();
+        // a record cut short by the end of the file: its missing lines read as empty (fgets leaves "")
+        while (n_lines % (size_t)lines_per_record) {
+            b.text.need(have + 64);
+            b.text.p[have] = '\n';
+            nl.push_back((uint32_t)have);
+            ++have;
+            end = have;
+            ++n_lines;
+        }
     }
-    // a record cut short by the end of the file: its missing lines read as empty (fgets leaves "")
-    while (starts.size() % (size_t)lines_per_record) {
-        if (s.buf.size() < s.have + 1) s.buf.resize(s.have + 1);
-        s.buf[s.have++] = '\n';
-        starts.push_back((uint32_t)end);
-        end += 1;
+    b.records = n_lines / (size_t)lines_per_record;
+    if (have > end) {  // the tail behind the block waits in the source for the next call
+        s.left.need(have - end);
+        memcpy(s.left.p, b.text.p + end, have - end);
     }
-    b.records = starts.size() / (size_t)lines_per_record;
+    s.left_len = have - end;
     if (b.records == 0) return;
-    b.text.assign(s.buf.data(), s.buf.data() + end);
-    starts.push_back((uint32_t)end);
-    b.line.swap(starts);
-    memmove(s.buf.data(), s.buf.data() + end, s.have - end);
-    s.have -= end;
+    b.line.resize(n_lines + 1);
+    b.line[0] = 0;
+    parallel_for(n_lines, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) b.line[i + 1] = nl[i] + 1;
+    });
 }
 
 struct ReadFile {
     std::string path;
     bool paired = false, interleaved = false, fastq = true, out_gz = false;
     Source src;
-    FILE *out = nullptr;
+    FILE *out = nullptr;  // only its descriptor is used, with pwrite (stdout: fwrite)
+    off_t out_off = 0;
     bool wrote = false;
 };
 
@@ -210,14 +349,15 @@ static void open_file(ReadFile &f, const char *path, bool paired, bool interleav
     f.paired = paired;
     f.interleaved = interleaved;
     f.src.open(path);
-    f.src.refill();
-    const char first = f.src.have ? f.src.buf[0] : 0;
+    f.src.left.need(4096);  // peek at the head of the file; the bytes stay queued for the first block
+    f.src.left_len = f.src.fill(f.src.left.p, 4096);
+    const char first = f.src.left_len ? f.src.left.p[0] : 0;
     if (first == '>')
         f.fastq = false;
     else if (first == '@')
         f.fastq = true;
     else {
-        std::string l(f.src.buf.data(), std::min<size_t>(f.src.have, 200));
+        std::string l(f.src.left.p, std::min<size_t>(f.src.left_len, 200));
         const size_t nl = l.find('\n');
         if (nl != std::string::npos) l = l.substr(0, nl + 1);
         die("\"%s\"'s format is wrong: %s\n", path, l.c_str());
@@ -240,11 +380,42 @@ static void open_file(ReadFile &f, const char *path, bool paired, bool interleav
     }
 }
 
-static void emit(ReadFile &f, const char *s, size_t n)
+// the slices of a batch, in order: stdout through stdio, files by one pwrite per slice from
+// several threads (the copy into the page cache is what bounds a single writer)
+static void emit_slices(ReadFile &f, const std::vector<std::vector<char>> &sl)
 {
-    if (n) {
-        fwrite(s, 1, n, f.out);
-        f.wrote = true;
+    size_t total = 0;
+    for (const auto &v : sl) total += v.size();
+    if (total == 0) return;
+    f.wrote = true;
+    if (f.out == stdout) {
+        for (const auto &v : sl)
+            if (!v.empty()) fwrite(v.data(), 1, v.size(), stdout);
+        return;
+    }
+    const int fd = fileno(f.out);
+    std::vector<off_t> at(sl.size());
+    off_t o = f.out_off;
+    for (size_t i = 0; i < sl.size(); ++i) {
+        at[i] = o;
+        o += (off_t)sl[i].size();
+    }
+    f.out_off = o;
+    auto wr = [&](size_t i) {
+        size_t done = 0;
+        while (done < sl[i].size()) {
+            const ssize_t n = ::pwrite(fd, sl[i].data() + done, sl[i].size() - done, at[i] + (off_t)done);
+            if (n <= 0) die("ERROR: write failed on %s\n", f.path.c_str());
+            done += (size_t)n;
+        }
+    };
+    if (sl.size() == 1 || total < ((size_t)4 << 20)) {
+        for (size_t i = 0; i < sl.size(); ++i) wr(i);
+    } else {
+        std::vector<std::thread> th;
+        for (size_t i = 0; i < sl.size(); ++i)
+            if (!sl[i].empty()) th.emplace_back(wr, i);
+        for (auto &x : th) x.join();
     }
 }
 
@@ -268,7 +439,7 @@ static void gzip_member(const std::vector<char> &in, std::vector<char> &out)
 struct Arena {  // one file's share of a batch
     Block blk;
     int lpr = 4;  // lines per record
-    std::vector<char> seq, qual;
+    Buf seq, qual;
     std::vector<uint32_t> off;
     size_t n() const { return blk.records; }
     const char *line(size_t rec, int which, uint32_t *len) const
@@ -286,6 +457,7 @@ struct Job {
     Arena a, b;
     std::vector<int32_t> ret, l, m, h;
     std::vector<int32_t> tr_before, tr_after, tr_flags, tr_niter, tr_iter;  // -verbose only
+    std::vector<std::vector<char>> o1, o2;  // the formatted (and, for .gz, deflated) output records, in slices
     bool done = false;
     int rc = 0;
     std::string err;
@@ -310,8 +482,8 @@ static void pack_arena(Arena &A, const std::string &path)
         A.off[r + 1] = (uint32_t)total;
     }
     if (total >= (1ull << 32)) die("ERROR: batch too large; lower -batch\n");
-    A.seq.resize(total);
-    A.qual.assign(total, 0);
+    A.seq.need(total);
+    A.qual.need(total);
     parallel_for(n, [&](size_t lo, size_t hi) {
         for (size_t r = lo; r < hi; ++r) {
             uint32_t sl, ql = 0;
@@ -319,10 +491,14 @@ static void pack_arena(Arena &A, const std::string &path)
             char *d = A.seq.data() + A.off[r];
             memcpy(d, s, sl);
             d[sl] = 0;
+            char *dq = A.qual.data() + A.off[r];
+            uint32_t qc = 0;
             if (A.lpr == 4) {
                 const char *q = A.line(r, 3, &ql);
-                memcpy(A.qual.data() + A.off[r], q, std::min(ql, sl));
+                qc = std::min(ql, sl);
+                memcpy(dq, q, qc);
             }
+            memset(dq + qc, 0, sl + 1 - qc);
         }
     });
 }
@@ -619,6 +795,11 @@ int main(int argc, char **argv)
         if (g_threads < 1) g_threads = 1;
     }
     g_timing = getenv("RC_TIMING") != nullptr;
+    // batches recycle buffers of hundreds of MB: keep freed memory in the heap instead of handing it
+    // back to the kernel and faulting it in again page by page (with dozens of threads every
+    // mmap/munmap/page fault also serialises on the process's memory-map lock)
+    mallopt(M_MMAP_THRESHOLD, 1 << 30);
+    mallopt(M_TRIM_THRESHOLD, -1);
 
     std::vector<ReadFile> files(0), mates(0);
     files.reserve(MAX_READ_FILE);
@@ -721,9 +902,59 @@ int main(int argc, char **argv)
     std::mutex mu;
     std::condition_variable cv;
     std::deque<std::shared_ptr<Job>> order;  // submission order, for the writer
+    std::vector<std::shared_ptr<Job>> pool;  // finished jobs: their buffers are reused (no fresh page faults)
     std::vector<std::deque<std::shared_ptr<Job>>> q((size_t)nctx);
     bool closing = false, reader_done = false;
     const size_t max_in_flight = (size_t)(nctx + 2);
+
+    // the output records of a finished batch, formatted (and deflated for .gz outputs) in slices by
+    // the worker that ran it; the writer thread only writes
+    auto format_job = [&](Job &J) {
+        const Job *j = &J;
+        const size_t n = j->a.n();
+        ReadFile &f = files[(size_t)j->file];
+        const bool alternate = j->mode == 1 && g_stdout;  // main.cpp:487-495
+        const size_t S = std::max<size_t>(1, std::min<size_t>((size_t)g_threads, (n + 8191) / 8192));
+        std::vector<std::vector<char>> &o1 = J.o1, &o2 = J.o2;
+        o1.resize(S);
+        o2.resize(S);
+        for (auto &v : o1) v.clear();
+        for (auto &v : o2) v.clear();
+        auto fmt = [&](size_t lo, size_t hi) {
+            for (size_t s = lo; s < hi; ++s) {
+                const size_t r0 = n * s / S, r1 = n * (s + 1) / S;
+                o1[s].reserve((r1 - r0) * 300);
+                for (size_t r = r0; r < r1; ++r) {
+                    put_record(o1[s], j->a, r, j->fastq, j->ret[r], j->l[r], j->m[r], j->h[r]);
+                    if (alternate) put_record(o1[s], j->b, r, j->fastq, j->ret[n + r], j->l[n + r], j->m[n + r], j->h[n + r]);
+                }
+                if (j->mode == 1 && !alternate) {
+                    o2[s].reserve((r1 - r0) * 300);
+                    for (size_t r = r0; r < r1; ++r)
+                        put_record(o2[s], j->b, r, j->fastq, j->ret[n + r], j->l[n + r], j->m[n + r], j->h[n + r]);
+                }
+            }
+        };
+        if (S == 1) {
+            fmt(0, 1);
+        } else {
+            std::vector<std::thread> th;
+            for (size_t s = 0; s < S; ++s) th.emplace_back([&, s]() { fmt(s, s + 1); });
+            for (auto &x : th) x.join();
+        }
+        if (f.out_gz && !g_stdout) {  // deflate every slice into its own gzip member, in parallel
+            std::vector<std::vector<char>> z1(S), z2(S);
+            std::vector<std::thread> th;
+            for (size_t s = 0; s < S; ++s)
+                th.emplace_back([&, s]() {
+                    if (!o1[s].empty()) gzip_member(o1[s], z1[s]);
+                    if (!o2[s].empty()) gzip_member(o2[s], z2[s]);
+                });
+            for (auto &x : th) x.join();
+            o1.swap(z1);
+            o2.swap(z2);
+        }
+    };
 
     std::vector<std::thread> workers;
     for (int g = 0; g < nctx; ++g) {
@@ -732,11 +963,17 @@ int main(int argc, char **argv)
                 std::shared_ptr<Job> j;
                 {
                     std::unique_lock<std::mutex> lk(mu);
+                    const double tw = now_s();
                     cv.wait(lk, [&] { return closing || !q[g].empty(); });
+                    g_w_worker += now_s() - tw;
                     if (q[g].empty()) return;
                     j = q[g].front();
                     q[g].pop_front();
                 }
+                const double tp0 = now_s();
+                pack_arena(j->a, files[(size_t)j->file].path);
+                if (j->mode == 1) pack_arena(j->b, mates[(size_t)j->file].path);
+                const double tp1 = now_s();
                 const size_t n = j->a.n();
                 const size_t total = j->mode == 1 ? 2 * n : n;
                 j->ret.assign(total, 0);
@@ -760,6 +997,7 @@ int main(int argc, char **argv)
                 rb.m = j->m.data();
                 rb.h = j->h.data();
                 int rc;
+                const double tg0 = now_s();
                 if (g_verbose) {
                     const size_t nbytes = (size_t)j->a.off[n] + (j->mode == 1 ? (size_t)j->b.off[n] : 0);
                     j->tr_before.assign(nbytes, 0);
@@ -778,8 +1016,14 @@ int main(int argc, char **argv)
                 } else {
                     rc = rc_correct_batch(ctx[g], &rb);
                 }
+                const double tf0 = now_s();
+                if (!rc) format_job(*j);
+                const double tf1 = now_s();
                 {
                     std::lock_guard<std::mutex> lk(mu);
+                    g_t_gpu += tf0 - tg0;
+                    g_t_format += tf1 - tf0;
+                    g_t_pack += tp1 - tp0;
                     j->rc = rc;
                     if (rc) j->err = rc_last_error(ctx[g]);
                     j->done = true;
@@ -795,7 +1039,9 @@ int main(int argc, char **argv)
             std::shared_ptr<Job> j;
             {
                 std::unique_lock<std::mutex> lk(mu);
+                const double tw = now_s();
                 cv.wait(lk, [&] { return (!order.empty() && order.front()->done) || (reader_done && order.empty()); });
+                g_w_writer += now_s() - tw;
                 if (order.empty()) return;
                 j = order.front();
             }
@@ -824,47 +1070,10 @@ int main(int argc, char **argv)
                 flush();
                 fflush(stdout);
             }
-            // format slices in parallel, write them in order
-            const size_t S = std::max<size_t>(1, std::min<size_t>((size_t)g_threads, (n + 8191) / 8192));
-            std::vector<std::vector<char>> o1(S), o2(S);
-            auto fmt = [&](size_t lo, size_t hi) {
-                for (size_t s = lo; s < hi; ++s) {
-                    const size_t r0 = n * s / S, r1 = n * (s + 1) / S;
-                    o1[s].reserve((r1 - r0) * 300);
-                    for (size_t r = r0; r < r1; ++r) {
-                        put_record(o1[s], j->a, r, j->fastq, j->ret[r], j->l[r], j->m[r], j->h[r]);
-                        if (alternate) put_record(o1[s], j->b, r, j->fastq, j->ret[n + r], j->l[n + r], j->m[n + r], j->h[n + r]);
-                    }
-                    if (j->mode == 1 && !alternate) {
-                        o2[s].reserve((r1 - r0) * 300);
-                        for (size_t r = r0; r < r1; ++r)
-                            put_record(o2[s], j->b, r, j->fastq, j->ret[n + r], j->l[n + r], j->m[n + r], j->h[n + r]);
-                    }
-                }
-            };
-            if (S == 1) {
-                fmt(0, 1);
-            } else {
-                std::vector<std::thread> th;
-                for (size_t s = 0; s < S; ++s) th.emplace_back([&, s]() { fmt(s, s + 1); });
-                for (auto &x : th) x.join();
-            }
-            if (f.out_gz && !g_stdout) {  // deflate every slice into its own gzip member, in parallel
-                std::vector<std::vector<char>> z1(S), z2(S);
-                std::vector<std::thread> th;
-                for (size_t s = 0; s < S; ++s)
-                    th.emplace_back([&, s]() {
-                        if (!o1[s].empty()) gzip_member(o1[s], z1[s]);
-                        if (!o2[s].empty()) gzip_member(o2[s], z2[s]);
-                    });
-                for (auto &x : th) x.join();
-                o1.swap(z1);
-                o2.swap(z2);
-            }
-            if (!(g_verbose && g_stdout))
-                for (size_t s = 0; s < S; ++s) emit(f, o1[s].data(), o1[s].size());
-            if (j->mode == 1 && !alternate)
-                for (size_t s = 0; s < S; ++s) emit(g2, o2[s].data(), o2[s].size());
+            const double tw0 = now_s();
+            if (!(g_verbose && g_stdout)) emit_slices(f, j->o1);
+            if (j->mode == 1 && !alternate) emit_slices(g2, j->o2);
+            g_t_write += now_s() - tw0;
             for (size_t r = 0; r < j->ret.size(); ++r) {  // UpdateSummary, main.cpp:73-79
                 ++total_reads;
                 if (j->ret[r] > 0) total_cor += (uint64_t)j->ret[r];
@@ -872,6 +1081,9 @@ int main(int argc, char **argv)
             {
                 std::lock_guard<std::mutex> lk(mu);
                 order.pop_front();
+                j->done = false;
+                j->rc = 0;
+                pool.push_back(j);
             }
             cv.notify_all();
         }
@@ -884,12 +1096,21 @@ int main(int argc, char **argv)
             ReadFile &f = files[fi];
             const int lpr = f.fastq ? 4 : 2;
             for (;;) {
-                auto j = std::make_shared<Job>();
+                std::shared_ptr<Job> j;
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    if (!pool.empty()) {
+                        j = pool.back();
+                        pool.pop_back();
+                    }
+                }
+                if (!j) j = std::make_shared<Job>();
                 j->file = (int)fi;
                 j->mode = f.paired ? 1 : (f.interleaved ? 2 : 0);
                 j->fastq = f.fastq;
                 j->a.lpr = lpr;
                 j->b.lpr = f.paired ? (mates[fi].fastq ? 4 : 2) : lpr;
+                const double tr0 = now_s();
                 take_records(f.src, batch_reads, lpr, j->a.blk);
                 if (f.paired) {
                     take_records(mates[fi].src, j->a.blk.records ? j->a.blk.records : 1, j->b.lpr, j->b.blk);
@@ -897,11 +1118,12 @@ int main(int argc, char **argv)
                 }
                 if (j->a.blk.records == 0) break;
                 if (j->mode == 2 && (j->a.blk.records & 1)) die("ERROR: interleaved file %s holds an odd number of reads\n", f.path.c_str());
-                pack_arena(j->a, f.path);
-                if (f.paired) pack_arena(j->b, mates[fi].path);
+                g_t_read += now_s() - tr0;
                 {
                     std::unique_lock<std::mutex> lk(mu);
+                    const double tw = now_s();
                     cv.wait(lk, [&] { return order.size() < max_in_flight; });
+                    g_w_reader += now_s() - tw;
                     order.push_back(j);
                     q[seqno % (size_t)nctx].push_back(j);
                 }
@@ -916,6 +1138,7 @@ int main(int argc, char **argv)
     }
     cv.notify_all();
     writer.join();
+    const double t_loop_end = now_s();
     {
         std::lock_guard<std::mutex> lk(mu);
         closing = true;
@@ -928,16 +1151,25 @@ int main(int argc, char **argv)
             if (f->out && f->out_gz && !f->wrote) {  // an empty .gz is still one (empty) gzip member
                 std::vector<char> none, z;
                 gzip_member(none, z);
-                fwrite(z.data(), 1, z.size(), f->out);
+                std::vector<std::vector<char>> one(1);
+                one[0].swap(z);
+                emit_slices(*f, one);
             }
             if (f->out && f->out != stdout) fclose(f->out);
             f->src.close();
         }
     }
-    for (int c = nctx - 1; c >= 0; --c) rc_destroy(ctx[c]);  // borrowers first, owners last
+    // (the contexts are not torn down: the process ends here, and releasing gigabytes of device and
+    // host memory piece by piece costs more than everything else after the last write)
     if (g_timing)
         fprintf(stderr, "[rc timing] start-up (dump load, table build, ERROR_RATE, bad quality) %.2f s; correction loop (read, correct, write) %.2f s; %d host threads\n",
-                t_setup - t_start, now_s() - t_setup, g_threads);
+                t_setup - t_start, t_loop_end - t_setup, g_threads);
+    if (g_timing)
+        fprintf(stderr, "[rc timing] stage totals: read+index %.2f s (reader thread); pack %.2f s + correct_batch %.2f s + format %.2f s (sum over %d worker threads); write %.2f s (writer thread)\n",
+                g_t_read, g_t_pack, g_t_gpu, g_t_format, nctx, g_t_write);
+    if (g_timing)
+        fprintf(stderr, "[rc timing] blocked: reader %.2f s (no free slot), workers %.2f s (no batch), writer %.2f s (next batch not done)\n", g_w_reader, g_w_worker, g_w_writer);
     fprintf(stderr, "Processed %llu reads\n\tCorrected %llu bases.\n", (unsigned long long)total_reads, (unsigned long long)total_cor);
-    return 0;
+    fflush(NULL);
+    _exit(0);  // every output is closed: skip unmapping gigabytes of buffers one by one
 }

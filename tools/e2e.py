@@ -73,6 +73,9 @@ def main():
     import hashlib
     for variant in a.cli_args.split(";"):
         for dump in ([["-c", "x.jf"], []] if a.count else [["-c", "x.jf"]]):
+            import shutil
+            shutil.rmtree(a.dir + "/out", ignore_errors=True)   # truncating last run's multi-GB output is not part of the run
+            os.sync()
             t0 = time.time()
             p = subprocess.run([cli, "-r", "x.fq", "-k", str(k), "-od", a.dir + "/out"] + dump + variant.split(),
                                cwd=a.dir, env=env, stderr=subprocess.PIPE)
