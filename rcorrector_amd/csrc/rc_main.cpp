@@ -1111,10 +1111,13 @@ int main(int argc, char **argv)
                 j->a.lpr = lpr;
                 j->b.lpr = f.paired ? (mates[fi].fastq ? 4 : 2) : lpr;
                 const double tr0 = now_s();
-                take_records(f.src, batch_reads, lpr, j->a.blk);
-                if (f.paired) {
-                    take_records(mates[fi].src, j->a.blk.records ? j->a.blk.records : 1, j->b.lpr, j->b.blk);
+                if (f.paired) {  // both mates' files at once (two inflate streams run side by side for .gz pairs)
+                    std::thread mate([&]() { take_records(mates[fi].src, batch_reads, j->b.lpr, j->b.blk); });
+                    take_records(f.src, batch_reads, lpr, j->a.blk);
+                    mate.join();
                     if (j->b.blk.records != j->a.blk.records) die("ERROR: The files are not paired!\n");
+                } else {
+                    take_records(f.src, batch_reads, lpr, j->a.blk);
                 }
                 if (j->a.blk.records == 0) break;
                 if (j->mode == 2 && (j->a.blk.records & 1)) die("ERROR: interleaved file %s holds an odd number of reads\n", f.path.c_str());

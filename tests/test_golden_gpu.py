@@ -105,3 +105,18 @@ def test_cli_gz_paired_multi_member_output(tmp_path):
         assert got == open(os.path.join(src, "ref", n + ".cor.fq"), "rb").read()
     import subprocess
     assert subprocess.run(["gzip", "-t", str(out / "reads_1.cor.fq.gz")]).returncode == 0
+
+
+def test_cli_unpaired_files_are_refused(tmp_path):
+    """main.cpp:462-467: a mate file with a different number of records ends the run with
+    'ERROR: The files are not paired!' and exit status 1."""
+    import subprocess
+    src = os.path.join(gu.GOLDEN, "fx_pe_k23")
+    work = tmp_path / "in"
+    work.mkdir()
+    shutil.copy(os.path.join(src, "reads_1.fq"), work / "reads_1.fq")
+    lines = open(os.path.join(src, "reads_2.fq"), "rb").read().split(b"\n")
+    open(work / "reads_2.fq", "wb").write(b"\n".join(lines[:-5]) + b"\n")     # one record fewer
+    p = subprocess.run([CLI, "-p", str(work / "reads_1.fq"), str(work / "reads_2.fq"), "-k", "23", "-c", os.path.join(src, "dump.jf"),
+                        "-od", str(tmp_path / "out")], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 1 and b"ERROR: The files are not paired!" in p.stderr
