@@ -158,6 +158,11 @@ typedef struct {
     int32_t *d_ret, *d_l, *d_m, *d_h;
 } rc_device_batch;
 int rc_correct_device(rc_ctx *ctx, const rc_device_batch *b);
+/* replaces GetStrongTrustedThreshold (ErrorCorrection.h:26, ErrorCorrection.cpp:1482-1565) for every
+ * read of an arena in HBM (asynchronous; the run parameters must be set): d_strong[r] = the
+ * function's return value for read r (-1 for reads it screens out). */
+int rc_strong_threshold_device(rc_ctx *ctx, const uint8_t *d_seq, const uint32_t *d_off, uint32_t n_reads,
+                               uint64_t nbytes, int32_t max_read_len, int32_t *d_strong);
 /* the hash-probe kernel alone: d_counts[a] = count of the k-mer starting at arena byte a
  * (ErrorCorrection.cpp:716-723 for every read of the arena) */
 int rc_probe_device(rc_ctx *ctx, const uint8_t *d_seq, uint64_t nbytes, int32_t *d_counts);

@@ -15,7 +15,7 @@ ABI_SYMBOLS = [
     "rc_table_count_begin", "rc_table_count_add", "rc_table_count_add_device", "rc_table_count_finish",
     "rc_table_count_reads_device", "rc_table_write_jfdump", "rc_table_share", "rc_table_lookup", "rc_table_export", "rc_table_stats",
     "rc_estimate_error_rate", "rc_bad_quality_from_hist", "rc_set_run_params",
-    "rc_correct_batch", "rc_correct_batch_traced", "rc_correct_device", "rc_probe_device", "rc_sync",
+    "rc_correct_batch", "rc_correct_batch_traced", "rc_correct_device", "rc_strong_threshold_device", "rc_probe_device", "rc_sync",
     "rc_profile_enable", "rc_profile_get", "rc_profile_reset", "rc_selftest_get_bound", "rc_summary",
 ]
 
@@ -104,6 +104,7 @@ def load_library():
     L.rc_correct_batch.argtypes = [vp, C.POINTER(_Batch)]
     L.rc_correct_device.argtypes = [vp, C.POINTER(_DeviceBatch)]
     L.rc_probe_device.argtypes = [vp, vp, C.c_uint64, vp]
+    L.rc_strong_threshold_device.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint64, C.c_int32, vp]
     L.rc_sync.argtypes = [vp]
     L.rc_profile_enable.argtypes = [vp, C.c_int]
     L.rc_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
@@ -273,6 +274,9 @@ class Context:
         b = _DeviceBatch(mode, n_reads, nbytes, max_read_len, _ptr(d_seq), _ptr(d_qual), _ptr(d_off),
                          _ptr(d_ret), _ptr(d_l), _ptr(d_m), _ptr(d_h))
         self._ck(self._L.rc_correct_device(self._h, C.byref(b)))
+
+    def strong_threshold_device(self, d_seq, d_off, n_reads, nbytes, max_read_len, d_strong):
+        self._ck(self._L.rc_strong_threshold_device(self._h, _ptr(d_seq), _ptr(d_off), n_reads, nbytes, max_read_len, _ptr(d_strong)))
 
     def probe_device(self, d_seq, nbytes, d_counts):
         self._ck(self._L.rc_probe_device(self._h, _ptr(d_seq), nbytes, _ptr(d_counts)))

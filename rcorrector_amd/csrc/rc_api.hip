@@ -628,6 +628,35 @@ int rc_correct_device(rc_ctx *ctx, const rc_device_batch *b)
     return RC_OK;
 }
 
+// GetStrongTrustedThreshold (ErrorCorrection.h:26, ErrorCorrection.cpp:1482-1565) for every read of
+// an arena in HBM: probe kernel + threshold kernel, the per-read values copied to d_strong
+int rc_strong_threshold_device(rc_ctx *ctx, const uint8_t *d_seq, const uint32_t *d_off, uint32_t n_reads, uint64_t nbytes,
+                               int32_t max_read_len, int32_t *d_strong)
+{
+    if (!ctx || !d_seq || !d_off || !d_strong) return RC_ERR_ARG;
+    if (n_reads == 0) return RC_OK;
+    if (nbytes >= (1ull << 32)) {
+        rc_set_error(ctx, "strong_threshold_device: arena of %llu bytes exceeds the 4 GiB batch limit", (unsigned long long)nbytes);
+        return RC_ERR_ARG;
+    }
+    RC_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = rc_dbuf_reserve(ctx, &ctx->counts, (size_t)nbytes * 4 + 256))) return rc;
+    if ((rc = rc_dbuf_reserve(ctx, &ctx->strong, (size_t)n_reads * 4 + 256))) return rc;
+    if ((rc = rc_dbuf_reserve(ctx, &ctx->info, (size_t)n_reads * 4 + 256))) return rc;
+    rc_device_batch_args a;
+    memset(&a, 0, sizeof a);
+    a.mode = 0;
+    a.n = n_reads;
+    a.seq = const_cast<uint8_t *>(d_seq);
+    a.off = d_off;
+    a.max_len = max_read_len;
+    if ((rc = rc_launch_probe(ctx, d_seq, (size_t)nbytes, (int32_t *)ctx->counts.p))) return rc;
+    if ((rc = rc_launch_threshold(ctx, a))) return rc;
+    RC_CHECK_HIP(ctx, hipMemcpyAsync(d_strong, ctx->strong.p, (size_t)n_reads * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    return RC_OK;
+}
+
 int rc_sync(rc_ctx *ctx)
 {
     if (!ctx) return RC_ERR_ARG;

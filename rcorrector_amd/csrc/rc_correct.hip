@@ -6,6 +6,7 @@
 // atomic counter, which is the reference's mutex-protected batchUsed counter (:87-90) and
 // absorbs the heavy tail of the search.  Per-read state is carved out of dynamic LDS.
 #include <cstdio>
+#include <cstdlib>
 
 #include "rc_internal.h"
 #include "rc_device.h"
@@ -434,6 +435,8 @@ __global__ __launch_bounds__(64) void k_threshold(rc_kernel_args A)
     }
 }
 
+#include "rc_quarter.h"
+
 #ifndef RC_DEQUEUE
 #define RC_DEQUEUE 8  // reads per work-counter atomic
 #endif
@@ -584,10 +587,16 @@ int rc_launch_threshold(rc_ctx *ctx, const rc_device_batch_args &a)
     int rc = fill_args(ctx, a, A);
     if (rc) return rc;
     const rc_lds_layout L = rc_layout(A.cap);
-    unsigned grid = (unsigned)ctx->n_cu * 32u;
-    if (grid > a.n) grid = a.n;
+    // four reads per wave when every read of the batch fits the quarter-wave layout (rc_quarter.h)
+    const bool quarter = a.max_len <= rcq::MAX_LEN && a.max_len - A.P.k + 1 <= rcq::MAX_KCNT && !getenv("RC_K2_WAVE_PER_READ");
     rc_timer_begin(ctx);
-    hipLaunchKernelGGL(k_threshold, dim3(grid), dim3(64), L.total, ctx->stream, A);
+    if (quarter) {
+        hipLaunchKernelGGL(k_threshold_q, dim3((a.n + 15) / 16), dim3(256), 0, ctx->stream, A);
+    } else {
+        unsigned grid = (unsigned)ctx->n_cu * 32u;
+        if (grid > a.n) grid = a.n;
+        hipLaunchKernelGGL(k_threshold, dim3(grid), dim3(64), L.total, ctx->stream, A);
+    }
     rc_timer_end(ctx, RC_T_THRESH);
     RC_CHECK_HIP(ctx, hipGetLastError());
     return RC_OK;

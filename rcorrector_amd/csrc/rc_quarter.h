@@ -1,0 +1,244 @@
+// rc_quarter.h -- "quarter-wave" kernels: FOUR reads per 64-lane wavefront, one per 16-lane DPP
+// row, for the per-read array work whose control flow does not depend on the data
+// (GetStrongTrustedThreshold, ErrorCorrection.cpp:1482-1565).
+//
+// Why: with one read per wave (rc_correct_core.h) a 150-base read gives every lane two or three
+// elements, so most instructions of these phases are executed for a handful of useful lanes, and
+// every lane exchange is an LDS round trip (ds_bpermute) on a serial dependency chain -- the
+// wave-per-read threshold kernel spends ~17 000 cycles per read on ~900 instructions.  Here element
+// g of a read lives in register g/16 of lane g%16 of the read's row: the sort network exchanges
+// through DPP row operations (quad_perm, row_shr/shl, row_ror, row_mirror: plain VALU, no LDS),
+// strides >= 16 are register-to-register, the letter masks are 32-bit words in registers and a
+// window's A/T count is one v_alignbit + v_and + v_bcnt.  No LDS allocation at all.
+//
+// Limits of this layout: k-mer windows per read <= 128 (8 registers x 16 lanes) and read length
+// <= 160; batches with longer reads take the wave-per-read kernel (same results, rc_front_end()).
+// Included by rc_correct.hip only.
+#pragma once
+
+namespace rcq {
+
+constexpr int E_CNT = 8;    // count registers per lane: 8 x 16 = 128 windows
+constexpr int E_BASE = 10;  // base registers per lane: 10 x 16 = 160 bases
+constexpr int MAX_KCNT = E_CNT * 16;
+constexpr int MAX_LEN = E_BASE * 16;
+
+template <int CTRL>
+__device__ __forceinline__ int dpp(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+// value of lane (l ^ X) of the same 16-lane row
+template <int X>
+__device__ __forceinline__ int row_xor(int v)
+{
+    if constexpr (X == 1) {
+        return dpp<0xB1>(v);  // quad_perm [1,0,3,2]
+    } else if constexpr (X == 2) {
+        return dpp<0x4E>(v);  // quad_perm [2,3,0,1]
+    } else if constexpr (X == 3) {
+        return dpp<0x1B>(v);  // quad_perm [3,2,1,0]
+    } else if constexpr (X == 4) {
+        const int t = __builtin_amdgcn_update_dpp(v, v, 0x104, 0xF, 0x5, false);  // row_shl:4 into banks 0,2
+        return __builtin_amdgcn_update_dpp(t, v, 0x114, 0xF, 0xA, false);        // row_shr:4 into banks 1,3
+    } else if constexpr (X == 7) {
+        return dpp<0x141>(v);  // row_half_mirror
+    } else if constexpr (X == 8) {
+        return dpp<0x128>(v);  // row_ror:8
+    } else {
+        static_assert(X == 15, "row_xor: unsupported pattern");
+        return dpp<0x140>(v);  // row_mirror
+    }
+}
+__device__ __forceinline__ int med3(int a, int b, int c)
+{
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
+
+// ascending bitonic network over the 128 elements (e, l) of each row, all-ascending ("flip")
+// formulation: the first stage of a merge pairs g with g ^ (size-1), the others g with g ^ stride,
+// the lower index keeps the minimum.  c[b] = bit b of l ? INT_MAX : INT_MIN turns one v_med3_i32
+// into "min on the lower side, max on the upper side".
+template <int X, int BIT>
+__device__ __forceinline__ void cx_row(int (&x)[E_CNT], const int (&c)[4])
+{
+#pragma unroll
+    for (int e = 0; e < E_CNT; ++e) x[e] = med3(x[e], row_xor<X>(x[e]), c[BIT]);
+}
+template <int STRIDE>
+__device__ __forceinline__ void strides(int (&x)[E_CNT], const int (&c)[4])
+{
+    if constexpr (STRIDE >= 16) {
+#pragma unroll
+        for (int e = 0; e < E_CNT; ++e) {
+            const int pe = e ^ (STRIDE >> 4);
+            if (pe > e) {
+                const int lo = x[e] < x[pe] ? x[e] : x[pe];
+                const int hi = x[e] < x[pe] ? x[pe] : x[e];
+                x[e] = lo;
+                x[pe] = hi;
+            }
+        }
+    } else {
+        cx_row<STRIDE, ilog2(STRIDE)>(x, c);
+    }
+    if constexpr (STRIDE > 1) strides<STRIDE / 2>(x, c);
+}
+template <int SIZE>
+__device__ __forceinline__ void merges(int (&x)[E_CNT], const int (&c)[4])
+{
+    if constexpr (SIZE <= 16) {
+        cx_row<SIZE - 1, ilog2(SIZE) - 1>(x, c);
+    } else {
+#pragma unroll
+        for (int e = 0; e < E_CNT; ++e) {
+            const int pe = e ^ ((SIZE >> 4) - 1);
+            if (pe > e) {
+                const int ye = row_xor<15>(x[pe]), yp = row_xor<15>(x[e]);
+                x[e] = x[e] < ye ? x[e] : ye;
+                x[pe] = x[pe] < yp ? yp : x[pe];
+            }
+        }
+    }
+    if constexpr (SIZE >= 4) strides<SIZE / 4>(x, c);
+    if constexpr (SIZE < E_CNT * 16) merges<SIZE * 2>(x, c);
+}
+
+// the 16 bits of a wave-wide ballot that belong to this lane's row
+__device__ __forceinline__ uint32_t row_bits(uint64_t ballot, int row)
+{
+    return (uint32_t)(ballot >> (row << 4)) & 0xffffu;
+}
+
+}  // namespace rcq
+
+// GetStrongTrustedThreshold for every read (what k_threshold computes through rc_front_end()),
+// four reads per wave.  256-thread workgroups = 16 reads.
+__global__ __launch_bounds__(256) void k_threshold_q(rc_kernel_args A)
+{
+    using namespace rcq;
+    const int lane = threadIdx.x & 63, row = lane >> 4, l = lane & 15;
+    const int k = A.P.k;
+    const uint32_t r = ((uint32_t)blockIdx.x * 4u + (threadIdx.x >> 6)) * 4u + (uint32_t)row;
+    const bool live = r < A.n;
+    uint32_t o = 0;
+    int len = 0;
+    if (live) {
+        o = A.off[r];
+        len = (int)(A.off[r + 1] - o) - 1;
+    }
+    const int kcnt = len >= k ? len - k + 1 : 0;
+
+    // bases (as letter codes) and K1's counts, element g in register g/16 of lane g%16
+    int code[E_BASE], x[E_CNT];
+#pragma unroll
+    for (int e = 0; e < E_BASE; ++e) {
+        const int p = e * 16 + l;
+        code[e] = p < len ? rc_base_code(A.seq[o + p]) : 7;
+    }
+#pragma unroll
+    for (int e = 0; e < E_CNT; ++e) {
+        const int g = e * 16 + l;
+        x[e] = g < kcnt ? A.counts[o + g] : 0;
+    }
+
+    // letter masks of the row's read as 32-bit words (bit p%32 of word p/32 = base p is the letter)
+    uint32_t ma[E_BASE / 2 + 1], mt[E_BASE / 2 + 1];
+    int n_cnt = 0;
+    {
+        uint32_t fa[E_BASE], ft[E_BASE];
+#pragma unroll
+        for (int e = 0; e < E_BASE; ++e) {
+            fa[e] = row_bits(__ballot(code[e] == 0), row);
+            ft[e] = row_bits(__ballot(code[e] == 3), row);
+            n_cnt += __popc(row_bits(__ballot(code[e] == 4), row));
+        }
+#pragma unroll
+        for (int j = 0; j < E_BASE / 2; ++j) {
+            ma[j] = fa[2 * j] | (fa[2 * j + 1] << 16);
+            mt[j] = ft[2 * j] | (ft[2 * j + 1] << 16);
+        }
+        ma[E_BASE / 2] = mt[E_BASE / 2] = 0;
+    }
+    int a_cnt = 0, t_cnt = 0;
+#pragma unroll
+    for (int j = 0; j < E_BASE / 2; ++j) {
+        a_cnt += __popc(ma[j]);
+        t_cnt += __popc(mt[j]);
+    }
+    const bool screened = len < k || n_cnt > 5 || a_cnt > len - k || t_cnt > len - k;  // :1491,1507-1527
+
+    // poly-A masked counts (:1530-1541): a window with >= k - max(7, k/2) A's or T's counts as -1;
+    // window g = bits [g, g+k) of the mask = one funnel shift of two adjacent words (k <= 32)
+    int thr7 = 7;
+    if (k / 2 > thr7) thr7 = k / 2;
+    const uint32_t kmask = k >= 32 ? 0xffffffffu : ((1u << k) - 1u);
+#pragma unroll
+    for (int e = 0; e < E_CNT; ++e) {
+        const int g = e * 16 + l;
+        const int w = e >> 1;                     // (e*16 + l) / 32
+        const uint32_t sh = (uint32_t)((e & 1) * 16 + l);
+        const int a = __popc(__builtin_amdgcn_alignbit(ma[w + 1], ma[w], sh) & kmask);
+        const int t = __popc(__builtin_amdgcn_alignbit(mt[w + 1], mt[w], sh) & kmask);
+        const bool polya = a >= k - thr7 || t >= k - thr7;
+        x[e] = g < kcnt ? (polya ? -1 : x[e]) : 2147483647;
+    }
+
+    int c[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) c[b] = __builtin_amdgcn_sbfe(l, b, 1) ^ (int)0x80000000;  // bit ? INT_MAX : INT_MIN
+    merges<2>(x, c);
+
+    // the "drop" scan (:1543-1563): highest g in [1, kcnt) with v[g] > 2 v[g-1] && v[g] > 10
+    const int row_lane0 = row << 4;
+    int strong = 0, prev = 0;
+    bool found = false;
+    int i0 = kcnt;  // lowest g with v[g] > 0
+    bool have_pos = false;
+    uint32_t fdrop[E_CNT], fpos[E_CNT];
+    int pv[E_CNT];
+#pragma unroll
+    for (int e = 0; e < E_CNT; ++e) {
+        const int g = e * 16 + l;
+        const int same = dpp<0x111>(x[e]);                  // row_shr:1 -- the element before, same register
+        const int wrap = e > 0 ? dpp<0x121>(x[e - 1]) : 0;  // row_ror:1 -- lane 0 sees lane 15 of the register before
+        const int p = l == 0 ? wrap : same;
+        pv[e] = p;
+        const bool drop = g >= 1 && g < kcnt && x[e] > 2 * p && x[e] > 10;
+        fdrop[e] = row_bits(__ballot(drop), row);
+        fpos[e] = row_bits(__ballot(g < kcnt && x[e] > 0), row);
+    }
+#pragma unroll
+    for (int e = E_CNT - 1; e >= 0; --e) {
+        const bool hit = !found && fdrop[e] != 0;
+        const int li = 31 - __clz((int)(fdrop[e] | 1u));
+        const int src = (row_lane0 + li) << 2;
+        const int s = __builtin_amdgcn_ds_bpermute(src, x[e]);
+        const int pp = __builtin_amdgcn_ds_bpermute(src, pv[e]);
+        strong = hit ? s : strong;
+        prev = hit ? pp : prev;
+        found = found || hit;
+    }
+#pragma unroll
+    for (int e = 0; e < E_CNT; ++e) {
+        const bool hit = !have_pos && fpos[e] != 0;
+        i0 = hit ? e * 16 + (__ffs((int)fpos[e]) - 1) : i0;
+        have_pos = have_pos || hit;
+    }
+    {
+        // no drop: the median of the positive part, v[(i0 + kcnt - 1) / 2]   (:1556-1563)
+        const int idx = kcnt > 0 ? (i0 + kcnt - 1) / 2 : 0;
+        int sel = x[0];
+#pragma unroll
+        for (int e = 1; e < E_CNT; ++e) sel = (idx >> 4) == e ? x[e] : sel;
+        const int med = __builtin_amdgcn_ds_bpermute((row_lane0 + (idx & 15)) << 2, sel);
+        strong = found ? strong : med;
+    }
+    if (live && l == 0) {
+        A.strong[r] = screened ? -1 : strong;
+        A.info[r] = screened ? 4 : ((found ? 1 : 0) | ((found && prev == 2) ? 2 : 0));
+    }
+}

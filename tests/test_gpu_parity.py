@@ -4,6 +4,8 @@ import numpy as np
 import pytest
 
 import datasets
+import rcorrector_amd
+import synth
 
 pytestmark = pytest.mark.gpu
 
@@ -253,3 +255,55 @@ def test_get_bound_device_equals_x86(gpu_ctx_factory, oracle, rate):
     assert np.isnan(gd[~ok]).all() and (gi[~ok] == -2147483648).all()
     want_i = np.where(want_d[ok] < 2147483648.0, np.trunc(np.minimum(want_d[ok], 2147483647.0)), -2147483648.0).astype(np.int64)
     assert np.array_equal(gi[ok].astype(np.int64), want_i)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,length", [(23, 150), (23, 100), (31, 158), (15, 90), (32, 159), (19, 146), (11, 138)])
+def test_strong_threshold_quarter_wave_equals_wave_per_read_and_oracle(gpu_ctx_factory, oracle, k, length, monkeypatch):
+    """GetStrongTrustedThreshold through both threshold kernels -- four reads per wave
+    (rc_quarter.h, taken when every read has <= 128 k-mers and <= 160 bases) and one read per wave
+    -- and through the oracle, on reads with ragged lengths (also < k), N runs, poly-A/T tails and
+    count spectra with and without a 'drop'."""
+    import torch
+    rng = np.random.Generator(np.random.PCG64(1000 + k + length))
+    s1, _, _, _, _ = synth.make_reads(4100 + k, 6000, length, n_tx=12, l_tx=max(600, length + 50), e=0.01, alpha=1.2)
+    reads = []
+    for i in range(len(s1)):
+        r = bytearray(s1[i].tobytes())
+        u = rng.random()
+        if u < 0.25:
+            r = r[:int(rng.integers(1, length + 1))]
+        if u > 0.5 and u < 0.6 and len(r) > 30:
+            t = int(rng.integers(10, len(r)))
+            r[len(r) - t:] = (b"A" if rng.random() < 0.5 else b"T") * t
+        if u > 0.6 and u < 0.7 and len(r) > 10:
+            for p in rng.choice(len(r), int(rng.integers(1, 9)), replace=False):
+                r[p] = ord("N") if rng.random() < 0.8 else ord("R")
+        reads.append(bytes(r))
+    keys, cnt = synth.count_kmers([s1], k)
+    keep = rng.random(len(keys)) < 0.9
+    ctx = gpu_ctx_factory(k=k)
+    ctx.table_build(keys[keep], cnt[keep].astype(np.int32))
+    ctx.set_run_params(0.01, b"#")
+    arena, off = rcorrector_amd.pack_reads(reads)
+    d_seq = torch.from_numpy(arena.copy()).cuda()
+    d_off = torch.from_numpy(off.astype(np.int32)).cuda()
+    out = {}
+    for name, env in (("quarter", None), ("wave", "1")):
+        if env:
+            monkeypatch.setenv("RC_K2_WAVE_PER_READ", env)
+        else:
+            monkeypatch.delenv("RC_K2_WAVE_PER_READ", raising=False)
+        d_strong = torch.full((len(reads),), -7, dtype=torch.int32, device="cuda")
+        ctx.strong_threshold_device(d_seq, d_off, len(reads), arena.size, max(len(r) for r in reads), d_strong)
+        ctx.sync()
+        out[name] = d_strong.cpu().numpy()
+    monkeypatch.delenv("RC_K2_WAVE_PER_READ", raising=False)
+    T = oracle.Table(k, len(keys))
+    T.put_many(keys[keep], cnt[keep].astype(np.int32))
+    P = oracle.make_params(k, 4, 0.01, b"#")
+    import ctypes
+    want = np.array([oracle.lib().rco_strong_trusted_threshold(ctypes.byref(P), T.h, r) for r in reads], dtype=np.int32)
+    assert np.array_equal(out["wave"], want)
+    assert np.array_equal(out["quarter"], want)
+    assert (want == -1).any() and (want > 10).any()
