@@ -118,10 +118,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus and world > 1:
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, a.gpus))
+    # RC_BENCH_SHARED_GPU=1 (tests only): every rank uses GPU 0 and the collectives run over gloo, so
+    # that the N>1 code path can be exercised on a one-GPU box
+    shared_gpu = os.environ.get("RC_BENCH_SHARED_GPU") == "1"
+    if shared_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    coll_dev = torch.device("cpu") if shared_gpu else dev
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if shared_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     def barrier():
         if world > 1:
@@ -195,12 +204,12 @@ def main():
     progress("timed steps done: %.1f ms per step" % (dt / a.steps * 1e3))
     ctx.profile(False)
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     n_cor_reads = int((ret > 0).sum().item())
     # the one RCCL collective of the whole path: global count statistics (main.cpp:32-36)
-    g_reads, g_bases = reduce_summary(n, int(ret.clamp(min=0).sum().item()), device=dev)
+    g_reads, g_bases = reduce_summary(n, int(ret.clamp(min=0).sum().item()), device=coll_dev)
     stats = [g_reads, n_cor_reads * world, g_bases]
 
     if rank == 0:

@@ -307,3 +307,33 @@ def test_strong_threshold_quarter_wave_equals_wave_per_read_and_oracle(gpu_ctx_f
     assert np.array_equal(out["wave"], want)
     assert np.array_equal(out["quarter"], want)
     assert (want == -1).any() and (want > 10).any()
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu(tmp_path):
+    """The N>1 path of bench.py as the driver launches it (torch.distributed.run, one rank per
+    GPU) -- exercised here with both ranks on GPU 0 and gloo collectives (RC_BENCH_SHARED_GPU=1):
+    one JSON line from rank 0, the whole-job value over both ranks, weak scaling."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RC_BENCH_SHARED_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--reads", "400000", "--n-tx", "2000", "--cpu-sample", "0"]
+    p = subprocess.run(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["cpu_baseline"] is None
+    assert d["config"]["reads_per_gpu"] == 400000 and "x2" in d["config"]["parallelism"]
+    assert abs(d["value"] - 2 * 400000 * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 1e-6
+    assert 0.2 < d["config"]["reads_corrected_frac"] < 0.9
