@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""One-off extended fuzz: tests/test_gpu_fuzz.py's random cases for an arbitrary seed range
+(GPU CLI vs the pinned CPU oracle CLI, every output byte, stderr and -verbose transcript)."""
+import os
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tools"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import test_gpu_fuzz as F  # noqa: E402
+from oracle import pyoracle  # noqa: E402
+
+pyoracle.build()
+lo, hi = int(sys.argv[1]), int(sys.argv[2])
+bad = 0
+for seed in range(lo, hi):
+    with tempfile.TemporaryDirectory() as d:
+        args = F._random_case(seed, d)
+        outs = {}
+        verbose = ["-verbose"] if seed % 3 == 0 else []
+        for name, binary, more in (("gpu", F.CLI, ["-batch", "64"] if seed % 2 else []), ("cpu", pyoracle.CLI_BIN, ["-t", "2"])):
+            od = os.path.join(d, name)
+            os.makedirs(od)
+            p = subprocess.run([binary] + args + ["-od", od] + more + verbose, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            outs[name] = (p.returncode, p.stderr, {f: open(os.path.join(od, f), "rb").read() for f in sorted(os.listdir(od))}, p.stdout)
+        if outs["gpu"] != outs["cpu"]:
+            bad += 1
+            print("MISMATCH seed", seed, args, outs["gpu"][0], outs["cpu"][0], flush=True)
+print("seeds %d..%d: %d mismatches" % (lo, hi, bad))
