@@ -141,6 +141,11 @@ def _ptr(x):
     if isinstance(x, np.ndarray):
         return x.ctypes.data
     if hasattr(x, "data_ptr"):
+        # a torch tensor: whatever produced it ran on torch's stream, the library works on its own --
+        # make sure the producer has finished before the address is handed over
+        if getattr(x, "is_cuda", False):
+            import torch
+            torch.cuda.current_stream(x.device).synchronize()
         return x.data_ptr()
     raise TypeError("cannot take a pointer of %r" % type(x))
 
