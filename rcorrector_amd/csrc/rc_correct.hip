@@ -590,8 +590,10 @@ int rc_launch_threshold(rc_ctx *ctx, const rc_device_batch_args &a)
     // four reads per wave when every read of the batch fits the quarter-wave layout (rc_quarter.h)
     const bool quarter = a.max_len <= rcq::MAX_LEN && a.max_len - A.P.k + 1 <= rcq::MAX_KCNT && !getenv("RC_K2_WAVE_PER_READ");
     rc_timer_begin(ctx);
-    if (quarter) {
-        hipLaunchKernelGGL(k_threshold_q, dim3((a.n + 15) / 16), dim3(256), 0, ctx->stream, A);
+    if (quarter && a.max_len <= 160 && a.max_len - A.P.k + 1 <= 128) {
+        hipLaunchKernelGGL((k_threshold_q<8, 10>), dim3((a.n + 15) / 16), dim3(256), 0, ctx->stream, A);
+    } else if (quarter) {
+        hipLaunchKernelGGL((k_threshold_q<16, 20>), dim3((a.n + 15) / 16), dim3(256), 0, ctx->stream, A);
     } else {
         unsigned grid = (unsigned)ctx->n_cu * 32u;
         if (grid > a.n) grid = a.n;

@@ -11,17 +11,17 @@
 // strides >= 16 are register-to-register, the letter masks are 32-bit words in registers and a
 // window's A/T count is one v_alignbit + v_and + v_bcnt.  No LDS allocation at all.
 //
-// Limits of this layout: k-mer windows per read <= 128 (8 registers x 16 lanes) and read length
-// <= 160; batches with longer reads take the wave-per-read kernel (same results, rc_front_end()).
+// Limits of this layout: k-mer windows per read <= 256 (16 registers x 16 lanes) and read length
+// <= 320; batches with longer reads take the wave-per-read kernel (same results, rc_front_end()).
 // Included by rc_correct.hip only.
 #pragma once
 
 namespace rcq {
 
-constexpr int E_CNT = 8;    // count registers per lane: 8 x 16 = 128 windows
-constexpr int E_BASE = 10;  // base registers per lane: 10 x 16 = 160 bases
-constexpr int MAX_KCNT = E_CNT * 16;
-constexpr int MAX_LEN = E_BASE * 16;
+// two instantiations: <8, 10> = up to 128 windows / 160 bases per read, <16, 20> = 256 / 320
+// (EC count registers and EB base registers per lane, 16 lanes per read)
+constexpr int MAX_KCNT = 16 * 16;
+constexpr int MAX_LEN = 20 * 16;
 
 template <int CTRL>
 __device__ __forceinline__ int dpp(int v)
@@ -62,18 +62,18 @@ constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
 // formulation: the first stage of a merge pairs g with g ^ (size-1), the others g with g ^ stride,
 // the lower index keeps the minimum.  c[b] = bit b of l ? INT_MAX : INT_MIN turns one v_med3_i32
 // into "min on the lower side, max on the upper side".
-template <int X, int BIT>
-__device__ __forceinline__ void cx_row(int (&x)[E_CNT], const int (&c)[4])
+template <int EC, int X, int BIT>
+__device__ __forceinline__ void cx_row(int (&x)[EC], const int (&c)[4])
 {
 #pragma unroll
-    for (int e = 0; e < E_CNT; ++e) x[e] = med3(x[e], row_xor<X>(x[e]), c[BIT]);
+    for (int e = 0; e < EC; ++e) x[e] = med3(x[e], row_xor<X>(x[e]), c[BIT]);
 }
-template <int STRIDE>
-__device__ __forceinline__ void strides(int (&x)[E_CNT], const int (&c)[4])
+template <int EC, int STRIDE>
+__device__ __forceinline__ void strides(int (&x)[EC], const int (&c)[4])
 {
     if constexpr (STRIDE >= 16) {
 #pragma unroll
-        for (int e = 0; e < E_CNT; ++e) {
+        for (int e = 0; e < EC; ++e) {
             const int pe = e ^ (STRIDE >> 4);
             if (pe > e) {
                 const int lo = x[e] < x[pe] ? x[e] : x[pe];
@@ -83,18 +83,18 @@ __device__ __forceinline__ void strides(int (&x)[E_CNT], const int (&c)[4])
             }
         }
     } else {
-        cx_row<STRIDE, ilog2(STRIDE)>(x, c);
+        cx_row<EC, STRIDE, ilog2(STRIDE)>(x, c);
     }
-    if constexpr (STRIDE > 1) strides<STRIDE / 2>(x, c);
+    if constexpr (STRIDE > 1) strides<EC, STRIDE / 2>(x, c);
 }
-template <int SIZE>
-__device__ __forceinline__ void merges(int (&x)[E_CNT], const int (&c)[4])
+template <int EC, int SIZE>
+__device__ __forceinline__ void merges(int (&x)[EC], const int (&c)[4])
 {
     if constexpr (SIZE <= 16) {
-        cx_row<SIZE - 1, ilog2(SIZE) - 1>(x, c);
+        cx_row<EC, SIZE - 1, ilog2(SIZE) - 1>(x, c);
     } else {
 #pragma unroll
-        for (int e = 0; e < E_CNT; ++e) {
+        for (int e = 0; e < EC; ++e) {
             const int pe = e ^ ((SIZE >> 4) - 1);
             if (pe > e) {
                 const int ye = row_xor<15>(x[pe]), yp = row_xor<15>(x[e]);
@@ -103,8 +103,8 @@ __device__ __forceinline__ void merges(int (&x)[E_CNT], const int (&c)[4])
             }
         }
     }
-    if constexpr (SIZE >= 4) strides<SIZE / 4>(x, c);
-    if constexpr (SIZE < E_CNT * 16) merges<SIZE * 2>(x, c);
+    if constexpr (SIZE >= 4) strides<EC, SIZE / 4>(x, c);
+    if constexpr (SIZE < EC * 16) merges<EC, SIZE * 2>(x, c);
 }
 
 // the 16 bits of a wave-wide ballot that belong to this lane's row
@@ -117,6 +117,7 @@ __device__ __forceinline__ uint32_t row_bits(uint64_t ballot, int row)
 
 // GetStrongTrustedThreshold for every read (what k_threshold computes through rc_front_end()),
 // four reads per wave.  256-thread workgroups = 16 reads.
+template <int E_CNT, int E_BASE>
 __global__ __launch_bounds__(256) void k_threshold_q(rc_kernel_args A)
 {
     using namespace rcq;
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(256) void k_threshold_q(rc_kernel_args A)
     int c[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) c[b] = __builtin_amdgcn_sbfe(l, b, 1) ^ (int)0x80000000;  // bit ? INT_MAX : INT_MIN
-    merges<2>(x, c);
+    merges<E_CNT, 2>(x, c);
 
     // the "drop" scan (:1543-1563): highest g in [1, kcnt) with v[g] > 2 v[g-1] && v[g] > 10
     const int row_lane0 = row << 4;

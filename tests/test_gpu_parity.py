@@ -258,10 +258,12 @@ def test_get_bound_device_equals_x86(gpu_ctx_factory, oracle, rate):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("k,length", [(23, 150), (23, 100), (31, 158), (15, 90), (32, 159), (19, 146), (11, 138)])
+@pytest.mark.parametrize("k,length", [(23, 150), (23, 100), (31, 158), (15, 90), (32, 159), (19, 146), (11, 138),
+                                      (25, 250), (25, 280), (32, 287), (23, 161), (21, 320), (23, 300)])
 def test_strong_threshold_quarter_wave_equals_wave_per_read_and_oracle(gpu_ctx_factory, oracle, k, length, monkeypatch):
     """GetStrongTrustedThreshold through both threshold kernels -- four reads per wave
-    (rc_quarter.h, taken when every read has <= 128 k-mers and <= 160 bases) and one read per wave
+    (rc_quarter.h: two register layouts, up to 128 k-mers / 160 bases and up to 256 / 320; the last
+    case is beyond both) and one read per wave
     -- and through the oracle, on reads with ragged lengths (also < k), N runs, poly-A/T tails and
     count spectra with and without a 'drop'."""
     import torch
