@@ -903,7 +903,7 @@ int main(int argc, char **argv)
     std::condition_variable cv;
     std::deque<std::shared_ptr<Job>> order;  // submission order, for the writer
     std::vector<std::shared_ptr<Job>> pool;  // finished jobs: their buffers are reused (no fresh page faults)
-    std::vector<std::deque<std::shared_ptr<Job>>> q((size_t)nctx);
+    std::deque<std::shared_ptr<Job>> q;  // one queue for all workers: whichever context is free takes the next batch
     bool closing = false, reader_done = false;
     const size_t max_in_flight = (size_t)(nctx + 2);
 
@@ -964,11 +964,11 @@ int main(int argc, char **argv)
                 {
                     std::unique_lock<std::mutex> lk(mu);
                     const double tw = now_s();
-                    cv.wait(lk, [&] { return closing || !q[g].empty(); });
+                    cv.wait(lk, [&] { return closing || !q.empty(); });
                     g_w_worker += now_s() - tw;
-                    if (q[g].empty()) return;
-                    j = q[g].front();
-                    q[g].pop_front();
+                    if (q.empty()) return;
+                    j = q.front();
+                    q.pop_front();
                 }
                 const double tp0 = now_s();
                 pack_arena(j->a, files[(size_t)j->file].path);
@@ -1091,7 +1091,6 @@ int main(int argc, char **argv)
 
     // reader
     {
-        size_t seqno = 0;
         for (size_t fi = 0; fi < files.size(); ++fi) {
             ReadFile &f = files[fi];
             const int lpr = f.fastq ? 4 : 2;
@@ -1128,9 +1127,8 @@ int main(int argc, char **argv)
                     cv.wait(lk, [&] { return order.size() < max_in_flight; });
                     g_w_reader += now_s() - tw;
                     order.push_back(j);
-                    q[seqno % (size_t)nctx].push_back(j);
+                    q.push_back(j);
                 }
-                ++seqno;
                 cv.notify_all();
             }
         }
