@@ -221,3 +221,15 @@ def test_simulated_reads_end_to_end_with_accuracy_score(tmp_path):
     subprocess.run(["make", "-C", os.path.join(gu.ROOT, "rcorrector_amd", "csrc"), "../verify"], check=True, stdout=subprocess.DEVNULL)
     out = subprocess.run([os.path.join(gu.ROOT, "rcorrector_amd", "verify"), str(tmp_path / "raw.cor.fq")], stdout=subprocess.PIPE, check=True).stdout
     assert out == open(os.path.join(g, "cor.plain.txt"), "rb").read()
+
+
+def test_write_jfdump_of_an_empty_table(rc, tmp_path):
+    ctx = rc.Context(k=23)
+    ctx.count_begin()
+    ctx.count_add(b"ACGTACGT\0")            # shorter than k: no k-mer at all
+    assert ctx.count_finish(2) == 0
+    path = str(tmp_path / "empty.jf")
+    assert ctx.write_jfdump(path) == 0 and os.path.getsize(path) == 0
+    ctx2 = rc.Context(k=23)
+    assert ctx2.load_jfdump(path) == 0
+    assert ctx2.estimate_error_rate(0.95) == 0.01   # the reference's fallback (main.cpp:355-356)
