@@ -21,7 +21,15 @@ struct DevWaveT {
     unsigned long long t_last = 0;
     int cur_phase = 0;
     unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#ifdef RC_EXP_ROUNDS  // dev builds: gather rounds per read, reported in place of l (tools/rounds_hist.py)
+    int rounds = 0;
+    __device__ __forceinline__ void stat(int i, int v)
+    {
+        if (i == 3) rounds += v;
+    }
+#else
     __device__ __forceinline__ void stat(int, int) {}
+#endif
     // trace record of the current read: [0] flags (bit 0: passed the screens, i.e. "Before
     // correction" is printed), [1] iterations seen, then RC_TRACE_WORDS per recorded iteration:
     // strong, trust, has_bitmap, 0, 32 words of the per-base "strong trusted" bitmap
@@ -514,7 +522,12 @@ __global__ __launch_bounds__(64, RC_K3_WAVES) void k_correct(rc_kernel_args A)
         rc_kmer_info(w, S, A.P, ret, &l, &m, &h);
         if (w.lane == 0) {
             A.ret[r] = ret;
+#ifdef RC_EXP_ROUNDS
+            A.l[r] = w.rounds;
+            w.rounds = 0;
+#else
             A.l[r] = l;
+#endif
             A.m[r] = m;
             A.h[r] = h;
         }
