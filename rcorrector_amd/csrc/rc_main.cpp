@@ -881,11 +881,20 @@ int main(int argc, char **argv)
                     const uint32_t *L = b.line.data() + r * (size_t)lpr;
                     const uint32_t sl = L[2] - L[1] - 1, ql = lpr == 4 ? L[4] - L[3] - 1 : 0;
                     ++total;
-                    if (sl == 0 || lpr != 4) continue;
+                    if (lpr != 4) continue;
                     const char *q = b.text.data() + L[3];
-                    // qual[strlen(seq)-1] and qual[0] of the reference's fgets buffers
-                    const unsigned char lastq = sl - 1 < ql ? (unsigned char)q[sl - 1] : (sl - 1 == ql ? (unsigned char)'\n' : 0);
-                    const unsigned char firstq = ql ? (unsigned char)q[0] : (unsigned char)'\n';
+                    // qual[strlen(seq)-1] and qual[0] of the reference's fgets buffers.  An empty
+                    // sequence line: its "\n" makes Reads::Next strip qual[0] if that is the
+                    // newline of an empty quality line too (Reads.h:213-219), and qual[-1] is the
+                    // last byte of the sequence buffer in front of it, 0.
+                    unsigned char lastq, firstq;
+                    if (sl == 0) {
+                        lastq = 0;
+                        firstq = ql ? (unsigned char)q[0] : 0;
+                    } else {
+                        lastq = sl - 1 < ql ? (unsigned char)q[sl - 1] : (sl - 1 == ql ? (unsigned char)'\n' : 0);
+                        firstq = ql ? (unsigned char)q[0] : (unsigned char)'\n';
+                    }
                     ++lh[lastq];
                     ++fh[firstq];
                 }

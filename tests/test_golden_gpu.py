@@ -120,3 +120,37 @@ def test_cli_unpaired_files_are_refused(tmp_path):
     p = subprocess.run([CLI, "-p", str(work / "reads_1.fq"), str(work / "reads_2.fq"), "-k", "23", "-c", os.path.join(src, "dump.jf"),
                         "-od", str(tmp_path / "out")], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert p.returncode == 1 and b"ERROR: The files are not paired!" in p.stderr
+
+
+def test_cli_empty_and_one_base_reads(oracle, tmp_path):
+    """Records whose sequence line is empty (or a single base) travel through packing, the kernels
+    and the writer like any other read (the reference prints them as unfixable, l/m/h 0)."""
+    import subprocess
+    import numpy as np
+    import synth
+    d = str(tmp_path)
+    s1, q1, _, _, _ = synth.make_reads(3, 200, 60, n_tx=3, l_tx=300, e=0.01)
+    keys, cnt = synth.count_kmers([s1], 23)
+    synth.write_dump(os.path.join(d, "d.jf"), keys, cnt, 23)
+    with open(os.path.join(d, "a.fq"), "wb") as f:
+        for i in range(len(s1)):
+            r, q = s1[i].tobytes(), q1[i].tobytes()
+            if i % 7 == 3:
+                r = q = b""
+            if i % 11 == 5:
+                r, q = r[:1], q[:1]
+            f.write(b"@r%d\n%s\n+\n%s\n" % (i, r, q))
+    outs = []
+    for name, binary, more in (("g", CLI, ["-batch", "32"]), ("c", oracle.CLI_BIN, [])):
+        od = os.path.join(d, name)
+        os.makedirs(od)
+        p = subprocess.run([binary, "-r", "a.fq", "-k", "23", "-c", "d.jf", "-od", od, "-verbose"] + more, cwd=d,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert p.returncode == 0, p.stderr.decode()
+        outs.append((open(os.path.join(od, "a.cor.fq"), "rb").read(), p.stderr, p.stdout))
+    for j, what in enumerate(("output", "stderr", "verbose transcript")):
+        if outs[0][j] != outs[1][j]:
+            a, b = outs[0][j].split(b"\n"), outs[1][j].split(b"\n")
+            k = next(i for i in range(min(len(a), len(b))) if a[i] != b[i]) if any(x != y for x, y in zip(a, b)) else min(len(a), len(b))
+            raise AssertionError("%s differs at line %d: gpu %r vs cpu %r (context %r)" % (what, k, a[k:k + 2], b[k:k + 2], b[max(0, k - 3):k]))
+    assert b"@r3 l:0 m:0 h:0 unfixable_error\n\n+\n\n" in outs[0][0]
