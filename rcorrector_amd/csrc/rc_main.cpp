@@ -869,6 +869,7 @@ int main(int argc, char **argv)
     if (!files.empty() && files[0].fastq) {
         std::vector<int32_t> fh(300, 0), lh(300, 0);
         int total = 0;
+        static char qbuf[MAX_READ_LENGTH];  // Reads::qual, reused from record to record
         for (size_t fi = 0; fi < files.size() && total < 1000000; ++fi) {
             Source s;
             s.open(files[fi].path);
@@ -883,18 +884,22 @@ int main(int argc, char **argv)
                     ++total;
                     if (lpr != 4) continue;
                     const char *q = b.text.data() + L[3];
-                    // qual[strlen(seq)-1] and qual[0] of the reference's fgets buffers.  An empty
-                    // sequence line: its "\n" makes Reads::Next strip qual[0] if that is the
-                    // newline of an empty quality line too (Reads.h:213-219), and qual[-1] is the
-                    // last byte of the sequence buffer in front of it, 0.
-                    unsigned char lastq, firstq;
-                    if (sl == 0) {
-                        lastq = 0;
-                        firstq = ql ? (unsigned char)q[0] : 0;
+                    // qual[strlen(seq)-1] and qual[0] as GetBadQuality sees them: Reads::Next reads every
+                    // quality line into ONE reused buffer (bytes behind a short line keep what earlier
+                    // records left there) and strips a newline only at index strlen(seq)
+                    // (Reads.h:204-219); qual[-1], for an empty sequence, is the last byte of the
+                    // sequence buffer in front of it, 0.
+                    const uint32_t qn = std::min<uint32_t>(ql, MAX_READ_LENGTH - 1);
+                    memcpy(qbuf, q, qn);
+                    if (qn + 1 < MAX_READ_LENGTH) {
+                        qbuf[qn] = '\n';
+                        qbuf[qn + 1] = 0;
                     } else {
-                        lastq = sl - 1 < ql ? (unsigned char)q[sl - 1] : (sl - 1 == ql ? (unsigned char)'\n' : 0);
-                        firstq = ql ? (unsigned char)q[0] : (unsigned char)'\n';
+                        qbuf[qn] = 0;
                     }
+                    if (sl < MAX_READ_LENGTH && qbuf[sl] == '\n') qbuf[sl] = 0;
+                    const unsigned char lastq = sl ? (unsigned char)qbuf[sl - 1] : 0;
+                    const unsigned char firstq = (unsigned char)qbuf[0];
                     ++lh[lastq];
                     ++fh[firstq];
                 }

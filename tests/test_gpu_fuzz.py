@@ -98,3 +98,23 @@ def test_cli_equals_oracle_cli_on_random_inputs(oracle, seed, tmp_path):
         assert outs["gpu"][1][f] == outs["cpu"][1][f], "%s differs (seed %d, args %s)" % (f, seed, args)
     assert outs["gpu"][0] == outs["cpu"][0], "stderr differs (seed %d)" % seed
     assert outs["gpu"][2] == outs["cpu"][2], "-verbose transcript differs (seed %d)" % seed
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(300, 340)))
+def test_cli_equals_oracle_cli_on_io_quirks(oracle, seed, tmp_path):
+    """Input quirks (tests/io_quirks.py: empty / one-base / k-long reads, quality lines of the wrong
+    length or empty, '+' lines with text, kilobyte headers, no final newline): the drop-in binary
+    against the oracle CLI, which tests/test_oracle_vs_ref.py pins to the reference on the same cases."""
+    import io_quirks
+    d = str(tmp_path)
+    args = io_quirks.make_case(seed, d)
+    res = []
+    for name, binary, more in (("gpu", CLI, ["-batch", "32"] if seed % 2 else []), ("cpu", oracle.CLI_BIN, [])):
+        od = os.path.join(d, name)
+        os.makedirs(od)
+        p = subprocess.run([binary] + args + ["-od", od, "-verbose"] + more, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        res.append((p.returncode, p.stderr, {f: open(os.path.join(od, f), "rb").read() for f in sorted(os.listdir(od))}, p.stdout))
+    assert res[0][0] == 0
+    for j, what in enumerate(("exit status", "stderr", "output files", "-verbose transcript")):
+        assert res[0][j] == res[1][j], "%s differs (seed %d)" % (what, seed)

@@ -26,3 +26,22 @@ def test_oracle_cli_equals_reference_on_random_inputs(oracle, seed, tmp_path):
     for f in outs["ref"][1]:
         assert outs["ref"][1][f] == outs["cpu"][1][f], "%s differs (seed %d, args %s)" % (f, seed, args)
     assert outs["ref"][0] == outs["cpu"][0], "stderr differs (seed %d)" % seed
+
+
+@pytest.mark.parametrize("seed", list(range(300, 330)))
+def test_oracle_cli_equals_reference_on_io_quirks(oracle, seed, tmp_path):
+    """Input quirks with defined behaviour in the reference (tests/io_quirks.py): the oracle's
+    command-line front end must write the reference's bytes and stderr lines."""
+    import io_quirks
+    import subprocess
+    if not os.path.exists(oracle.REF_BIN):
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    d = str(tmp_path)
+    args = io_quirks.make_case(seed, d)
+    res = []
+    for name, binary in (("ref", oracle.REF_BIN), ("ora", oracle.CLI_BIN)):
+        od = os.path.join(d, name)
+        os.makedirs(od)
+        p = subprocess.run([binary] + args + ["-od", od], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        res.append((p.returncode, p.stderr, {f: open(os.path.join(od, f), "rb").read() for f in sorted(os.listdir(od))}))
+    assert res[0][0] == 0 and res[0] == res[1]

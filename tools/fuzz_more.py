@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """One-off extended fuzz: tests/test_gpu_fuzz.py's random cases for an arbitrary seed range
-(GPU CLI vs the pinned CPU oracle CLI, every output byte, stderr and -verbose transcript)."""
+(GPU CLI vs the pinned CPU oracle CLI, every output byte, stderr and -verbose transcript).
+  fuzz_more.py LO HI        read-content fuzz
+  fuzz_more.py LO HI io     input-format quirks (tests/io_quirks.py)"""
 import os
 import subprocess
 import sys
@@ -14,12 +16,15 @@ from oracle import pyoracle  # noqa: E402
 
 pyoracle.build()
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
+io_mode = len(sys.argv) > 3 and sys.argv[3] == "io"   # tests/io_quirks.py cases instead of the read-content fuzz
+if io_mode:
+    import io_quirks  # noqa: E402
 bad = 0
 for seed in range(lo, hi):
     with tempfile.TemporaryDirectory() as d:
-        args = F._random_case(seed, d)
+        args = io_quirks.make_case(seed, d) if io_mode else F._random_case(seed, d)
         outs = {}
-        verbose = ["-verbose"] if seed % 3 == 0 else []
+        verbose = ["-verbose"] if (io_mode or seed % 3 == 0) else []
         for name, binary, more in (("gpu", F.CLI, ["-batch", "64"] if seed % 2 else []), ("cpu", pyoracle.CLI_BIN, ["-t", "2"])):
             od = os.path.join(d, name)
             os.makedirs(od)
