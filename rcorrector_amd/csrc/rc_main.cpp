@@ -213,6 +213,7 @@ struct Block {
     Buf text;
     std::vector<uint32_t> line;  // line i = text[line[i] .. line[i+1]-1), without its '\n'
     size_t records = 0;
+    bool unterminated_last = false;  // the file ended without a newline: the last line got one here
 };
 
 // positions of the '\n' bytes of p[lo, hi), appended to nl in ascending order
@@ -254,6 +255,7 @@ static void take_records(Source &s, size_t max_records, int lines_per_record, Bl
 {
     b.line.clear();
     b.records = 0;
+    b.unterminated_last = false;
     const size_t want_lines = max_records * (size_t)lines_per_record;
     std::vector<uint32_t> nl;  // newline positions found so far
     nl.reserve(std::min<size_t>(want_lines, (size_t)1 << 23) + 8);
@@ -287,6 +289,7 @@ static void take_records(Source &s, size_t max_records, int lines_per_record, Bl
             ++have;
             end = have;
             ++n_lines;
+            b.unterminated_last = true;
         }
         // a record cut short by the end of the file: its missing lines read as empty (fgets leaves "")
         while (n_lines % (size_t)lines_per_record) {
@@ -554,7 +557,9 @@ static inline void put_record(std::vector<char> &out, const Arena &A, size_t r, 
         *p++ = '\n';
         memcpy(p, q, ql);
         p += ql;
-        if (ql != sl) *p++ = '\n';  // fgets kept the quality line's own newline
+        // fgets kept the quality line's own newline (Reads.h strips it only at index strlen(seq)) --
+        // unless this is the last line of a file that does not end with one
+        if (ql != sl && !(A.blk.unterminated_last && r + 1 == A.n())) *p++ = '\n';
         *p++ = '\n';
     }
     out.resize((size_t)(p - out.data()));

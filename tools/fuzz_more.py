@@ -33,4 +33,14 @@ for seed in range(lo, hi):
         if outs["gpu"] != outs["cpu"]:
             bad += 1
             print("MISMATCH seed", seed, args, outs["gpu"][0], outs["cpu"][0], flush=True)
+            for j, what in ((1, "stderr"), (3, "stdout")):
+                if outs["gpu"][j] != outs["cpu"][j]:
+                    a, b = outs["gpu"][j].split(b"\n"), outs["cpu"][j].split(b"\n")
+                    i = next((i for i in range(min(len(a), len(b))) if a[i] != b[i]), min(len(a), len(b)))
+                    print("   %s line %d: gpu %r | cpu %r | before %r" % (what, i, a[i:i + 1], b[i:i + 1], b[max(0, i - 2):i]), flush=True)
+            for f in outs["cpu"][2]:
+                if outs["gpu"][2].get(f) != outs["cpu"][2][f]:
+                    a, b = outs["gpu"][2].get(f, b"").split(b"\n"), outs["cpu"][2][f].split(b"\n")
+                    i = next((i for i in range(min(len(a), len(b))) if a[i] != b[i]), min(len(a), len(b)))
+                    print("   %s line %d: gpu %r | cpu %r | before %r" % (f, i, a[i:i + 1], b[i:i + 1], b[max(0, i - 3):i]), flush=True)
 print("seeds %d..%d: %d mismatches" % (lo, hi, bad))
