@@ -37,7 +37,7 @@ def test_oracle_cli_equals_reference_on_io_quirks(oracle, seed, tmp_path):
     if not os.path.exists(oracle.REF_BIN):
         pytest.skip("oracle/_ref not built (needs /root/reference)")
     d = str(tmp_path)
-    args = io_quirks.make_case(seed, d)
+    args = io_quirks.make_case(seed, d, modes=(0, 1, 2))
     res = []
     for name, binary in (("ref", oracle.REF_BIN), ("ora", oracle.CLI_BIN)):
         od = os.path.join(d, name)

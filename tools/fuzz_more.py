@@ -14,6 +14,16 @@ for p in (ROOT, os.path.join(ROOT, "tools"), os.path.join(ROOT, "tests")):
 import test_gpu_fuzz as F  # noqa: E402
 from oracle import pyoracle  # noqa: E402
 
+def _content(path):
+    """file bytes; .gz outputs are compared after decompression (the drop-in binary writes parallel
+    gzip members, the reference one stream -- Reads.h:140-147 -- with identical content)"""
+    data = open(path, "rb").read()
+    if path.endswith(".gz"):
+        import gzip
+        return gzip.decompress(data)
+    return data
+
+
 pyoracle.build()
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
 io_mode = len(sys.argv) > 3 and sys.argv[3] == "io"   # tests/io_quirks.py cases instead of the read-content fuzz
@@ -22,14 +32,14 @@ if io_mode:
 bad = 0
 for seed in range(lo, hi):
     with tempfile.TemporaryDirectory() as d:
-        args = io_quirks.make_case(seed, d) if io_mode else F._random_case(seed, d)
+        args = io_quirks.make_case(seed, d, modes=(0, 1, 2)) if io_mode else F._random_case(seed, d)
         outs = {}
         verbose = ["-verbose"] if (io_mode or seed % 3 == 0) else []
         for name, binary, more in (("gpu", F.CLI, ["-batch", "64"] if seed % 2 else []), ("cpu", pyoracle.CLI_BIN, ["-t", "2"])):
             od = os.path.join(d, name)
             os.makedirs(od)
             p = subprocess.run([binary] + args + ["-od", od] + more + verbose, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-            outs[name] = (p.returncode, p.stderr, {f: open(os.path.join(od, f), "rb").read() for f in sorted(os.listdir(od))}, p.stdout)
+            outs[name] = (p.returncode, p.stderr, {f: _content(os.path.join(od, f)) for f in sorted(os.listdir(od))}, p.stdout)
         if outs["gpu"] != outs["cpu"]:
             bad += 1
             print("MISMATCH seed", seed, args, outs["gpu"][0], outs["cpu"][0], flush=True)
