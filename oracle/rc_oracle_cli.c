@@ -271,10 +271,32 @@ int main(int argc, char **argv)
                     }
                     m1->cor = rco_error_correction(&P, T, m1->id, m1->seq, m1->qual, t);
                     rco_kmer_information(&P, T, m1->seq, &m1->l, &m1->m, &m1->h);
+                    /* -verbose -stdout: the reference's -t 1 loop writes every record right after
+                     * its own trace (main.cpp:401-432), trace and record share stdout */
+                    if (verbose && use_stdout) {
+                        fflush(stdout);
+                        write_record(f, m1->id, m1->seq, m1->qual, m1->cor, m1->l, m1->m, m1->h);
+                        if (f->out == stdout) fflush(stdout);
+                    }
                     if (m2) {
                         m2->cor = rco_error_correction(&P, T, m2->id, m2->seq, m2->qual, t);
                         rco_kmer_information(&P, T, m2->seq, &m2->l, &m2->m, &m2->h);
+                        if (verbose && use_stdout) {
+                            fflush(stdout);
+                            write_record(f->paired ? g : f, m2->id, m2->seq, m2->qual, m2->cor, m2->l, m2->m, m2->h);
+                        }
                     }
+                }
+                if (verbose && use_stdout) {  /* already written; only the summary is left */
+                    for (int u = 0; u < n; ++u) {
+                        ++total_reads;
+                        if (a[u].cor > 0) total_cor += (unsigned)a[u].cor;
+                        if (f->paired) {
+                            ++total_reads;
+                            if (b[u].cor > 0) total_cor += (unsigned)b[u].cor;
+                        }
+                    }
+                    continue;
                 }
                 for (int u = 0; u < n; ++u) {
                     write_record(f, a[u].id, a[u].seq, a[u].qual, a[u].cor, a[u].l, a[u].m, a[u].h);

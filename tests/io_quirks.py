@@ -91,4 +91,16 @@ def make_case(seed, d, n=120, length=70, k=23, modes=(0,)):
             both = [x for pair in zip(rec1, rec2) for x in pair]
             _write(os.path.join(d, "a_il" + ext), both, rng.random() < 0.3 and lastq2 > 0, gz)
             args = ["-i", "a_il" + ext]
-    return args + ["-k", str(k), "-c", "d.jf"]
+    if len(modes) > 1 and rng.random() < 0.3:
+        # a second, single-end input in the same run (files are processed one after the other; the
+        # bad-quality scan covers the primary files in order, main.cpp:88-128)
+        s3, q3, _, _, _ = synth.make_reads(seed + 7919, n // 2, length, n_tx=3, l_tx=300, e=0.01)
+        rec3, lastq3 = _quirky_records(rng, s3, q3, k, b"")
+        _write(os.path.join(d, "b" + ext), rec3, rng.random() < 0.3 and lastq3 > 0, gz)
+        args = (["-r", "b" + ext] + args) if rng.random() < 0.5 else (args + ["-r", "b" + ext])
+    extra = []
+    if len(modes) > 1 and rng.random() < 0.2:
+        extra.append("-stdout")
+    if len(modes) > 1 and rng.random() < 0.2:
+        extra += ["-maxcorK", str(int(rng.integers(1, 7)))]
+    return args + ["-k", str(k), "-c", "d.jf"] + extra

@@ -42,6 +42,6 @@ def test_oracle_cli_equals_reference_on_io_quirks(oracle, seed, tmp_path):
     for name, binary in (("ref", oracle.REF_BIN), ("ora", oracle.CLI_BIN)):
         od = os.path.join(d, name)
         os.makedirs(od)
-        p = subprocess.run([binary] + args + ["-od", od], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
-        res.append((p.returncode, p.stderr, {f: open(os.path.join(od, f), "rb").read() for f in sorted(os.listdir(od))}))
+        p = subprocess.run([binary] + args + ["-od", od, "-verbose"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        res.append((p.returncode, p.stderr, {f: open(os.path.join(od, f), "rb").read() for f in sorted(os.listdir(od))}, p.stdout))
     assert res[0][0] == 0 and res[0] == res[1]
