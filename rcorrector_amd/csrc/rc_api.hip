@@ -623,7 +623,15 @@ int rc_correct_device(rc_ctx *ctx, const rc_device_batch *b)
     a.h = b->d_h;
     a.max_len = b->max_read_len;
     if ((rc = rc_launch_probe(ctx, b->d_seq, (size_t)b->nbytes, (int32_t *)ctx->counts.p))) return rc;
-    if (a.mode != 0 && (rc = rc_launch_threshold(ctx, a))) return rc;  // single-end: fused into k_correct
+    // thresholds: mates need each other's before either can be corrected, so paired / interleaved
+    // batches always run the threshold kernel first; single-end batches do too when every read fits
+    // the four-reads-per-wave kernel (cheaper there than inside k_correct), else k_correct computes them
+    ctx->thr_ready = false;
+    const bool quarter_ok = a.max_len <= 320 && a.max_len - ctx->k + 1 <= 256 && !getenv("RC_K2_WAVE_PER_READ");
+    if (a.mode != 0 || quarter_ok) {
+        if ((rc = rc_launch_threshold(ctx, a))) return rc;
+        ctx->thr_ready = true;
+    }
     if ((rc = rc_launch_correct(ctx, a))) return rc;
     return RC_OK;
 }

@@ -342,6 +342,7 @@ struct rc_kernel_args {
     uint32_t *work;
     int cap;
     unsigned long long *phase_cycles;  // [8], PROF builds only
+    int fused_front_end;               // 1: k_correct computes the read's own threshold (single-end, no threshold kernel ran)
     int32_t *trace;                    // TRACE builds only: n x (2 + trace_cap * RC_TRACE_WORDS) words
     int trace_cap;
 };
@@ -488,7 +489,7 @@ __global__ __launch_bounds__(64, RC_K3_WAVES) void k_correct(rc_kernel_args A)
         rc_load_read(w, A, S, r, w.lane, true);
         const uint32_t o = A.off[r];
         int strong0, info0;
-        if (A.mode == 0) {  // single-end: no mate to wait for, the threshold pass runs right here
+        if (A.fused_front_end) {  // single-end: no mate to wait for, the threshold pass runs right here
             w.phase(1);
             strong0 = rc_front_end(w, S, A.P, &info0);
         } else {
@@ -504,7 +505,7 @@ __global__ __launch_bounds__(64, RC_K3_WAVES) void k_correct(rc_kernel_args A)
             pair_t = rc_min(strong0, A.strong[r ^ 1u]);
         }
         w.phase(1);
-        if (A.mode != 0 && S.kcnt > 0 && !(info0 & 4)) rc_polya_flags(w, S, A.P.k);
+        if (!A.fused_front_end && S.kcnt > 0 && !(info0 & 4)) rc_polya_flags(w, S, A.P.k);
         const int ret = rc_correct_read(w, S, A.P, pair_t, strong0, info0);
         w.phase(6);
         w.sync();
@@ -590,6 +591,7 @@ static int fill_args(rc_ctx *ctx, const rc_device_batch_args &a, rc_kernel_args 
     A.phase_cycles = nullptr;
     A.trace = nullptr;
     A.trace_cap = 0;
+    A.fused_front_end = a.mode == 0 && !ctx->thr_ready;
     return RC_OK;
 }
 

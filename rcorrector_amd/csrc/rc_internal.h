@@ -90,6 +90,7 @@ struct rc_ctx {
     rc_dbuf counts;   // int32 per arena byte
     rc_dbuf strong;   // int32 per read
     rc_dbuf info;     // int32 per read
+    bool thr_ready = false;  // strong / info hold this batch's thresholds (the threshold kernel ran)
     rc_dbuf stack;    // search stack frames
     rc_dbuf work;     // work counters
     rc_dbuf h_seq, h_qual, h_off, h_res;  // device staging for the host-buffer entry point
