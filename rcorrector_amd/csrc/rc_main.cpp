@@ -1090,8 +1090,14 @@ int main(int argc, char **argv)
                 fflush(stdout);
             }
             const double tw0 = now_s();
-            if (!(g_verbose && g_stdout)) emit_slices(f, j->o1);
-            if (j->mode == 1 && !alternate) emit_slices(g2, j->o2);
+            if (j->mode == 1 && !alternate && !g_stdout) {  // two output files: written side by side
+                std::thread second([&]() { emit_slices(g2, j->o2); });
+                emit_slices(f, j->o1);
+                second.join();
+            } else {
+                if (!(g_verbose && g_stdout)) emit_slices(f, j->o1);
+                if (j->mode == 1 && !alternate) emit_slices(g2, j->o2);
+            }
             g_t_write += now_s() - tw0;
             for (size_t r = 0; r < j->ret.size(); ++r) {  // UpdateSummary, main.cpp:73-79
                 ++total_reads;

@@ -27,12 +27,13 @@ def main():
     ap.add_argument("--err", type=float, default=0.005)
     ap.add_argument("--dir", default="/tmp/rc_e2e")
     ap.add_argument("--cli-args", default="")
+    ap.add_argument("--paired", action="store_true", help="paired-end: --reads counts both mates, files x_1.fq / x_2.fq")
     ap.add_argument("--count", action="store_true", help="also run every variant without -c (k-mers counted by the CLI)")
     a = ap.parse_args()
     os.makedirs(a.dir, exist_ok=True)
     dev = torch.device("cuda", 0)
     n, L, k = a.reads, a.len, a.k
-    seq, qual = bench.synth_reads_gpu(77000, n, L, a.n_tx, 1500, 0.8, a.err, dev)
+    seq, qual = bench.synth_reads_gpu(77000, n, L, a.n_tx, 1500, 0.8, a.err, dev, paired=a.paired)
     ctx = rcorrector_amd.Context(k=k)
     nk = ctx.count_reads_device(seq, seq.numel(), 2)
     codes, counts = ctx.table_export()
@@ -48,24 +49,34 @@ def main():
                 f.write(b"".join(parts))
                 parts = []
         f.write(b"".join(parts))
-    # FASTQ with fixed-width ids: one numpy 2-D array
-    s = seq.view(n, L + 1)[:, :L].cpu().numpy()
-    q = qual.view(n, L + 1)[:, :L].cpu().numpy()
-    ids = np.char.zfill(np.arange(n).astype(str), 9)
-    idb = np.frombuffer("".join(ids.tolist()).encode(), dtype=np.uint8).reshape(n, 9)
-    rec = np.empty((n, 2 + 9 + 1 + L + 1 + 2 + L + 1), dtype=np.uint8)
-    c = 0
-    rec[:, 0] = ord('@'); rec[:, 1] = ord('r'); c = 2
-    rec[:, c:c + 9] = idb; c += 9
-    rec[:, c] = 10; c += 1
-    rec[:, c:c + L] = s; c += L
-    rec[:, c] = 10; c += 1
-    rec[:, c] = ord('+'); rec[:, c + 1] = 10; c += 2
-    rec[:, c:c + L] = q; c += L
-    rec[:, c] = 10
-    rec.tofile(os.path.join(a.dir, "x.fq"))
+    # FASTQ with fixed-width ids: one numpy 2-D array per file (paired: first mates, second mates)
+    S = seq.view(n, L + 1)[:, :L].cpu().numpy()
+    Q = qual.view(n, L + 1)[:, :L].cpu().numpy()
+
+    def write_fq(path, s, q):
+        m = len(s)
+        ids = np.char.zfill(np.arange(m).astype(str), 9)
+        idb = np.frombuffer("".join(ids.tolist()).encode(), dtype=np.uint8).reshape(m, 9)
+        rec = np.empty((m, 2 + 9 + 1 + L + 1 + 2 + L + 1), dtype=np.uint8)
+        rec[:, 0] = ord('@'); rec[:, 1] = ord('r'); c = 2
+        rec[:, c:c + 9] = idb; c += 9
+        rec[:, c] = 10; c += 1
+        rec[:, c:c + L] = s; c += L
+        rec[:, c] = 10; c += 1
+        rec[:, c] = ord('+'); rec[:, c + 1] = 10; c += 2
+        rec[:, c:c + L] = q; c += L
+        rec[:, c] = 10
+        rec.tofile(path)
+
+    if a.paired:
+        write_fq(os.path.join(a.dir, "x_1.fq"), S[:n // 2], Q[:n // 2])
+        write_fq(os.path.join(a.dir, "x_2.fq"), S[n // 2:], Q[n // 2:])
+        inputs, first_out = ["-p", "x_1.fq", "x_2.fq"], "x_1.cor.fq"
+    else:
+        write_fq(os.path.join(a.dir, "x.fq"), S, Q)
+        inputs, first_out = ["-r", "x.fq"], "x.cor.fq"
     print("generated %d reads, %d k-mers in %.1f s (fq %.0f MB, dump %.0f MB)" % (
-        n, nk, time.time() - t0, os.path.getsize(os.path.join(a.dir, "x.fq")) / 1e6,
+        n, nk, time.time() - t0, sum(os.path.getsize(os.path.join(a.dir, f)) for f in inputs[1:]) / 1e6,
         os.path.getsize(os.path.join(a.dir, "x.jf")) / 1e6), file=sys.stderr)
     del ctx
     cli = os.path.join(ROOT, "rcorrector_amd", "rcorrector")
@@ -77,11 +88,11 @@ def main():
             shutil.rmtree(a.dir + "/out", ignore_errors=True)   # truncating last run's multi-GB output is not part of the run
             os.sync()
             t0 = time.time()
-            p = subprocess.run([cli, "-r", "x.fq", "-k", str(k), "-od", a.dir + "/out"] + dump + variant.split(),
+            p = subprocess.run([cli] + inputs + ["-k", str(k), "-od", a.dir + "/out"] + dump + variant.split(),
                                cwd=a.dir, env=env, stderr=subprocess.PIPE)
             dt = time.time() - t0
             sys.stderr.write(p.stderr.decode())
-            md5 = hashlib.md5(open(a.dir + "/out/x.cor.fq", "rb").read()).hexdigest()
+            md5 = hashlib.md5(open(a.dir + "/out/" + first_out, "rb").read()).hexdigest()
             print("CLI [%s %s] wall %.2f s -> %.2f M reads/s end to end, output md5 %s" % (
                 " ".join(dump) or "(counting)", variant, dt, n / dt / 1e6, md5))
 
