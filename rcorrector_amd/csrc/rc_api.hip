@@ -7,7 +7,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <new>
+#include <unistd.h>
 #include <thread>
 #include <vector>
 
@@ -16,8 +18,12 @@
 
 // parsed dump kept between rc_table_load_jfdump() and rc_estimate_error_rate()
 struct rc_dump_cache {
-    std::vector<uint64_t> codes;  // forward code of every entry (file order), main.cpp:326-328
-    std::vector<int8_t> inv_mid;  // 1 if the entry holds a non-ACGT letter before its last base
+    // forward code of every entry (file order), main.cpp:326-328, and a flag "holds a non-ACGT
+    // letter before its last base" -- kept in the chunks the parser threads produced (concatenating
+    // a few hundred MB on one thread cost more than parsing them on thirty-two)
+    std::vector<std::vector<uint64_t>> codes;
+    std::vector<std::vector<int8_t>> inv_mid;
+    size_t n = 0;
     int load_state_invalid = 0;   // validity of the KmerCode object the load pass leaves behind
     bool valid = false;
 };
@@ -177,20 +183,64 @@ int rc_table_load_jfdump(rc_ctx *c, const char *path, int64_t *stored)
     fseek(fp, 0, SEEK_END);
     long sz = ftell(fp);
     fseek(fp, 0, SEEK_SET);
-    std::vector<char> buf((size_t)sz + 1);
-    if (sz > 0 && fread(buf.data(), 1, (size_t)sz, fp) != (size_t)sz) {
+    // the whole text, uninitialised and read by several threads at once (pread into disjoint slices:
+    // a single reader is bound by the copy out of the page cache)
+    struct text_buf {
+        char *p = nullptr;
+        ~text_buf() { free(p); }
+        char *data() { return p; }
+        char &operator[](size_t i) { return p[i]; }
+    } buf;
+    buf.p = (char *)malloc((size_t)sz + 1);
+    if (!buf.p) {
         fclose(fp);
-        rc_set_error(ctx, "short read on %s", path);
-        return RC_ERR_IO;
+        rc_set_error(ctx, "out of memory reading %s (%ld bytes)", path, sz);
+        return RC_ERR_NOMEM;
     }
-    fclose(fp);
+    {
+        const int fd = fileno(fp);
+        unsigned RT = std::thread::hardware_concurrency();
+        if (RT == 0) RT = 4;
+        if (RT > 32) RT = 32;
+        if ((size_t)sz < ((size_t)8 << 20)) RT = 1;
+        std::vector<char> ok(RT, 1);
+        auto rd = [&](unsigned t) {
+            size_t at = (size_t)sz * t / RT;
+            const size_t hi = (size_t)sz * (t + 1) / RT;
+            while (at < hi) {
+                const ssize_t n = pread(fd, buf.p + at, hi - at, (off_t)at);
+                if (n <= 0) {
+                    ok[t] = 0;
+                    return;
+                }
+                at += (size_t)n;
+            }
+        };
+        if (RT == 1) {
+            rd(0);
+        } else {
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < RT; ++t) th.emplace_back(rd, t);
+            for (auto &x : th) x.join();
+        }
+        fclose(fp);
+        for (unsigned t = 0; t < RT; ++t)
+            if (!ok[t]) {
+                rc_set_error(ctx, "short read on %s", path);
+                return RC_ERR_IO;
+            }
+    }
     buf[(size_t)sz] = 0;
+    const bool tm = getenv("RC_TIMING") != nullptr;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_read = now();
 
     const int k = ctx->k;
     const uint64_t mask = rc_kmer_mask(k);
     rc_dump_cache &D = ctx->dump;
     D.codes.clear();
     D.inv_mid.clear();
+    D.n = 0;
     D.load_state_invalid = 0;
     auto is_ws = [](char ch) { return ch == ' ' || ch == '\n' || ch == '\t' || ch == '\r' || ch == '\f' || ch == '\v'; };
 
@@ -216,6 +266,22 @@ int rc_table_load_jfdump(rc_ctx *c, const char *path, int64_t *stored)
         cut[t] = pos;
     }
     std::vector<piece> pieces(T);
+    int8_t base_code[256];
+    memset(base_code, -1, sizeof base_code);
+    base_code[(unsigned char)'A'] = 0;
+    base_code[(unsigned char)'C'] = 1;
+    base_code[(unsigned char)'G'] = 2;
+    base_code[(unsigned char)'T'] = 3;
+    // atoi() as glibc implements it, (int)strtol(): the long value saturates at LONG_MAX / LONG_MIN and
+    // the conversion to int keeps its low 32 bits (main.cpp:297 applies it to the count token)
+    auto atoi_of = [](unsigned long long v, bool ovf, bool neg) -> int {
+        long long lv;
+        if (ovf)
+            lv = neg ? (long long)0x8000000000000000ULL : 0x7fffffffffffffffLL;
+        else
+            lv = neg ? -(long long)v : (long long)v;
+        return (int)(uint32_t)(uint64_t)lv;
+    };
     auto parse = [&](unsigned t) {
         piece &P = pieces[t];
         const char *p = buf.data() + cut[t], *end = buf.data() + cut[t + 1];
@@ -225,24 +291,62 @@ int rc_table_load_jfdump(rc_ctx *c, const char *path, int64_t *stored)
         P.put_codes.reserve(guess);
         P.put_counts.reserve(guess);
         while (true) {
+            // fast path for the layout `jellyfish dump` writes: ">DIGITS\nKMER\n" with exactly k
+            // letters out of ACGT -- everything else goes through the general tokeniser below,
+            // which is what defines the result
+            if (p < end && *p == '>' && p + 1 < end && (unsigned)(p[1] - '0') <= 9u) {
+                const char *q = p + 1;
+                unsigned long long v = 0;
+                bool ovf = false;
+                while (q < end && (unsigned)(*q - '0') <= 9u) {
+                    const unsigned d = (unsigned)(*q - '0');
+                    if (v > (0x7fffffffffffffffULL - d) / 10) ovf = true;
+                    if (!ovf) v = v * 10 + d;
+                    ++q;
+                }
+                const int cnt = atoi_of(v, ovf, false);
+                if (q < end && *q == '\n' && q + 1 + k < end && q[1 + k] == '\n') {
+                    const unsigned char *s2 = reinterpret_cast<const unsigned char *>(q + 1);
+                    uint64_t code = 0;
+                    int bad = 0;
+                    for (int i = 0; i < k; ++i) {
+                        const int b = base_code[s2[i]];
+                        bad |= b;
+                        code = (code << 2) | (uint64_t)(b & 3);
+                    }
+                    if (bad >= 0) {  // all four codes are non-negative: no other letter in the k-mer
+                        p = q + 2 + k;
+                        P.codes.push_back(code);
+                        P.inv_mid.push_back(0);
+                        if (cnt <= 1) continue;
+                        P.last_state_invalid = 0;
+                        ++P.accepted;
+                        P.put_codes.push_back(code);
+                        P.put_counts.push_back((int32_t)cnt);
+                        continue;
+                    }
+                }
+            }
             while (p < end && is_ws(*p)) ++p;
             if (p >= end) break;
             const char *t0 = p;
             while (p < end && !is_ws(*p)) ++p;
-            long long cnt = 0;  // atoi(&token[1])
+            int cnt = 0;  // atoi(&token[1])
             {
                 const char *q = t0 + 1;
-                bool neg = false;
+                bool neg = false, ovf = false;
+                unsigned long long v = 0;
                 if (q < p && (*q == '-' || *q == '+')) {
                     neg = *q == '-';
                     ++q;
                 }
                 while (q < p && *q >= '0' && *q <= '9') {
-                    cnt = cnt * 10 + (*q - '0');
-                    if (cnt > 0x7fffffffLL) cnt = 0x7fffffffLL;
+                    const unsigned d = (unsigned)(*q - '0');
+                    if (v > (0x7fffffffffffffffULL - d) / 10) ovf = true;
+                    if (!ovf) v = v * 10 + d;
                     ++q;
                 }
-                if (neg) cnt = -cnt;
+                cnt = atoi_of(v, ovf, neg);
             }
             while (p < end && is_ws(*p)) ++p;
             const char *k0 = p;
@@ -281,31 +385,39 @@ int rc_table_load_jfdump(rc_ctx *c, const char *path, int64_t *stored)
         for (unsigned t = 0; t < T; ++t) th.emplace_back(parse, t);
         for (auto &x : th) x.join();
     }
-    std::vector<uint64_t> put_codes;
-    std::vector<int32_t> put_counts;
     int64_t accepted = 0;
-    {
-        size_t n_all = 0, n_put = 0;
-        for (auto &P : pieces) {
-            n_all += P.codes.size();
-            n_put += P.put_codes.size();
-        }
-        D.codes.reserve(n_all);
-        D.inv_mid.reserve(n_all);
-        put_codes.reserve(n_put);
-        put_counts.reserve(n_put);
-        for (auto &P : pieces) {
-            D.codes.insert(D.codes.end(), P.codes.begin(), P.codes.end());
-            D.inv_mid.insert(D.inv_mid.end(), P.inv_mid.begin(), P.inv_mid.end());
-            put_codes.insert(put_codes.end(), P.put_codes.begin(), P.put_codes.end());
-            put_counts.insert(put_counts.end(), P.put_counts.begin(), P.put_counts.end());
-            accepted += P.accepted;
-            if (P.last_state_invalid >= 0) D.load_state_invalid = P.last_state_invalid;
-            P = piece();
-        }
+    size_t n_put = 0;
+    for (auto &P : pieces) {
+        D.n += P.codes.size();
+        n_put += P.put_codes.size();
+        accepted += P.accepted;
+        if (P.last_state_invalid >= 0) D.load_state_invalid = P.last_state_invalid;
     }
+    const double t_parse = now();
     if (stored) *stored = accepted;
-    int rc = rc_table_build(ctx, put_codes.data(), put_counts.data(), put_codes.size());
+    // n x Store::Put in file order: the pieces go to the device one after the other, no host copy
+    int rc = RC_OK;
+    {
+        rc_dev_tmp b_codes, b_counts;
+        RC_CHECK_HIP(ctx, b_codes.alloc(n_put * 8));
+        RC_CHECK_HIP(ctx, b_counts.alloc(n_put * 4));
+        size_t at = 0;
+        for (auto &P : pieces) {
+            const size_t m = P.put_codes.size();
+            if (m) {
+                RC_CHECK_HIP(ctx, hipMemcpyAsync(b_codes.as<uint64_t>() + at, P.put_codes.data(), m * 8, hipMemcpyHostToDevice, ctx->stream));
+                RC_CHECK_HIP(ctx, hipMemcpyAsync(b_counts.as<int32_t>() + at, P.put_counts.data(), m * 4, hipMemcpyHostToDevice, ctx->stream));
+            }
+            at += m;
+        }
+        rc = rc_table_build_device(ctx, b_codes.as<uint64_t>(), b_counts.as<int32_t>(), n_put);
+        RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the pieces' host arrays are released below
+    }
+    for (auto &P : pieces) {
+        D.codes.emplace_back(std::move(P.codes));
+        D.inv_mid.emplace_back(std::move(P.inv_mid));
+    }
+    if (tm) fprintf(stderr, "[rc timing] dump: parse %.2f s, table build %.2f s\n", t_parse - t_read, now() - t_parse);
     D.valid = rc == RC_OK;  // (rc_table_build drops the cache of an earlier dump)
     return rc;
 }
@@ -518,20 +630,26 @@ int rc_estimate_error_rate(rc_ctx *c, double wk, double *rate_out)
         // no dump file was read (the table was counted here or handed over as arrays): scan the
         // entries in the order rc_table_write_jfdump would write them -- what the reference would
         // see if it were given that dump
-        int rc = rc_table_entries_in_dump_order(ctx, &ctx->dump.codes, nullptr);
+        ctx->dump.codes.assign(1, std::vector<uint64_t>());
+        int rc = rc_table_entries_in_dump_order(ctx, &ctx->dump.codes[0], nullptr);
         if (rc) return rc;
-        ctx->dump.inv_mid.assign(ctx->dump.codes.size(), 0);
+        ctx->dump.n = ctx->dump.codes[0].size();
+        ctx->dump.inv_mid.assign(1, std::vector<int8_t>(ctx->dump.n, 0));
         ctx->dump.load_state_invalid = 0;
         ctx->dump.valid = true;
     }
     const rc_dump_cache &D = ctx->dump;
-    const size_t n = D.codes.size();
+    const size_t n = D.n;
     std::vector<int32_t> mx2(2 * n);
     if (n) {
         rc_dev_tmp b_codes, b_out;
         RC_CHECK_HIP(ctx, b_codes.alloc(n * 8));
         RC_CHECK_HIP(ctx, b_out.alloc(n * 8));
-        RC_CHECK_HIP(ctx, hipMemcpyAsync(b_codes.p, D.codes.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
+        size_t at = 0;
+        for (const auto &ch : D.codes) {
+            if (!ch.empty()) RC_CHECK_HIP(ctx, hipMemcpyAsync(b_codes.as<uint64_t>() + at, ch.data(), ch.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+            at += ch.size();
+        }
         int rc = rc_launch_last_base_variants(ctx, b_codes.as<uint64_t>(), n, b_out.as<int32_t>());
         if (rc) return rc;
         RC_CHECK_HIP(ctx, hipMemcpyAsync(mx2.data(), b_out.p, n * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -542,15 +660,18 @@ int rc_estimate_error_rate(rc_ctx *c, double wk, double *rate_out)
     double *r = store.data() + 1;  // r[-1] readable, as in the reference when k == 0
     int cnt = 0;
     bool state_invalid = D.load_state_invalid != 0;  // the IsValid() test at main.cpp:323
-    for (size_t i = 0; i < n && cnt < rate_size; ++i) {
-        if (state_invalid) continue;
-        if (D.inv_mid[i]) {  // this entry leaves an invalid KmerCode behind: everything after is skipped
-            state_invalid = true;
-            continue;
+    size_t i = 0;
+    for (size_t c = 0; c < D.inv_mid.size() && cnt < rate_size && !state_invalid; ++c) {
+        const std::vector<int8_t> &inv = D.inv_mid[c];
+        for (size_t j = 0; j < inv.size() && cnt < rate_size; ++j, ++i) {
+            if (inv[j]) {  // this entry leaves an invalid KmerCode behind: everything after is skipped
+                state_invalid = true;
+                break;
+            }
+            const int mx = mx2[2 * i], second = mx2[2 * i + 1];
+            if (mx < 1000) continue;
+            r[cnt++] = (double)second / (double)mx;
         }
-        const int mx = mx2[2 * i], second = mx2[2 * i + 1];
-        if (mx < 1000) continue;
-        r[cnt++] = (double)second / (double)mx;
     }
     qsort(r, (size_t)cnt, sizeof(double), cmp_double);
     r[cnt] = r[cnt - 1];

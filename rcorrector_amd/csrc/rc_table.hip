@@ -191,13 +191,32 @@ int rc_launch_last_base_variants(rc_ctx *ctx, const uint64_t *d_codes, size_t n,
 }
 
 // every stored (canonical code, count) pair, in unspecified order (jf_dump writer / test support)
-__global__ void k_export(const uint32_t *__restrict__ buckets, size_t nslots, uint64_t *__restrict__ codes,
+__global__ void k_export(const uint32_t *__restrict__ buckets, size_t nslots, uint32_t nb_home, uint64_t *__restrict__ codes,
                          int32_t *__restrict__ counts, unsigned long long *__restrict__ n_out, size_t cap)
 {
     size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nslots) return;
     const uint32_t *w = buckets + (s / RC_BUCKET_SLOTS) * RC_BUCKET_DWORDS + (s % RC_BUCKET_SLOTS) * 3;
     if (w[2] == 0) return;
+    // a key that was Put more than once occupies several slots; the one a probe reaches first (the
+    // latest Put, Store.h:55) is the table's entry, the others are dead: walk the probe sequence
+    // from the key's home bucket and keep this slot only if it is the first match
+    {
+        const uint64_t key = ((uint64_t)w[1] << 32) | w[0];
+        size_t b = rc_home(key, nb_home);
+        for (;;) {
+            const uint32_t *q = buckets + b * RC_BUCKET_DWORDS;
+            bool found = false;
+            for (int i = 0; i < RC_BUCKET_SLOTS; ++i)
+                if (q[3 * i + 2] != 0 && q[3 * i] == w[0] && q[3 * i + 1] == w[1]) {
+                    if (b * RC_BUCKET_SLOTS + (size_t)i != s) return;  // shadowed by an earlier slot
+                    found = true;
+                    break;
+                }
+            if (found) break;
+            ++b;  // (the slot exists, so the walk ends at it at the latest)
+        }
+    }
     unsigned long long at = atomicAdd(n_out, 1ull);
     if (at < cap) {
         codes[at] = ((uint64_t)w[1] << 32) | w[0];
@@ -208,7 +227,7 @@ __global__ void k_export(const uint32_t *__restrict__ buckets, size_t nslots, ui
 int rc_launch_export(rc_ctx *ctx, uint64_t *d_codes, int32_t *d_counts, unsigned long long *d_n, size_t cap)
 {
     const size_t nslots = (size_t)ctx->nb_alloc * RC_BUCKET_SLOTS;
-    hipLaunchKernelGGL(k_export, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_buckets, nslots, d_codes, d_counts, d_n, cap);
+    hipLaunchKernelGGL(k_export, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_buckets, nslots, ctx->nb_home, d_codes, d_counts, d_n, cap);
     RC_CHECK_HIP(ctx, hipGetLastError());
     return RC_OK;
 }

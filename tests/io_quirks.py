@@ -104,3 +104,55 @@ def make_case(seed, d, n=120, length=70, k=23, modes=(0,)):
     if len(modes) > 1 and rng.random() < 0.2:
         extra += ["-maxcorK", str(int(rng.integers(1, 7)))]
     return args + ["-k", str(k), "-c", "d.jf"] + extra
+
+
+def make_quirky_dump(seed, path, k=23, n=4000, mid_n=True):
+    """A k-mer dump in the layout `jellyfish dump` writes with departures from it sprinkled in --
+    what main.cpp:295-307 (two fscanf("%s") per entry, atoi on the first, every letter of the second
+    pushed through KmerCode) accepts: blanks and tabs between tokens, empty lines, signs and trailing
+    junk in the count, counts of 0 / 1 (dropped) and beyond int range, k-mers that are too long or too
+    short or hold N, repeated k-mers (the later count wins), no final newline.
+    mid_n=False leaves out the k-mers with an N before their last base: the first of them ends the
+    ERROR_RATE scan (the KmerCode object stays invalid, main.cpp:323), so the estimate falls back to
+    0.01 for most dumps that hold one."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    codes = rng.integers(0, 4, size=(n, k), dtype=np.uint8)
+    kmers = [synth.NUC[c].tobytes() for c in codes]
+    out = []
+    for i, km in enumerate(kmers):
+        cnt = int(rng.choice([0, 1, 2, 3, 7, 50, 1200, 5000, 70000]))
+        head = b">%d" % cnt
+        sep1, sep2 = b"\n", b"\n"
+        if rng.random() < 0.15:
+            u = int(rng.integers(0, 10))
+            if u == 0:
+                head = b">+%d" % cnt
+            elif u == 1:
+                head = b">%dx7" % cnt
+            elif u == 2:
+                sep1 = b" "
+            elif u == 3:
+                sep1, sep2 = b"\t", b"\n\n"
+            elif u == 4 and mid_n:
+                km = km[:10] + b"N" + km[11:]
+            elif u == 5:
+                km = km + b"ACG"
+            elif u == 6:
+                km = km[:k - 2]
+            elif u == 7:
+                km = kmers[int(rng.integers(0, i + 1))]     # an earlier k-mer again
+            elif u == 8:
+                head = b">99999999999"
+            elif u == 9:
+                km = km[:k - 1] + b"N"
+        out.append(head + sep1 + km + sep2)
+        if cnt >= 1000 and len(km) == k and rng.random() < 0.5:
+            # a sibling that differs in the last base, with a smaller count: what the ERROR_RATE pass
+            # (main.cpp:310-358) looks for
+            sib = km[:-1] + (b"A" if km[-1:] != b"A" else b"C")
+            out.append(b">%d\n" % (cnt // int(rng.integers(20, 400)) + 2) + sib + b"\n")
+    data = b"".join(out)
+    if rng.random() < 0.5:
+        data = data.rstrip(b"\n")
+    with open(path, "wb") as f:
+        f.write(data)

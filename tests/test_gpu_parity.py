@@ -339,3 +339,25 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     assert d["config"]["reads_per_gpu"] == 400000 and "x2" in d["config"]["parallelism"]
     assert abs(d["value"] - 2 * 400000 * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 1e-6
     assert 0.2 < d["config"]["reads_corrected_frac"] < 0.9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(400, 420)))
+def test_jfdump_loader_on_quirky_dumps(gpu_ctx_factory, oracle, seed, tmp_path):
+    """The multi-threaded dump parser (fast path for the clean layout, general tokeniser for the
+    rest) against the oracle's loader -- itself pinned to the reference on the same dumps
+    (tests/test_oracle_vs_ref.py): number stored, every count, ERROR_RATE."""
+    import io_quirks
+    path = str(tmp_path / "d.jf")
+    io_quirks.make_quirky_dump(seed, path, n=60000 if seed % 4 == 0 else 4000, mid_n=seed % 2 == 0)   # some above the parser's threading threshold
+    T = oracle.Table(23, 1 << 12)
+    stored = T.load_dump(path)
+    want_rate = T.error_rate(path, 0.5)
+    ctx = gpu_ctx_factory(23)
+    assert ctx.load_jfdump(path) == stored
+    assert ctx.estimate_error_rate(0.5) == want_rate   # (0.01 fallback for some seeds, estimated for others)
+    codes, counts = T.export()
+    assert np.array_equal(ctx.lookup(codes), counts)
+    got_c, got_n = ctx.table_export()
+    o1, o2 = np.argsort(got_c), np.argsort(codes)
+    assert np.array_equal(got_c[o1], codes[o2]) and np.array_equal(got_n[o1], counts[o2])

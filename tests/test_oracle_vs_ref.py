@@ -45,3 +45,26 @@ def test_oracle_cli_equals_reference_on_io_quirks(oracle, seed, tmp_path):
         p = subprocess.run([binary] + args + ["-od", od, "-verbose"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
         res.append((p.returncode, p.stderr, {f: open(os.path.join(od, f), "rb").read() for f in sorted(os.listdir(od))}, p.stdout))
     assert res[0][0] == 0 and res[0] == res[1]
+
+
+@pytest.mark.parametrize("seed", list(range(400, 412)))
+def test_oracle_dump_loader_equals_reference_on_quirky_dumps(oracle, seed, tmp_path):
+    """tests/io_quirks.py: make_quirky_dump -- 'Stored N kmers', the ERROR_RATE estimate and the
+    corrected reads must be the reference's when the dump departs from the clean jellyfish layout."""
+    import io_quirks
+    import subprocess
+    import synth
+    if not os.path.exists(oracle.REF_BIN):
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    d = str(tmp_path)
+    io_quirks.make_quirky_dump(seed, os.path.join(d, "d.jf"), mid_n=seed % 2 == 0)
+    s1, q1, _, _, _ = synth.make_reads(seed, 30, 60, n_tx=2, l_tx=200, e=0.01)
+    synth.write_fastq(os.path.join(d, "a.fq"), s1, q1)
+    res = []
+    for name, binary in (("ref", oracle.REF_BIN), ("ora", oracle.CLI_BIN)):
+        od = os.path.join(d, name)
+        os.makedirs(od)
+        p = subprocess.run([binary, "-r", "a.fq", "-k", "23", "-c", "d.jf", "-od", od, "-wk", "0.5"], cwd=d,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        res.append((p.returncode, p.stderr, open(os.path.join(od, "a.cor.fq"), "rb").read()))
+    assert res[0][0] == 0 and res[0] == res[1]
