@@ -64,3 +64,36 @@ def test_product_sources_do_not_reference_the_oracle():
                     if re.search(r"pyoracle|liboracle|rc_oracle|rco_|import oracle|from oracle", t):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_bad_quality_from_hist_equals_oracle(built, oracle):
+    """GetBadQuality's arithmetic (main.cpp:108-127) is host code of the library: random
+    histograms (spiky, flat, empty, all in one bin, totals that do not match the bins) through
+    rc_bad_quality_from_hist and through the oracle's restatement."""
+    import ctypes as C
+    import numpy as np
+    L = built.load_library()
+    O = oracle.lib()
+    rng = np.random.Generator(np.random.PCG64(5))
+    for it in range(2000):
+        kind = it % 5
+        fh = np.zeros(300, dtype=np.int32)
+        lh = np.zeros(300, dtype=np.int32)
+        if kind == 0:
+            fh[rng.integers(33, 75, size=1000)] += 1
+            lh[rng.integers(33, 75, size=1000)] += 1
+        elif kind == 1:
+            fh[int(rng.integers(0, 300))] = int(rng.integers(1, 10 ** 6))
+            lh[int(rng.integers(0, 300))] = int(rng.integers(1, 10 ** 6))
+        elif kind == 2:
+            fh[:] = rng.integers(0, 50, size=300)
+            lh[:] = rng.integers(0, 50, size=300)
+        elif kind == 3:
+            pass
+        else:
+            np.add.at(fh, rng.integers(0, 300, size=200), 1)
+            np.add.at(lh, rng.integers(0, 300, size=200), 1)
+        total = int(fh.sum()) if kind != 4 else int(rng.integers(0, 2000))
+        a = L.rc_bad_quality_from_hist(fh.ctypes.data, lh.ctypes.data, total)
+        b = O.rco_bad_quality_from_hist(fh.ctypes.data, lh.ctypes.data, total)
+        assert a == b, (it, a, b)
