@@ -24,12 +24,12 @@ def _content(path):
     return data
 
 
-def _random_case(seed, d):
+def _random_case(seed, d, max_len=160):
     rng = np.random.Generator(np.random.PCG64(seed))
     k = int(rng.choice([15, 19, 23, 27, 31, 32]))
     mode = int(rng.integers(0, 3))
     n = int(rng.integers(1, 400))
-    L = int(rng.integers(k + 5, 160))
+    L = int(rng.integers(k + 5, max_len))
     e = float(rng.choice([0.0, 0.005, 0.02, 0.06]))
     n_tx = int(rng.integers(1, 12))
     s1, q1, s2, q2, _ = synth.make_reads(seed, n, L, n_tx=n_tx, l_tx=max(400, 2 * L + 10), e=e, paired=mode != 0,

@@ -2,7 +2,8 @@
 """One-off extended fuzz: tests/test_gpu_fuzz.py's random cases for an arbitrary seed range
 (GPU CLI vs the pinned CPU oracle CLI, every output byte, stderr and -verbose transcript).
   fuzz_more.py LO HI        read-content fuzz
-  fuzz_more.py LO HI io     input-format quirks (tests/io_quirks.py)"""
+  fuzz_more.py LO HI io     input-format quirks (tests/io_quirks.py)
+  fuzz_more.py LO HI long   read-content fuzz with read lengths up to 1023"""
 import os
 import subprocess
 import sys
@@ -26,13 +27,14 @@ def _content(path):
 
 pyoracle.build()
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
-io_mode = len(sys.argv) > 3 and sys.argv[3] == "io"   # tests/io_quirks.py cases instead of the read-content fuzz
+io_mode = len(sys.argv) > 3 and sys.argv[3] == "io"
+long_mode = len(sys.argv) > 3 and sys.argv[3] == "long"   # reads of up to 1023 bases   # tests/io_quirks.py cases instead of the read-content fuzz
 if io_mode:
     import io_quirks  # noqa: E402
 bad = 0
 for seed in range(lo, hi):
     with tempfile.TemporaryDirectory() as d:
-        args = io_quirks.make_case(seed, d, modes=(0, 1, 2)) if io_mode else F._random_case(seed, d)
+        args = io_quirks.make_case(seed, d, modes=(0, 1, 2)) if io_mode else F._random_case(seed, d, max_len=1024 if long_mode else 160)
         outs = {}
         verbose = ["-verbose"] if (io_mode or seed % 3 == 0) else []
         for name, binary, more in (("gpu", F.CLI, ["-batch", "64"] if seed % 2 else []), ("cpu", pyoracle.CLI_BIN, ["-t", "2"])):
