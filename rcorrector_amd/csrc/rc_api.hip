@@ -111,13 +111,17 @@ rc_ctx *rc_create(const rc_config *cfg, char *errbuf, size_t errbuf_len)
     if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
-        hipMalloc(&ctx->work.p, 256) != hipSuccess) {
+        hipMalloc(&ctx->work.p, RC_WORK_BYTES) != hipSuccess) {
         delete ctx;
         return fail("rc_create: could not create stream/events");
     }
-    ctx->work.bytes = 256;
+    ctx->work.bytes = RC_WORK_BYTES;
     if (const char *e = getenv("RC_PHASE_PROF")) ctx->phase_prof = atoi(e) != 0;
     if (const char *e = getenv("RC_TABLE_LOAD")) ctx->table_load = atof(e);  // tuning knob
+    ctx->env_k2_wave_per_read = getenv("RC_K2_WAVE_PER_READ") != nullptr;  // dev: force the wave-per-read threshold kernel
+    ctx->env_no_classify = getenv("RC_NO_CLASSIFY") != nullptr;            // dev: every read goes through k_correct
+    ctx->env_timing = getenv("RC_TIMING") != nullptr;
+    if (const char *e = getenv("RC_K3_GRID_WAVES")) ctx->env_k3_grid_waves = atoi(e);
     return ctx;
 }
 
@@ -128,7 +132,7 @@ void rc_destroy(rc_ctx *c)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     rc_dbuf *bufs[] = {&ctx->counts, &ctx->strong, &ctx->info, &ctx->stack, &ctx->work,
-                       &ctx->h_seq, &ctx->h_qual, &ctx->h_off, &ctx->h_res, &ctx->trace};
+                       &ctx->h_seq, &ctx->h_qual, &ctx->h_off, &ctx->h_res, &ctx->trace, &ctx->cls, &ctx->worklist, &ctx->sel_tmp};
     for (rc_dbuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (ctx->cnt_keys) (void)hipFree(ctx->cnt_keys);
@@ -231,7 +235,7 @@ int rc_table_load_jfdump(rc_ctx *c, const char *path, int64_t *stored)
             }
     }
     buf[(size_t)sz] = 0;
-    const bool tm = getenv("RC_TIMING") != nullptr;
+    const bool tm = ctx->env_timing;
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_read = now();
 
@@ -748,10 +752,17 @@ int rc_correct_device(rc_ctx *ctx, const rc_device_batch *b)
     // batches always run the threshold kernel first; single-end batches do too when every read fits
     // the four-reads-per-wave kernel (cheaper there than inside k_correct), else k_correct computes them
     ctx->thr_ready = false;
-    const bool quarter_ok = a.max_len <= 320 && a.max_len - ctx->k + 1 <= 256 && !getenv("RC_K2_WAVE_PER_READ");
+    ctx->cls_ready = false;
+    const bool quarter_ok = a.max_len <= 320 && a.max_len - ctx->k + 1 <= 256 && !ctx->env_k2_wave_per_read;
     if (a.mode != 0 || quarter_ok) {
-        if ((rc = rc_launch_threshold(ctx, a))) return rc;
+        if ((rc = rc_launch_threshold(ctx, a, true))) return rc;
         ctx->thr_ready = true;
+    }
+    if (ctx->cls_ready) {  // the reads the threshold kernel could not finish, as k_correct's work list
+        if ((rc = rc_dbuf_reserve(ctx, &ctx->worklist, (size_t)a.n * 4 + 256))) return rc;
+        if ((rc = rc_launch_compact(ctx, (const uint8_t *)ctx->cls.p, a.n, (uint32_t *)ctx->worklist.p,
+                                    (uint32_t *)((char *)ctx->work.p + RC_WORK_NWORK_OFF))))
+            return rc;
     }
     if ((rc = rc_launch_correct(ctx, a))) return rc;
     return RC_OK;
@@ -781,7 +792,7 @@ int rc_strong_threshold_device(rc_ctx *ctx, const uint8_t *d_seq, const uint32_t
     a.off = d_off;
     a.max_len = max_read_len;
     if ((rc = rc_launch_probe(ctx, d_seq, (size_t)nbytes, (int32_t *)ctx->counts.p))) return rc;
-    if ((rc = rc_launch_threshold(ctx, a))) return rc;
+    if ((rc = rc_launch_threshold(ctx, a, false))) return rc;
     RC_CHECK_HIP(ctx, hipMemcpyAsync(d_strong, ctx->strong.p, (size_t)n_reads * 4, hipMemcpyDeviceToDevice, ctx->stream));
     return RC_OK;
 }

@@ -28,7 +28,12 @@ struct DevWaveT {
         if (i == 3) rounds += v;
     }
 #else
-    __device__ __forceinline__ void stat(int, int) {}
+    int rounds = 0, rounds_max = 0;  // PROF builds: gather rounds of the current read / of the wave's worst read
+    long long rounds_sum = 0;
+    __device__ __forceinline__ void stat(int i, int v)
+    {
+        if (PROF && i == 3) rounds += v;
+    }
 #endif
     // trace record of the current read: [0] flags (bit 0: passed the screens, i.e. "Before
     // correction" is printed), [1] iterations seen, then RC_TRACE_WORDS per recorded iteration:
@@ -128,6 +133,22 @@ struct DevWaveT {
         for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
         return __builtin_amdgcn_readfirstlane(x);
     }
+
+    // min / max over the 64 lanes: DPP inside each 16-lane row (no LDS), v_readlane across rows
+    template <bool MAX>
+    __device__ __forceinline__ uint32_t wave_minmax_u32(uint32_t x)
+    {
+        auto op = [](uint32_t a, uint32_t b) { return MAX ? (a > b ? a : b) : (a < b ? a : b); };
+        x = op(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+        x = op(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+        x = op(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xF, 0xF, true));  // row_half_mirror
+        x = op(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xF, 0xF, true));  // row_mirror
+        const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)x, 0), r1 = (uint32_t)__builtin_amdgcn_readlane((int)x, 16);
+        const uint32_t r2 = (uint32_t)__builtin_amdgcn_readlane((int)x, 32), r3 = (uint32_t)__builtin_amdgcn_readlane((int)x, 48);
+        return op(op(r0, r1), op(r2, r3));
+    }
+    __device__ __forceinline__ uint32_t wave_min_u32(uint32_t x) { return wave_minmax_u32<false>(x); }
+    __device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) { return wave_minmax_u32<true>(x); }
 
     __device__ __forceinline__ int get(rc_kmer km)
     {
@@ -246,7 +267,7 @@ typedef DevWaveT<false> DevWave;
 
 struct rc_lds_layout {
     int cap, cap2;
-    size_t o_counts, o_v, o_isl, o_seg, o_base, o_path, o_best, o_strongb, o_polya, o_qual, o_masks, o_spec, total;
+    size_t o_counts, o_v, o_isl, o_seg, o_base, o_path, o_best, o_strongb, o_polya, o_qual, o_masks, o_spec, o_pk, total;
     int mask_words;
 };
 
@@ -264,6 +285,8 @@ static __host__ __device__ inline rc_lds_layout rc_layout(int cap)
     o += (size_t)L.mask_words * 8 * 5;
     L.o_spec = o;
     o += (size_t)RC_SPEC * (8 + 4 * 4 + 4 + 4 * 4);
+    L.o_pk = o;
+    o += (size_t)(cap / 16 + 4) * 4;
     L.o_counts = o;
     o += (size_t)cap * 4;
     L.o_v = o;
@@ -272,6 +295,7 @@ static __host__ __device__ inline rc_lds_layout rc_layout(int cap)
     o += (size_t)nseg * sizeof(rc_segment);
     L.o_isl = o;
     o += (size_t)nseg * sizeof(rc_island);
+    o = (o + 15) & ~(size_t)15;  // rc_pack_read reads base[] as dwords
     L.o_base = o;
     o += cap;
     L.o_path = o;
@@ -306,6 +330,7 @@ __device__ __forceinline__ void rc_carve(uint8_t *lds, const rc_lds_layout &L, r
     S.m_n = mm + 2 * L.mask_words;
     S.m_inv = mm + 3 * L.mask_words;
     S.m_x = mm + 4 * L.mask_words;
+    S.pk = reinterpret_cast<uint32_t *>(lds + L.o_pk);
     S.spec_code = reinterpret_cast<uint64_t *>(lds + L.o_spec);
     S.spec_cnt = reinterpret_cast<int *>(lds + L.o_spec + RC_SPEC * 8);
     S.spec_inv = S.spec_cnt + RC_SPEC * 4;
@@ -336,6 +361,9 @@ struct rc_kernel_args {
     const uint32_t *off;
     const int32_t *counts;  // K1 output, indexed like seq
     int32_t *strong, *info;
+    uint8_t *cls;              // K2 -> compaction: 1 = the read still needs k_correct (nullptr: no classification)
+    const uint32_t *worklist;  // k_correct: the reads to process (nullptr: all of [0, n))
+    const uint32_t *n_work;    // k_correct: number of entries of worklist (device memory)
     int32_t *ret, *l, *m, *h;
     rc_frame *stack;
     int stack_frames;  // per wave
@@ -361,6 +389,7 @@ __device__ __forceinline__ void rc_load_read(W &w, const rc_kernel_args &A, rc_r
     }
     w.sync();
     rc_build_masks(w, S);
+    rc_pack_read(w, S);
 }
 
 // Software-pipelined over the reads of a wave: the kernel has no table probes, so a read costs two
@@ -449,6 +478,9 @@ __global__ __launch_bounds__(64) void k_threshold(rc_kernel_args A)
 #ifndef RC_DEQUEUE
 #define RC_DEQUEUE 8  // reads per work-counter atomic
 #endif
+#ifndef RC_HEADS
+#define RC_HEADS 8    // work-queue heads (one per XCD)
+#endif
 #ifndef RC_K3_WAVES
 #define RC_K3_WAVES 6  // waves per SIMD the register allocation of k_correct is held to
 #endif
@@ -467,19 +499,41 @@ __global__ __launch_bounds__(64, RC_K3_WAVES) void k_correct(rc_kernel_args A)
     w.T = A.T;
     w.k = A.P.k;
     w.stack = A.stack + (size_t)blockIdx.x * A.stack_frames;
-    // work distribution: the reference's mutex-protected counter (ErrorCorrection.cpp:87-90), taken
-    // RC_DEQUEUE reads at a time -- one device-scope atomic word sustains only ~88 dequeues/us on
-    // MI355X, which at one read per dequeue would cap the kernel at ~88 M reads/s by itself
+    if (PROF && w.lane == 0) atomicMin(A.phase_cycles + 8, (unsigned long long)wall_clock64());
+    // Work distribution.  The reference hands out read indices from one mutex-protected counter
+    // (ErrorCorrection.cpp:87-90); one device-scope atomic word sustains only ~88 dequeues/us on
+    // MI355X, so the queue [0, n_work) is cut into RC_HEADS slices with a head word each (128 B
+    // apart).  A wave starts on the slice of its XCD (workgroup b runs on XCD b % 8 -- an affinity
+    // for speed, nothing depends on it), takes RC_DEQUEUE entries per atomic, and moves on to the
+    // next slice when one is exhausted, so no slice is left behind whatever the placement.
+    const uint32_t n_work = A.n_work ? (uint32_t)__builtin_amdgcn_readfirstlane((int)*A.n_work) : A.n;
     uint32_t chunk_lo = 0, chunk_hi = 0;
+    int head = (int)(blockIdx.x % RC_HEADS), heads_done = 0;
     for (;;) {
         if (chunk_lo >= chunk_hi) {
-            uint32_t r0 = 0;
-            if (w.lane == 0) r0 = atomicAdd(A.work, (uint32_t)RC_DEQUEUE);
-            chunk_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)r0);
-            if (chunk_lo >= A.n) break;
-            chunk_hi = chunk_lo + RC_DEQUEUE < A.n ? chunk_lo + RC_DEQUEUE : A.n;
+            bool got = false;
+            while (heads_done < RC_HEADS) {
+                const uint32_t lo = (uint32_t)(((uint64_t)n_work * (uint32_t)head) / RC_HEADS);
+                const uint32_t hi = (uint32_t)(((uint64_t)n_work * (uint32_t)(head + 1)) / RC_HEADS);
+                uint32_t r0 = 0;
+                if (w.lane == 0) r0 = atomicAdd(A.work + head * 32, (uint32_t)RC_DEQUEUE);
+                r0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)r0);
+                if (r0 < hi - lo) {
+                    chunk_lo = lo + r0;
+                    chunk_hi = hi - chunk_lo > (uint32_t)RC_DEQUEUE ? chunk_lo + RC_DEQUEUE : hi;
+                    got = true;
+                    break;
+                }
+                head = head + 1 == RC_HEADS ? 0 : head + 1;
+                ++heads_done;
+            }
+            if (!got) {
+                if (PROF && w.lane == 0) atomicMin(A.phase_cycles + 9, (unsigned long long)wall_clock64());
+                break;
+            }
         }
-        const uint32_t r = chunk_lo++;
+        uint32_t r = chunk_lo++;
+        if (A.worklist) r = (uint32_t)__builtin_amdgcn_readfirstlane((int)A.worklist[r]);
         w.phase(0);
         if (TRACE) {
             w.tr = A.trace + (size_t)r * (2 + (size_t)A.trace_cap * RC_TRACE_WORDS);
@@ -518,6 +572,7 @@ __global__ __launch_bounds__(64, RC_K3_WAVES) void k_correct(rc_kernel_args A)
                 }
             }
             w.sync();
+            rc_pack_read(w, S);
         }
         int l, m, h;
         rc_kmer_info(w, S, A.P, ret, &l, &m, &h);
@@ -534,10 +589,22 @@ __global__ __launch_bounds__(64, RC_K3_WAVES) void k_correct(rc_kernel_args A)
         }
         w.sync();
         w.phase(7);
+#ifndef RC_EXP_ROUNDS
+        if (PROF) {
+            w.rounds_sum += w.rounds;
+            w.rounds_max = w.rounds > w.rounds_max ? w.rounds : w.rounds_max;
+            w.rounds = 0;
+        }
+#endif
     }
     if (PROF && w.lane == 0) {
         w.phase(7);
         for (int i = 0; i < 8; ++i) atomicAdd(A.phase_cycles + i, w.acc[i]);
+        atomicMax(A.phase_cycles + 10, (unsigned long long)wall_clock64());
+#ifndef RC_EXP_ROUNDS
+        atomicAdd(A.phase_cycles + 11, (unsigned long long)w.rounds_sum);
+        atomicMax(A.phase_cycles + 12, (unsigned long long)w.rounds_max);
+#endif
     }
 }
 
@@ -580,6 +647,9 @@ static int fill_args(rc_ctx *ctx, const rc_device_batch_args &a, rc_kernel_args 
     A.counts = (const int32_t *)ctx->counts.p;
     A.strong = (int32_t *)ctx->strong.p;
     A.info = (int32_t *)ctx->info.p;
+    A.cls = nullptr;
+    A.worklist = nullptr;
+    A.n_work = nullptr;
     A.ret = a.ret;
     A.l = a.l;
     A.m = a.m;
@@ -595,15 +665,23 @@ static int fill_args(rc_ctx *ctx, const rc_device_batch_args &a, rc_kernel_args 
     return RC_OK;
 }
 
-int rc_launch_threshold(rc_ctx *ctx, const rc_device_batch_args &a)
+// classify: let the quarter-wave kernel finish the reads that need no correction (ret, l, m, h
+// written there) and flag the others in ctx->cls; ctx->cls_ready tells the caller whether it did
+int rc_launch_threshold(rc_ctx *ctx, const rc_device_batch_args &a, bool classify)
 {
+    ctx->cls_ready = false;
     if (a.n == 0) return RC_OK;
     rc_kernel_args A;
     int rc = fill_args(ctx, a, A);
     if (rc) return rc;
     const rc_lds_layout L = rc_layout(A.cap);
     // four reads per wave when every read of the batch fits the quarter-wave layout (rc_quarter.h)
-    const bool quarter = a.max_len <= rcq::MAX_LEN && a.max_len - A.P.k + 1 <= rcq::MAX_KCNT && !getenv("RC_K2_WAVE_PER_READ");
+    const bool quarter = a.max_len <= rcq::MAX_LEN && a.max_len - A.P.k + 1 <= rcq::MAX_KCNT && !ctx->env_k2_wave_per_read;
+    if (quarter && classify && a.ret && ctx->trace_cap == 0 && !ctx->env_no_classify) {
+        if ((rc = rc_dbuf_reserve(ctx, &ctx->cls, (size_t)a.n + 256))) return rc;
+        A.cls = (uint8_t *)ctx->cls.p;
+        ctx->cls_ready = true;
+    }
     rc_timer_begin(ctx);
     if (quarter && a.max_len <= 160 && a.max_len - A.P.k + 1 <= 128) {
         hipLaunchKernelGGL((k_threshold_q<8, 10>), dim3((a.n + 15) / 16), dim3(256), 0, ctx->stream, A);
@@ -627,13 +705,21 @@ int rc_launch_correct(rc_ctx *ctx, const rc_device_batch_args &a)
     if (rc) return rc;
     const rc_lds_layout L = rc_layout(A.cap);
     unsigned grid = (unsigned)ctx->n_cu * 4u * RC_K3_WAVES;
+    if (ctx->env_k3_grid_waves > 0 && ctx->env_k3_grid_waves < RC_K3_WAVES) grid = (unsigned)ctx->n_cu * 4u * (unsigned)ctx->env_k3_grid_waves;
     if (grid > a.n) grid = a.n;
     A.stack_frames = A.cap + 64;
     rc = rc_dbuf_reserve(ctx, &ctx->stack, (size_t)grid * A.stack_frames * sizeof(rc_frame));
     if (rc) return rc;
     A.stack = (rc_frame *)ctx->stack.p;
-    RC_CHECK_HIP(ctx, hipMemsetAsync(ctx->work.p, 0, 128, ctx->stream));
-    A.phase_cycles = (unsigned long long *)((char *)ctx->work.p + 64);
+    // queue heads and phase counters to zero; the work-list length (written by the compaction) stays
+    RC_CHECK_HIP(ctx, hipMemsetAsync(ctx->work.p, 0, RC_WORK_NWORK_OFF, ctx->stream));
+    RC_CHECK_HIP(ctx, hipMemsetAsync((char *)ctx->work.p + RC_WORK_PHASE_OFF, 0, 128, ctx->stream));
+    RC_CHECK_HIP(ctx, hipMemsetAsync((char *)ctx->work.p + RC_WORK_PHASE_OFF + 64, 0xff, 16, ctx->stream));  // the two minima
+    A.phase_cycles = (unsigned long long *)((char *)ctx->work.p + RC_WORK_PHASE_OFF);
+    if (ctx->cls_ready) {
+        A.worklist = (const uint32_t *)ctx->worklist.p;
+        A.n_work = (const uint32_t *)((char *)ctx->work.p + RC_WORK_NWORK_OFF);
+    }
     if (ctx->trace_cap > 0) {
         rc = rc_dbuf_reserve(ctx, &ctx->trace, (size_t)a.n * (2 + (size_t)ctx->trace_cap * RC_TRACE_WORDS) * 4);
         if (rc) return rc;
@@ -649,15 +735,19 @@ int rc_launch_correct(rc_ctx *ctx, const rc_device_batch_args &a)
         hipLaunchKernelGGL((k_correct<false, false>), dim3(grid), dim3(64), L.total, ctx->stream, A);
     rc_timer_end(ctx, RC_T_CORRECT);
     if (ctx->phase_prof) {
-        unsigned long long pc[8];
+        unsigned long long pc[13];
+        uint32_t nwork = a.n;
         RC_CHECK_HIP(ctx, hipMemcpyAsync(pc, A.phase_cycles, sizeof pc, hipMemcpyDeviceToHost, ctx->stream));
+        if (A.n_work) RC_CHECK_HIP(ctx, hipMemcpyAsync(&nwork, A.n_work, 4, hipMemcpyDeviceToHost, ctx->stream));
         RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         static const char *names[8] = {"dequeue+load", "polya", "islands/segments", "search", "lower-thresholds", "post-filters", "apply+kmerinfo", "store"};
         unsigned long long tot = 0;
         for (int i = 0; i < 8; ++i) tot += pc[i];
         fprintf(stderr, "[rc phase prof] k_correct, %u reads, cycles/read:", a.n);
         for (int i = 0; i < 8; ++i) fprintf(stderr, " %s=%.0f(%.0f%%)", names[i], (double)pc[i] / a.n, 100.0 * pc[i] / (tot ? tot : 1));
-        fprintf(stderr, "\n");
+        // wall_clock64 ticks at 100 MHz: when the queue ran dry and when the last wave ended
+        fprintf(stderr, "\n[rc phase prof] work list %u of %u reads; queue empty at %.2f ms, last wave done at %.2f ms; gather rounds: %.2f per listed read, worst read %llu\n",
+                nwork, a.n, (double)(pc[9] - pc[8]) / 1e5, (double)(pc[10] - pc[8]) / 1e5, (double)pc[11] / (nwork ? nwork : 1), pc[12]);
     }
     RC_CHECK_HIP(ctx, hipGetLastError());
     return RC_OK;

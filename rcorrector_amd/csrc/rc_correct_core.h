@@ -73,6 +73,9 @@ struct rc_read_state {
     uint64_t *m_a, *m_t;    // base is 'A' / 'T'
     uint64_t *m_n, *m_inv;  // base is 'N' / is not one of ACGT
     uint64_t *m_x;          // scratch: trusted k-mers, fixed positions
+    // the read as 2-bit codes, 16 bases per word, first base most significant (a letter outside
+    // ACGT contributes 3, as KmerCode::Append does); cap/16 + 3 words, the last two never written
+    uint32_t *pk;
     // speculation cache of the search (rc_probe4_cached): extension counts of the next RC_SPEC
     // positions of the keep-base path, fetched in one gather round
     int *spec_cnt;          // [RC_SPEC*4]
@@ -126,6 +129,45 @@ RC_HD uint64_t rc_window(const uint64_t *m, int i, int n)
     uint64_t x = m[w] >> sh;
     if (sh) x |= m[w + 1] << (64 - sh);
     return n >= 64 ? x : (x & ((1ull << n) - 1ull));
+}
+
+RC_HD int rc_clz32(uint32_t x)  // x != 0
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __clz((int)x);
+#else
+    return __builtin_clz(x);
+#endif
+}
+
+// pk[] from base[] (rc_read_state::pk): one lane packs 16 bases = four dwords of base[].  A byte
+// b in 0..5 becomes min(b, 3) by SWAR, and the multiply gathers the four 2-bit fields of a dword
+// into its top byte in reading order (the partial products do not overlap, so nothing carries).
+template <class W>
+RC_HD void rc_pack_read(W &w, rc_read_state &S)
+{
+    const int nwords = (S.len + 15) >> 4;
+    const uint32_t *b32 = reinterpret_cast<const uint32_t *>(S.base);
+    for (int wi = w.lane; wi < nwords; wi += W::STRIDE) {
+        uint32_t word = 0;
+        for (int q = 0; q < 4; ++q) {
+            uint32_t x = b32[4 * wi + q];
+            const uint32_t t = (x >> 2) & 0x01010101u;
+            x = (x | t | (t << 1)) & 0x03030303u;
+            word = (word << 8) | ((x * 0x40100401u) >> 24);
+        }
+        S.pk[wi] = word;
+    }
+    w.sync();
+}
+
+// 2-bit code of the n bases starting at base p (1 <= n <= 32), first base most significant
+RC_HD uint64_t rc_code_at(const uint32_t *pk, int p, int n)
+{
+    const int w0 = p >> 4, sh = 2 * (p & 15);
+    uint64_t x = ((uint64_t)pk[w0] << 32) | pk[w0 + 1];
+    if (sh) x = (x << sh) | ((uint64_t)pk[w0 + 2] >> (32 - sh));
+    return x >> (64 - 2 * n);
 }
 
 // bit masks of the read's letters; every lane-parallel window test below runs on these
@@ -281,6 +323,40 @@ RC_HD rc_kmer rc_extend(rc_kmer km, int k, int dir, int b)
     return dir > 0 ? rc_append(km, k, b) : rc_prepend(km, k, b);
 }
 
+// kc after j rc_extend() steps with the read's own bases p0, p0+dir, ..., p0+dir*(j-1)
+// (0 <= j <= 31), in closed form: the code is a shift plus a window of the packed read, and the
+// one-slot invalid tracker (KmerCode.cpp:7-42) ends at the most recently appended invalid base /
+// at the leftmost prepended one, or ages by j steps if the run holds none.
+RC_HD rc_kmer rc_extend_run(const rc_read_state &S, rc_kmer kc, int k, int dir, int p0, int j)
+{
+    if (j <= 0) return kc;
+    rc_kmer r;
+    if (dir > 0) {
+        r.code = ((kc.code << (2 * j)) | rc_code_at(S.pk, p0, j)) & rc_kmer_mask(k);
+        const uint64_t im = rc_window(S.m_inv, p0, j);  // bit i = base p0+i is not ACGT
+        int inv;
+        if (im)
+            inv = j - 1 - (63 - rc_clz64(im));
+        else
+            inv = kc.inv == -1 ? -1 : kc.inv + j;
+        r.inv = inv >= k ? -1 : inv;
+    } else {
+        const int lo = p0 - j + 1;
+        if (j >= k)
+            r.code = rc_code_at(S.pk, lo, k);
+        else
+            r.code = (kc.code >> (2 * j)) | (rc_code_at(S.pk, lo, j) << (2 * (k - j)));
+        const uint64_t im = rc_window(S.m_inv, lo, j);  // bit i = base lo+i, prepended at step j-1-i
+        int inv;
+        if (im)
+            inv = k - 1 - rc_ctz64(im);
+        else
+            inv = kc.inv == -1 ? -1 : kc.inv - j;
+        r.inv = inv < 0 ? -1 : inv;
+    }
+    return r;
+}
+
 // The four extension counts of search node (kc, pos).  InferPosThreshold and steps (1)/(3) of the
 // reference all look at the same four k-mers, so they are fetched once per node -- and, because a
 // node's successor along the keep-base path is known in advance (the read's own next base), the
@@ -309,8 +385,7 @@ RC_HD int rc_probe4_cached(W &w, rc_read_state &S, rc_spec_state &Z, rc_kmer kc,
     w.sync();
     w.for_lanes64(0, 4 * n, [&](int q, int) {
         const int j = q >> 2, c = q & 3;
-        rc_kmer kj = kc;
-        for (int s2 = 0; s2 < j; ++s2) kj = rc_extend(kj, k, dir, S.base[pos + dir * s2]);
+        const rc_kmer kj = rc_extend_run(S, kc, k, dir, pos, j);
         if (c == 0) {
             S.spec_code[j] = kj.code;
             S.spec_inv[j] = kj.inv;
@@ -596,15 +671,15 @@ RC_HD void rc_search(W &w, rc_read_state &S, const rc_run_params &P, rc_search_c
                 if (m > 0) {
                     const rc_kmer tmp0 = tmp;
                     const uint64_t hit = w.ballot64(1, m + 1, [&](int sN) {
-                        rc_kmer tq = tmp0;
-                        for (int u = 1; u <= sN; ++u) tq = rc_extend(tq, k, dir, S.base[pos + dir * u]);
-                        return w.get(tq) >= threshold;
+                        return w.get(rc_extend_run(S, tmp0, k, dir, pos + dir, sN)) >= threshold;
                     });
                     w.stat(4, 1);
                     w.stat(5, m);
                     if (hit) {
                         const int sN = 1 + rc_ctz64(hit);
-                        for (int u = 1; u <= sN; ++u) tmp = rc_extend(tmp, k, dir, RC_U(S.base[pos + dir * u]));
+                        tmp = rc_extend_run(S, tmp0, k, dir, pos + dir, sN);
+                        tmp.code = RC_U64(tmp.code);
+                        tmp.inv = RC_U(tmp.inv);
                         i = pos + dir * sN;
                         steps = sN;
                     }
@@ -709,16 +784,22 @@ RC_HD void rc_search(W &w, rc_read_state &S, const rc_run_params &P, rc_search_c
     }
 }
 
-// original k-mer of the read starting at base `a`, built as the reference does for an anchor
-// (Restart + k Appends, ErrorCorrection.cpp:1140-1142 / :1152-1154)
+// original k-mer of the read starting at base `a`, as the reference builds an anchor (Restart +
+// k Appends, ErrorCorrection.cpp:1140-1142 / :1152-1154): a window of the packed read, the
+// tracker at the last base of the window that is not ACGT.  Wave-uniform: scalar loads.
 template <class W>
 RC_HD rc_kmer rc_anchor(W &w, const rc_read_state &S, int k, int a)
 {
-    (void)w;
     rc_kmer kc;
-    kc.code = 0;
-    kc.inv = -1;
-    for (int i = a; i < a + k; ++i) kc = rc_append(kc, k, RC_U(S.base[i]));
+    const int w0 = a >> 4, sh = 2 * (a & 15);
+    uint64_t x = ((uint64_t)(uint32_t)RC_U(S.pk[w0]) << 32) | (uint32_t)RC_U(S.pk[w0 + 1]);
+    if (sh) x = (x << sh) | ((uint64_t)(uint32_t)RC_U(S.pk[w0 + 2]) >> (32 - sh));
+    kc.code = x >> (64 - 2 * k);
+    const int mw = a >> 6, ms = a & 63;
+    uint64_t im = RC_U64(S.m_inv[mw]) >> ms;
+    if (ms) im |= RC_U64(S.m_inv[mw + 1]) << (64 - ms);
+    if (k < 64) im &= (1ull << k) - 1ull;
+    kc.inv = im ? k - 1 - (63 - rc_clz64(im)) : -1;
     return kc;
 }
 
@@ -1103,9 +1184,26 @@ RC_HD int rc_correct_read(W &w, rc_read_state &S, const rc_run_params &P, int pa
     return ret;
 }
 
+// rank-`kth` (0-based, ascending) of the n unsigned values v[], none above `hi` except
+// 0xFFFFFFFF place holders: a radix descent over the bits of `hi`, one ballot per bit and 64
+// values -- for the few bits k-mer counts use this is an order of magnitude cheaper than sorting
+template <class W>
+RC_HD int rc_select_kth(W &w, const int *v, int n, int kth, uint32_t hi)
+{
+    uint32_t prefix = 0;
+    for (int b = 31 - rc_clz32(hi | 1u); b >= 0; --b) {
+        const uint32_t cand = prefix | (1u << b);
+        int below = 0;
+        for (int b0 = 0; b0 < n; b0 += 64) below += rc_popc64(w.ballot64(b0, n, [&](int q) { return (uint32_t)v[q] < cand; }));
+        if (below <= kth) prefix = cand;
+    }
+    return (int)prefix;
+}
+
 // GetKmerInformation (ErrorCorrection.cpp:1567-1602) on the read after `ret` fixes were
-// applied to base[] (so base[i] already holds the corrected base where best[i] != -1).
+// applied to base[] and pk[] (so both already hold the corrected bases where best[i] != -1).
 // counts[] still holds the pre-correction counts; only windows touching a fix are re-probed.
+// l and h are wave reductions, m = sorted[n/2] is a rank selection: no sort.
 template <class W>
 RC_HD void rc_kmer_info(W &w, rc_read_state &S, const rc_run_params &P, int ret, int *l, int *m,
                         int *h)
@@ -1122,29 +1220,33 @@ RC_HD void rc_kmer_info(W &w, rc_read_state &S, const rc_run_params &P, int ret,
     }
     w.sync();
     int nvalid = 0;
+    uint32_t lo = 0xFFFFFFFFu, hi = 0;
     for (int b0 = 0; b0 < S.kcnt; b0 += 64) {
         const uint64_t vm = w.ballot64(b0, S.kcnt, [&](int q) {
             return (rc_window(S.m_inv, q, k) & ~rc_window(S.m_x, q, k)) == 0;
         });
         nvalid += rc_popc64(vm);
         w.for_lanes64(b0, S.kcnt, [&](int q, int ln) {
-            int c = 2147483647;
+            uint32_t c = 0xFFFFFFFFu;
             if ((vm >> ln) & 1ull) {
-                if (ret > 0 && rc_window(S.m_x, q, k) != 0) {  // window holds a fix: probe the new k-mer
-                    uint64_t code = 0;
-                    for (int jj = 0; jj < k; ++jj) code = (code << 2) | (uint64_t)(S.base[q + jj] & 3);
-                    c = w.lookup(code);
-                } else
-                    c = S.counts[q];
-                if (c == 0) c = 1;
+                int cc;
+                if (ret > 0 && rc_window(S.m_x, q, k) != 0)  // window holds a fix: probe the new k-mer
+                    cc = w.lookup(rc_code_at(S.pk, q, k));
+                else
+                    cc = S.counts[q];
+                if (cc == 0) cc = 1;
+                c = (uint32_t)cc;
+                lo = c < lo ? c : lo;
+                hi = c > hi ? c : hi;
             }
-            S.v[q] = c;
+            S.v[q] = (int)c;
         });
     }
     w.sync();
     if (nvalid == 0) return;
-    w.sort(S.v, S.kcnt);
-    *l = RC_U(S.v[0]);
-    *m = RC_U(S.v[nvalid / 2]);
-    *h = RC_U(S.v[nvalid - 1]);
+    lo = w.wave_min_u32(lo);
+    hi = w.wave_max_u32(hi);
+    *l = (int)lo;
+    *h = (int)hi;
+    *m = rc_select_kth(w, S.v, S.kcnt, nvalid / 2, hi);
 }

@@ -91,6 +91,13 @@ struct rc_ctx {
     rc_dbuf strong;   // int32 per read
     rc_dbuf info;     // int32 per read
     bool thr_ready = false;  // strong / info hold this batch's thresholds (the threshold kernel ran)
+    rc_dbuf cls;      // uint8 per read: 1 = still needs k_correct (written by the threshold kernel)
+    rc_dbuf worklist; // uint32 per read: the reads with cls == 1, ascending
+    rc_dbuf sel_tmp;  // rocPRIM scratch of the compaction
+    bool cls_ready = false;  // cls / worklist describe this batch
+    // getenv() results, read once at rc_create
+    bool env_k2_wave_per_read = false, env_no_classify = false, env_timing = false;
+    int env_k3_grid_waves = 0;  // dev: persistent k_correct waves per SIMD actually launched (0 = as compiled)
     rc_dbuf stack;    // search stack frames
     rc_dbuf work;     // work counters
     rc_dbuf h_seq, h_qual, h_off, h_res;  // device staging for the host-buffer entry point
@@ -118,6 +125,7 @@ int rc_launch_selftest_bound(rc_ctx *ctx, const int32_t *d_c, size_t n, double e
 int rc_launch_export(rc_ctx *ctx, uint64_t *d_codes, int32_t *d_counts, unsigned long long *d_n, size_t cap);
 int rc_table_entries_in_dump_order(rc_ctx *ctx, std::vector<uint64_t> *codes, std::vector<int32_t> *counts);
 int rc_launch_last_base_variants(rc_ctx *ctx, const uint64_t *d_codes, size_t n, int32_t *d_max2);
+int rc_launch_compact(rc_ctx *ctx, const uint8_t *d_flags, uint32_t n, uint32_t *d_list, uint32_t *d_count);
 
 // rc_correct.hip
 struct rc_device_batch_args {
@@ -129,5 +137,11 @@ struct rc_device_batch_args {
     int32_t *ret, *l, *m, *h;
     int max_len;         // longest read in the batch (bases)
 };
-int rc_launch_threshold(rc_ctx *ctx, const rc_device_batch_args &a);
+int rc_launch_threshold(rc_ctx *ctx, const rc_device_batch_args &a, bool classify);
 int rc_launch_correct(rc_ctx *ctx, const rc_device_batch_args &a);
+
+// layout of rc_ctx::work (bytes): the RC_HEADS queue heads of k_correct, 128 B apart, then the
+// length of the work list, then the phase counters of PROF builds
+#define RC_WORK_BYTES 2048
+#define RC_WORK_NWORK_OFF 1024
+#define RC_WORK_PHASE_OFF 1152

@@ -123,8 +123,19 @@ __global__ __launch_bounds__(256) void k_threshold_q(rc_kernel_args A)
     using namespace rcq;
     const int lane = threadIdx.x & 63, row = lane >> 4, l = lane & 15;
     const int k = A.P.k;
-    const uint32_t r = ((uint32_t)blockIdx.x * 4u + (threadIdx.x >> 6)) * 4u + (uint32_t)row;
-    const bool live = r < A.n;
+    // rows 2j and 2j+1 of a wave hold the two mates of a pair (paired: reads u and n/2 + u;
+    // interleaved: reads 2u and 2u+1), so the pair threshold is one lane exchange away
+    const uint32_t wv = (uint32_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+    uint32_t r;
+    bool live;
+    if (A.mode == 1) {
+        const uint32_t half = A.n >> 1, u = wv * 2u + (uint32_t)(row >> 1);
+        live = u < half;
+        r = (row & 1) ? half + u : u;
+    } else {
+        r = wv * 4u + (uint32_t)row;
+        live = r < A.n;
+    }
     uint32_t o = 0;
     int len = 0;
     if (live) {
@@ -238,8 +249,69 @@ __global__ __launch_bounds__(256) void k_threshold_q(rc_kernel_args A)
         const int med = __builtin_amdgcn_ds_bpermute((row_lane0 + (idx & 15)) << 2, sel);
         strong = found ? strong : med;
     }
+    const int strong_self = screened ? -1 : strong;
+    // Class of the read.  Replay the first threshold iteration of ErrorCorrection (:793-842):
+    // `s` = the strong threshold it starts with (its own, lowered to the pair's), `t0` = the weak
+    // one ("trust").  If no k-mer of the read lies below t0 (v[0] >= t0 >= 2, which also means
+    // every window is in the table: no letter outside ACGT, no poly-A mask) and more than half of
+    // the k-mers reach s, the function's result is known without running it:
+    //  * more than ceil(kcnt/2) trusted k-mers cannot avoid two adjacent ones, so a real island
+    //    exists (:870-931), no boundary is moved (:934-965 needs a count < trust) and every
+    //    segment has its anchor k-mer inside the read (:1140-1154);
+    //  * in every segment search the keep-base child is taken at every node, because its count is
+    //    a count of the unchanged read, >= t0 >= the node's threshold (InferPosThreshold never
+    //    returns more than the threshold handed down, :165-172); the zero-fix path ends first
+    //    (:243-284), sets maxFixCnt = 0, and every substitution alternative is cut at its entry
+    //    (:211-224) before it can touch the result; trialCnt stays negative;
+    //  * so total_fix = 0, no segment is bad, and the function returns 0 at :1110, :1231 or :1479
+    //    without changing a base.  GetKmerInformation (:1567-1602) of the unchanged read is min /
+    //    element kcnt/2 / max of the counts sorted above.
+    // Such reads are finished here; k_correct only sees the others (cls = 1).
+    int cls = 1;
+    if (A.cls) {
+        int s = strong_self;
+        int t0 = rc_bound_i(s, A.P.error_rate);
+        bool flag = false;
+        if (found && s >= 20 && prev == 2 && t0 < 3) {
+            flag = true;
+            t0 = 3;
+        }
+        if (A.mode != 0) {
+            const int mate = __builtin_amdgcn_ds_bpermute((lane ^ 16) << 2, strong_self);
+            const int pair_t = strong_self < mate ? strong_self : mate;
+            if (pair_t >= 1 && s > pair_t) {
+                if (!flag || pair_t < 20) t0 = rc_bound_i(pair_t, A.P.error_rate);
+                s = pair_t;
+            }
+        }
+        if (t0 < 2) t0 = 2;
+        const int v0 = __builtin_amdgcn_ds_bpermute(row_lane0 << 2, x[0]);
+        int n_below = 0;  // k-mers with count < s
+#pragma unroll
+        for (int e = 0; e < E_CNT; ++e) n_below += __popc(row_bits(__ballot(x[e] < s), row));
+        const bool clean = !screened && v0 >= t0 && kcnt - n_below > (kcnt + 1) / 2;
+        const int im = kcnt >> 1, ih = kcnt > 0 ? kcnt - 1 : 0;
+        int sm = x[0], sh = x[0];
+#pragma unroll
+        for (int e = 1; e < E_CNT; ++e) {
+            sm = (im >> 4) == e ? x[e] : sm;
+            sh = (ih >> 4) == e ? x[e] : sh;
+        }
+        const int vm = __builtin_amdgcn_ds_bpermute((row_lane0 + (im & 15)) << 2, sm);
+        const int vh = __builtin_amdgcn_ds_bpermute((row_lane0 + (ih & 15)) << 2, sh);
+        if (clean) {
+            cls = 0;
+            if (live && l == 0) {
+                A.ret[r] = 0;
+                A.l[r] = v0;
+                A.m[r] = vm;
+                A.h[r] = vh;
+            }
+        }
+    }
     if (live && l == 0) {
-        A.strong[r] = screened ? -1 : strong;
+        A.strong[r] = strong_self;
         A.info[r] = screened ? 4 : ((found ? 1 : 0) | ((found && prev == 2) ? 2 : 0));
+        if (A.cls) A.cls[r] = (uint8_t)cls;
     }
 }

@@ -301,6 +301,18 @@ int rc_launch_selftest_bound(rc_ctx *ctx, const int32_t *d_c, size_t n, double e
     return RC_OK;
 }
 
+// d_list = the indices i in [0, n) with d_flags[i] != 0, ascending; *d_count = how many
+int rc_launch_compact(rc_ctx *ctx, const uint8_t *d_flags, uint32_t n, uint32_t *d_list, uint32_t *d_count)
+{
+    size_t tmp = 0;
+    rocprim::counting_iterator<uint32_t> ids(0);
+    RC_CHECK_HIP(ctx, rocprim::select(nullptr, tmp, ids, d_flags, d_list, d_count, (size_t)n, ctx->stream));
+    int rc = rc_dbuf_reserve(ctx, &ctx->sel_tmp, tmp);
+    if (rc) return rc;
+    RC_CHECK_HIP(ctx, rocprim::select(ctx->sel_tmp.p, tmp, ids, d_flags, d_list, d_count, (size_t)n, ctx->stream));
+    return RC_OK;
+}
+
 // ---- K1: probe kernel ----------------------------------------------------------------------
 // counts[a] = GetCount(k-mer starting at arena byte a) for every a whose k-window lies inside one
 // read (reads are NUL-terminated inside the arena, so "inside one read" == "no NUL in the

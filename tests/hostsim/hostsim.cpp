@@ -48,6 +48,8 @@ struct HostWave {
             if (base + l < n) body(base + l, l);
     }
     int reduce_add(int x) { return x; }
+    uint32_t wave_min_u32(uint32_t x) { return x; }
+    uint32_t wave_max_u32(uint32_t x) { return x; }
     int get(rc_kmer km)
     {
         ++gets;
@@ -82,6 +84,7 @@ struct Buffers {
     std::vector<rc_island> isl;
     std::vector<rc_segment> seg;
     std::vector<uint64_t> ma, mt, mn, mi, mx, scode;
+    std::vector<uint32_t> pk;
     std::vector<int> scnt, sinv, sret, skeep, sthr, smask;
     rc_read_state S;
     explicit Buffers(int cap)
@@ -105,6 +108,8 @@ struct Buffers {
         mi.resize(cap / 64 + 2);
         mx.resize(cap / 64 + 2);
         scode.resize(RC_SPEC);
+        pk.resize(cap / 16 + 3);
+        S.pk = pk.data();
         scnt.resize(RC_SPEC * 4);
         sinv.resize(RC_SPEC);
         sret.resize(RC_SPEC);
@@ -155,6 +160,7 @@ void load_read(Buffers &B, HostWave &w, const rco_params *p, const rco_table *t,
     for (int i = 0; i < len; ++i) B.S.base[i] = (unsigned char)base_code(seq[i]);
     if (B.S.kcnt > 0) rco_kmer_counts(p, t, seq, B.S.counts);  // stands in for the probe kernel
     rc_build_masks(w, B.S);
+    rc_pack_read(w, B.S);
 }
 
 }  // namespace
@@ -211,6 +217,7 @@ void hostsim_correct_batch(const rco_params *p, const rco_table *t, rco_batch *b
                     seq[i] = "ACGT"[B.S.best[i]];
                     B.S.base[i] = (unsigned char)B.S.best[i];
                 }
+            rc_pack_read(w, B.S);
         }
         int l, m, h;
         rc_kmer_info(w, B.S, P, ret, &l, &m, &h);
