@@ -5,6 +5,7 @@
 // One 64-lane wavefront (= one workgroup) per read; persistent waves pull read indices from an
 // atomic counter, which is the reference's mutex-protected batchUsed counter (:87-90) and
 // absorbs the heavy tail of the search.  Per-read state is carved out of dynamic LDS.
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 
@@ -243,19 +244,24 @@ struct DevWaveT {
     }
     __device__ __forceinline__ void stack_top(int idx, rc_frame &f)
     {
-        const volatile rc_frame *p = stack + idx;
-        f.code = uni64(p->code);
-        f.inv = __builtin_amdgcn_readfirstlane(p->inv);
-        f.pos = __builtin_amdgcn_readfirstlane(p->pos);
-        f.t = __builtin_amdgcn_readfirstlane(p->t);
-        f.threshold = __builtin_amdgcn_readfirstlane(p->threshold);
-        f.fix_cnt = __builtin_amdgcn_readfirstlane(p->fix_cnt);
-        f.bottleneck = __builtin_amdgcn_readfirstlane(p->bottleneck);
-        f.cnt[0] = __builtin_amdgcn_readfirstlane(p->cnt[0]);
-        f.cnt[1] = __builtin_amdgcn_readfirstlane(p->cnt[1]);
-        f.cnt[2] = __builtin_amdgcn_readfirstlane(p->cnt[2]);
-        f.cnt[3] = __builtin_amdgcn_readfirstlane(p->cnt[3]);
-        f.mask = __builtin_amdgcn_readfirstlane(p->mask);
+        // all loads go out before the first value is used (one round trip, not thirteen)
+        const volatile uint32_t *p = reinterpret_cast<const volatile uint32_t *>(stack + idx);
+        uint32_t d[13];
+#pragma unroll
+        for (int q = 0; q < 13; ++q) d[q] = p[q];
+        static_assert(sizeof(rc_frame) == 56 && offsetof(rc_frame, mask) == 48, "rc_frame layout");
+        f.code = ((uint64_t)(uint32_t)uni((int)d[1]) << 32) | (uint32_t)uni((int)d[0]);
+        f.inv = uni((int)d[2]);
+        f.pos = uni((int)d[3]);
+        f.t = uni((int)d[4]);
+        f.threshold = uni((int)d[5]);
+        f.fix_cnt = uni((int)d[6]);
+        f.bottleneck = uni((int)d[7]);
+        f.cnt.c0 = uni((int)d[8]);
+        f.cnt.c1 = uni((int)d[9]);
+        f.cnt.c2 = uni((int)d[10]);
+        f.cnt.c3 = uni((int)d[11]);
+        f.mask = uni((int)d[12]);
     }
     __device__ __forceinline__ void stack_set_mask(int idx, int mask)
     {
@@ -271,14 +277,20 @@ struct rc_lds_layout {
     int mask_words;
 };
 
-static __host__ __device__ inline rc_lds_layout rc_layout(int cap)
+static __host__ __device__ constexpr inline int rc_seg_capacity(int cap) { return cap / 6 + 4; }
+
+static __host__ __device__ constexpr inline rc_lds_layout rc_layout(int cap)
 {
-    rc_lds_layout L;
+    rc_lds_layout L{};
     L.cap = cap;
     int c2 = 64;
     while (c2 < cap) c2 <<= 1;
     L.cap2 = c2;
-    const int nseg = cap / 2 + 2;
+    // islands are runs of >= 2 trusted k-mers separated by >= 1 other: at most (kcnt+1)/3 (+1 for the
+    // fall-back island); segments lie between islands that cover >= k bases each and are >= 1 base
+    // apart: at most (len+1)/(k+1) + 1, which fill_args() checks against this capacity
+    const int nseg = rc_seg_capacity(cap);
+    const int nisl = cap / 3 + 2;
     size_t o = 0;
     L.mask_words = cap / 64 + 2;
     L.o_masks = o;
@@ -294,7 +306,7 @@ static __host__ __device__ inline rc_lds_layout rc_layout(int cap)
     L.o_seg = o;
     o += (size_t)nseg * sizeof(rc_segment);
     L.o_isl = o;
-    o += (size_t)nseg * sizeof(rc_island);
+    o += (size_t)nisl * sizeof(rc_island);
     o = (o + 15) & ~(size_t)15;  // rc_pack_read reads base[] as dwords
     L.o_base = o;
     o += cap;
@@ -368,7 +380,8 @@ struct rc_kernel_args {
     rc_frame *stack;
     int stack_frames;  // per wave
     uint32_t *work;
-    int cap;
+    int cap;        // LDS capacity of the runtime-layout kernels (k_threshold)
+    int cap_class;  // capacity class of k_correct (192 / 320 / 1024)
     unsigned long long *phase_cycles;  // [8], PROF builds only
     int fused_front_end;               // 1: k_correct computes the read's own threshold (single-end, no threshold kernel ran)
     int32_t *trace;                    // TRACE builds only: n x (2 + trace_cap * RC_TRACE_WORDS) words
@@ -378,8 +391,8 @@ struct rc_kernel_args {
 template <class W>
 __device__ __forceinline__ void rc_load_read(W &w, const rc_kernel_args &A, rc_read_state &S, uint32_t r, int lane, bool with_qual)
 {
-    const uint32_t o = A.off[r];
-    const int len = (int)(A.off[r + 1] - o) - 1;
+    const uint32_t o = (uint32_t)w.uni((int)A.off[r]);
+    const int len = w.uni((int)(A.off[r + 1] - o) - 1);
     S.len = len;
     S.kcnt = len >= A.P.k ? len - A.P.k + 1 : 0;
     for (int i = lane; i < len; i += 64) {
@@ -485,11 +498,22 @@ __global__ __launch_bounds__(64) void k_threshold(rc_kernel_args A)
 #define RC_K3_WAVES 6  // waves per SIMD the register allocation of k_correct is held to
 #endif
 
-template <bool PROF, bool TRACE>
-__global__ __launch_bounds__(64, RC_K3_WAVES) void k_correct(rc_kernel_args A)
+// CAP = LDS capacity class (bases per read, a multiple of 64): the layout is a compile-time
+// constant, so every array of rc_read_state is an immediate LDS address instead of a scalar
+// register (the kernel's scalar state does not fit the 102 SGPRs a wave has as it is)
+// resident waves per SIMD the register allocation is held to: RC_K3_WAVES where the LDS of the
+// capacity class allows that many, else what the LDS allows
+static constexpr int rc_k3_waves(int cap)
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const rc_lds_layout L = rc_layout(A.cap);
+    const int by_lds = cap <= 192 ? 8 : (cap <= 320 ? 5 : 1);
+    return by_lds < RC_K3_WAVES ? by_lds : RC_K3_WAVES;
+}
+
+template <int CAP, bool PROF, bool TRACE>
+__global__ __launch_bounds__(64, rc_k3_waves(CAP)) void k_correct(rc_kernel_args A)
+{
+    constexpr rc_lds_layout L = rc_layout(CAP);
+    __shared__ __attribute__((aligned(16))) uint8_t lds[L.total];
     rc_read_state S;
     rc_carve(lds, L, S);
     DevWaveT<PROF, TRACE> w;
@@ -541,22 +565,22 @@ __global__ __launch_bounds__(64, RC_K3_WAVES) void k_correct(rc_kernel_args A)
             w.sync();
         }
         rc_load_read(w, A, S, r, w.lane, true);
-        const uint32_t o = A.off[r];
+        const uint32_t o = (uint32_t)w.uni((int)A.off[r]);
         int strong0, info0;
         if (A.fused_front_end) {  // single-end: no mate to wait for, the threshold pass runs right here
             w.phase(1);
             strong0 = rc_front_end(w, S, A.P, &info0);
         } else {
-            strong0 = A.strong[r];
-            info0 = A.info[r];
+            strong0 = w.uni(A.strong[r]);
+            info0 = w.uni(A.info[r]);
         }
         int pair_t = -1;
         if (A.mode == 1) {
             const uint32_t half = A.n >> 1;
             const uint32_t mate = r < half ? r + half : r - half;
-            pair_t = rc_min(strong0, A.strong[mate]);
+            pair_t = rc_min(strong0, w.uni(A.strong[mate]));
         } else if (A.mode == 2) {
-            pair_t = rc_min(strong0, A.strong[r ^ 1u]);
+            pair_t = rc_min(strong0, w.uni(A.strong[r ^ 1u]));
         }
         w.phase(1);
         if (!A.fused_front_end && S.kcnt > 0 && !(info0 & 4)) rc_polya_flags(w, S, A.P.k);
@@ -658,6 +682,16 @@ static int fill_args(rc_ctx *ctx, const rc_device_batch_args &a, rc_kernel_args 
     A.stack_frames = 0;
     A.work = (uint32_t *)ctx->work.p;
     A.cap = rc_cap_for(a.max_len);
+    {   // capacity class of k_correct: room for the read and for its segments (tiny k only)
+        const int need_seg = (a.max_len + 1) / (ctx->k + 1) + 1;
+        int cls = A.cap <= 192 ? 192 : (A.cap <= 320 ? 320 : 1024);
+        while (cls < 1024 && rc_seg_capacity(cls) < need_seg) cls = cls == 192 ? 320 : 1024;
+        if (rc_seg_capacity(cls) < need_seg) {
+            rc_set_error(ctx, "correct: reads of %d bases with k = %d are not supported (too many segments)", a.max_len, ctx->k);
+            return RC_ERR_ARG;
+        }
+        A.cap_class = cls;
+    }
     A.phase_cycles = nullptr;
     A.trace = nullptr;
     A.trace_cap = 0;
@@ -703,8 +737,7 @@ int rc_launch_correct(rc_ctx *ctx, const rc_device_batch_args &a)
     rc_kernel_args A;
     int rc = fill_args(ctx, a, A);
     if (rc) return rc;
-    const rc_lds_layout L = rc_layout(A.cap);
-    unsigned grid = (unsigned)ctx->n_cu * 4u * RC_K3_WAVES;
+    unsigned grid = (unsigned)ctx->n_cu * 4u * (unsigned)rc_k3_waves(ctx->trace_cap > 0 ? 1024 : A.cap_class);
     if (ctx->env_k3_grid_waves > 0 && ctx->env_k3_grid_waves < RC_K3_WAVES) grid = (unsigned)ctx->n_cu * 4u * (unsigned)ctx->env_k3_grid_waves;
     if (grid > a.n) grid = a.n;
     A.stack_frames = A.cap + 64;
@@ -728,13 +761,17 @@ int rc_launch_correct(rc_ctx *ctx, const rc_device_batch_args &a)
     }
     rc_timer_begin(ctx);
     if (ctx->trace_cap > 0)
-        hipLaunchKernelGGL((k_correct<false, true>), dim3(grid), dim3(64), L.total, ctx->stream, A);
-    else if (ctx->phase_prof)
-        hipLaunchKernelGGL((k_correct<true, false>), dim3(grid), dim3(64), L.total, ctx->stream, A);
+        hipLaunchKernelGGL((k_correct<1024, false, true>), dim3(grid), dim3(64), 0, ctx->stream, A);
+    else if (ctx->phase_prof && A.cap_class == 192)
+        hipLaunchKernelGGL((k_correct<192, true, false>), dim3(grid), dim3(64), 0, ctx->stream, A);
+    else if (A.cap_class == 192)
+        hipLaunchKernelGGL((k_correct<192, false, false>), dim3(grid), dim3(64), 0, ctx->stream, A);
+    else if (A.cap_class == 320)
+        hipLaunchKernelGGL((k_correct<320, false, false>), dim3(grid), dim3(64), 0, ctx->stream, A);
     else
-        hipLaunchKernelGGL((k_correct<false, false>), dim3(grid), dim3(64), L.total, ctx->stream, A);
+        hipLaunchKernelGGL((k_correct<1024, false, false>), dim3(grid), dim3(64), 0, ctx->stream, A);
     rc_timer_end(ctx, RC_T_CORRECT);
-    if (ctx->phase_prof) {
+    if (ctx->phase_prof && A.cap_class == 192) {
         unsigned long long pc[13];
         uint32_t nwork = a.n;
         RC_CHECK_HIP(ctx, hipMemcpyAsync(pc, A.phase_cycles, sizeof pc, hipMemcpyDeviceToHost, ctx->stream));

@@ -43,6 +43,13 @@ struct rc_segment {
     int top2[2];
 };
 
+// the four extension counts of a search node.  Named members, not an array: an array that is ever
+// indexed at run time stays in private memory, and a load from private memory is a divergent value
+// to the compiler -- one such load in the search loop turned its whole state into vector registers
+struct rc_cnt4 {
+    int c0, c1, c2, c3;
+};
+
 // search-stack frame: a node whose substitution alternatives are still pending
 struct rc_frame {
     uint64_t code;
@@ -52,7 +59,7 @@ struct rc_frame {
     int threshold;
     int fix_cnt;
     int bottleneck;
-    int cnt[4];
+    rc_cnt4 cnt;
     int mask;  // pending substitution candidates, bit c
 };
 
@@ -296,22 +303,48 @@ struct rc_search_ctx {
     int top2a, top2b;  // top2FixBottleNeck[0], [1] of the segment being searched
 };
 
-// cnt[idx] for a wave-uniform runtime idx without spilling the 4-array to scratch
-RC_HD int rc_sel4(const int c[4], int idx)
+// a wave-uniform value, pinned as a value: on the device v_readfirstlane (free for a value that
+// already sits in a scalar register).  Without it the optimiser rewrites a chain of selects over
+// adjacent members into ONE load with a computed address, which keeps the struct in private memory
+RC_HD int rc_pin(int x)
 {
-    int r = c[0];
-    r = idx == 1 ? c[1] : r;
-    r = idx == 2 ? c[2] : r;
-    r = idx == 3 ? c[3] : r;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_readfirstlane(x);
+#else
+    return x;
+#endif
+}
+
+// cnt[idx] for a wave-uniform runtime idx
+RC_HD int rc_sel4(const rc_cnt4 &c, int idx)
+{
+    const int c0 = rc_pin(c.c0), c1 = rc_pin(c.c1), c2 = rc_pin(c.c2), c3 = rc_pin(c.c3);
+    int r = c0;
+    r = idx == 1 ? c1 : r;
+    r = idx == 2 ? c2 : r;
+    r = idx == 3 ? c3 : r;
     return r;
 }
 
+// bit c set iff c != b and cnt[c] >= threshold (substitution candidates, :343-352 / :577-588)
+RC_HD int rc_candidates(const rc_cnt4 &c, int b, int threshold)
+{
+    int m = 0;
+    if (b != 0 && c.c0 >= threshold) m |= 1;
+    if (b != 1 && c.c1 >= threshold) m |= 2;
+    if (b != 2 && c.c2 >= threshold) m |= 4;
+    if (b != 3 && c.c3 >= threshold) m |= 8;
+    return m;
+}
+
 // InferPosThreshold (ErrorCorrection.cpp:144-173) given the four extension counts
-RC_HD int rc_pos_threshold(const int cnt[4], int upper, double e)
+RC_HD int rc_pos_threshold(const rc_cnt4 &cnt, int upper, double e)
 {
     int mx = 0;
-    for (int i = 0; i < 4; ++i)
-        if (cnt[i] > mx) mx = cnt[i];
+    mx = cnt.c0 > mx ? cnt.c0 : mx;
+    mx = cnt.c1 > mx ? cnt.c1 : mx;
+    mx = cnt.c2 > mx ? cnt.c2 : mx;
+    mx = cnt.c3 > mx ? cnt.c3 : mx;
     int ret = rc_bound_i(mx, e);
     if (ret < 1) ret = 1;
     if (upper > ret || upper <= 0) return ret;
@@ -366,15 +399,15 @@ RC_HD rc_kmer rc_extend_run(const rc_read_state &S, rc_kmer kc, int k, int dir, 
 // popped frame) misses and refills from there.  Pure memoisation: results cannot change.
 template <class W>
 RC_HD int rc_probe4_cached(W &w, rc_read_state &S, rc_spec_state &Z, rc_kmer kc, int dir, int pos, int to, int k,
-                           int cnt[4])
+                           rc_cnt4 &cnt)
 {
     if (Z.n > 0 && Z.dir == dir) {
         const int j = (pos - Z.pos) * dir;
         if (j >= 0 && j < Z.n && RC_U64(S.spec_code[j]) == kc.code && RC_U(S.spec_inv[j]) == kc.inv) {
-            cnt[0] = RC_U(S.spec_cnt[4 * j + 0]);
-            cnt[1] = RC_U(S.spec_cnt[4 * j + 1]);
-            cnt[2] = RC_U(S.spec_cnt[4 * j + 2]);
-            cnt[3] = RC_U(S.spec_cnt[4 * j + 3]);
+            cnt.c0 = RC_U(S.spec_cnt[4 * j + 0]);
+            cnt.c1 = RC_U(S.spec_cnt[4 * j + 1]);
+            cnt.c2 = RC_U(S.spec_cnt[4 * j + 2]);
+            cnt.c3 = RC_U(S.spec_cnt[4 * j + 3]);
             return j;
         }
     }
@@ -396,10 +429,10 @@ RC_HD int rc_probe4_cached(W &w, rc_read_state &S, rc_spec_state &Z, rc_kmer kc,
     Z.n = n;
     Z.pos = pos;
     Z.dir = dir;
-    cnt[0] = RC_U(S.spec_cnt[0]);
-    cnt[1] = RC_U(S.spec_cnt[1]);
-    cnt[2] = RC_U(S.spec_cnt[2]);
-    cnt[3] = RC_U(S.spec_cnt[3]);
+    cnt.c0 = RC_U(S.spec_cnt[0]);
+    cnt.c1 = RC_U(S.spec_cnt[1]);
+    cnt.c2 = RC_U(S.spec_cnt[2]);
+    cnt.c3 = RC_U(S.spec_cnt[3]);
     return 0;
 }
 
@@ -534,7 +567,10 @@ RC_HD int rc_keep_run(W &w, rc_read_state &S, const rc_run_params &P, const rc_s
         int bb = bottleneck;
         for (int i = j0; i < jj; ++i) bb = rc_min(bb, RC_U(S.spec_keep[i]));
         f.bottleneck = bb;
-        for (int c = 0; c < 4; ++c) f.cnt[c] = RC_U(S.spec_cnt[4 * jj + c]);
+        f.cnt.c0 = RC_U(S.spec_cnt[4 * jj + 0]);
+        f.cnt.c1 = RC_U(S.spec_cnt[4 * jj + 1]);
+        f.cnt.c2 = RC_U(S.spec_cnt[4 * jj + 2]);
+        f.cnt.c3 = RC_U(S.spec_cnt[4 * jj + 3]);
         f.mask = RC_U(S.spec_mask[jj]);
         w.stack_push(sp, f);
         ++sp;
@@ -626,24 +662,21 @@ RC_HD void rc_search(W &w, rc_read_state &S, const rc_run_params &P, rc_search_c
             continue;
         }
 
-        int cnt[4];
+        rc_cnt4 cnt;
         const int j0 = rc_probe4_cached(w, S, Z, kc, dir, pos, C.to, k, cnt);
         // descend along "keep the base" for as many cached nodes as take that branch
         if (rc_keep_run(w, S, P, Z, j0, dir, kc, pos, t, fix_cnt, bottleneck, sp) > 0) {
             have = true;
             continue;
         }
-        int threshold = rc_pos_threshold(cnt, t, P.error_rate);  // :287 / :525
+        int threshold = RC_U(rc_pos_threshold(cnt, t, P.error_rate));  // :287 / :525
         const int b = RC_U(S.base[pos]);
         const bool bvalid = b < 4;
 
         int mask = 0;  // substitution candidates, :343-352 / :577-588
         {
             const int pa = RC_U(dir > 0 ? S.polya[pos - k + 1] : S.polya[pos]);
-            if (!RC_U(S.strongb[pos]) && !(pa & 1)) {
-                for (int c = 0; c < 4; ++c)
-                    if (c != b && cnt[c] >= threshold) mask |= 1 << c;
-            }
+            if (!RC_U(S.strongb[pos]) && !(pa & 1)) mask = rc_candidates(cnt, b, threshold);
         }
 
         bool first = false;
@@ -670,13 +703,25 @@ RC_HD void rc_search(W &w, rc_read_state &S, const rc_run_params &P, rc_search_c
                 (void)c0;
                 if (m > 0) {
                     const rc_kmer tmp0 = tmp;
-                    const uint64_t hit = w.ballot64(1, m + 1, [&](int sN) {
-                        return w.get(rc_extend_run(S, tmp0, k, dir, pos + dir, sN)) >= threshold;
-                    });
-                    w.stat(4, 1);
-                    w.stat(5, m);
-                    if (hit) {
-                        const int sN = 1 + rc_ctz64(hit);
+                    // window sN is the keep-base extension of the node sN steps down the keep path, and
+                    // those were fetched with this node's round (spec_keep[], set by rc_keep_run above):
+                    // only windows beyond the cached nodes need a round of their own
+                    int mc = Z.n - 1 - j0;
+                    if (mc > m) mc = m;
+                    int sN = 0;
+                    if (mc > 0) {
+                        const uint64_t hit = w.ballot64(1, mc + 1, [&](int q) { return S.spec_keep[j0 + q] >= threshold; });
+                        if (hit) sN = 1 + rc_ctz64(hit);
+                    }
+                    if (sN == 0 && m > mc) {
+                        const uint64_t hit = w.ballot64(mc + 1, m + 1, [&](int q) {
+                            return w.get(rc_extend_run(S, tmp0, k, dir, pos + dir, q)) >= threshold;
+                        });
+                        w.stat(4, 1);
+                        w.stat(5, m - mc);
+                        if (hit) sN = mc + 1 + rc_ctz64(hit);
+                    }
+                    if (sN > 0) {
                         tmp = rc_extend_run(S, tmp0, k, dir, pos + dir, sN);
                         tmp.code = RC_U64(tmp.code);
                         tmp.inv = RC_U(tmp.inv);
@@ -720,7 +765,7 @@ RC_HD void rc_search(W &w, rc_read_state &S, const rc_run_params &P, rc_search_c
                 f.threshold = threshold;
                 f.fix_cnt = fix_cnt;
                 f.bottleneck = bottleneck;
-                for (int c = 0; c < 4; ++c) f.cnt[c] = cnt[c];
+                f.cnt = cnt;
                 f.mask = mask;
                 w.stack_push(sp, f);
                 ++sp;
@@ -732,12 +777,12 @@ RC_HD void rc_search(W &w, rc_read_state &S, const rc_run_params &P, rc_search_c
             int thr = threshold;
             if (dir > 0) {
                 for (i = pos; i < C.to; ++i) {
-                    int cn[4];
-                    if (i == pos) {
-                        for (int c = 0; c < 4; ++c) cn[c] = cnt[c];
-                    } else
+                    rc_cnt4 cn;
+                    if (i == pos)
+                        cn = cnt;
+                    else
                         rc_probe4_cached(w, S, Z, tmp, dir, i, C.to, k, cn);
-                    thr = rc_pos_threshold(cn, t, P.error_rate);
+                    thr = RC_U(rc_pos_threshold(cn, t, P.error_rate));
                     int bb = RC_U(S.base[i]);
                     tmp = rc_append(tmp, k, bb);
                     c1 = (bb < 4) ? rc_sel4(cn, bb) : 0;
@@ -752,12 +797,12 @@ RC_HD void rc_search(W &w, rc_read_state &S, const rc_run_params &P, rc_search_c
                 nt = t;
             } else {
                 for (i = pos; i >= C.to; --i) {
-                    int cn[4];
-                    if (i == pos) {
-                        for (int c = 0; c < 4; ++c) cn[c] = cnt[c];
-                    } else
+                    rc_cnt4 cn;
+                    if (i == pos)
+                        cn = cnt;
+                    else
                         rc_probe4_cached(w, S, Z, tmp, dir, i, C.to, k, cn);
-                    thr = rc_pos_threshold(cn, t, P.error_rate);
+                    thr = RC_U(rc_pos_threshold(cn, t, P.error_rate));
                     int bb = RC_U(S.base[i]);
                     tmp = rc_prepend(tmp, k, bb);
                     c1 = (bb < 4) ? rc_sel4(cn, bb) : 0;
@@ -820,7 +865,7 @@ RC_HD int rc_correct_read(W &w, rc_read_state &S, const rc_run_params &P, int pa
     // initial thresholds, :793-842
     int strong = strong0, trust;
     bool flag = false;
-    trust = rc_bound_i(strong, P.error_rate);
+    trust = RC_U(rc_bound_i(strong, P.error_rate));
     if (info0 & 1) {
         if (strong >= 20 && (info0 & 2) && trust < 3) {
             flag = true;
@@ -828,7 +873,7 @@ RC_HD int rc_correct_read(W &w, rc_read_state &S, const rc_run_params &P, int pa
         }
     }
     if (pair_t >= 1 && strong > pair_t) {
-        if (!flag || pair_t < 20) trust = rc_bound_i(pair_t, P.error_rate);
+        if (!flag || pair_t < 20) trust = RC_U(rc_bound_i(pair_t, P.error_rate));
         strong = pair_t;
     }
     if (trust < 2) trust = 2;
@@ -1038,7 +1083,7 @@ RC_HD int rc_correct_read(W &w, rc_read_state &S, const rc_run_params &P, int pa
                     if (RC_U(S.seg[i].top2[1]) >= best_bottleneck) best_fix_cnt *= 2;
             }
             if (best_bottleneck != -1 && iter == 0 &&
-                rc_less_than_bound(best_bottleneck, strong, P.error_rate))  // :1195
+                RC_U(rc_less_than_bound(best_bottleneck, strong, P.error_rate) ? 1 : 0))  // :1195
                 force_next = true;
             if (best_fix_cnt >= 2)
                 return -1;
@@ -1068,7 +1113,7 @@ RC_HD int rc_correct_read(W &w, rc_read_state &S, const rc_run_params &P, int pa
         if (has_drop) {
             ++iter;
             int vi = RC_U(S.v[i]);
-            trust = rc_bound_i(vi, P.error_rate);
+            trust = RC_U(rc_bound_i(vi, P.error_rate));
             strong = vi;
         } else
             break;

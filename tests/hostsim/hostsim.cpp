@@ -22,7 +22,7 @@ struct HostWave {
     int k;
     const char *qualp;
     std::vector<rc_frame> stack;
-    long max_sp = 0;
+    long max_sp = 0, pushes = 0, pops = 0;
 
     void sync() {}
     void phase(int) {}
@@ -71,9 +71,10 @@ struct HostWave {
     {
         if ((int)stack.size() <= sp) stack.resize(sp + 1);
         stack[sp] = f;
+        ++pushes;
         if (sp + 1 > max_sp) max_sp = sp + 1;
     }
-    void stack_top(int idx, rc_frame &f) { f = stack[idx]; }
+    void stack_top(int idx, rc_frame &f) { f = stack[idx]; ++pops; }
     void stack_set_mask(int idx, int mask) { stack[idx].mask = mask; }
 };
 
@@ -230,7 +231,7 @@ void hostsim_correct_batch(const rco_params *p, const rco_table *t, rco_batch *b
         st->probes4 = w.gets;
         st->probes1 = 0;
         st->max_stack = w.max_sp;
-        if (getenv("HOSTSIM_STATS")) fprintf(stderr, "keep_run calls=%ld sumR=%ld sum_avail=%ld refills=%ld gap_attempts=%ld gap_probes=%ld reads=%ld\n", w.stats[0], w.stats[1], w.stats[2], w.stats[3], w.stats[4], w.stats[5], (long)total);
+        if (getenv("HOSTSIM_STATS")) fprintf(stderr, "keep_run calls=%ld sumR=%ld sum_avail=%ld refills=%ld gap_attempts=%ld gap_probes=%ld pushes=%ld pops=%ld reads=%ld\n", w.stats[0], w.stats[1], w.stats[2], w.stats[3], w.stats[4], w.stats[5], w.pushes, w.pops, (long)total);
         st->reads = (long)total;
     }
 }
