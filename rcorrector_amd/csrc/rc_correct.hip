@@ -15,7 +15,7 @@
 // PROF = per-phase s_memtime accounting (dev aid, RC_PHASE_PROF=1); compiled out otherwise
 // TRACE = record what the reference prints under -verbose for every threshold iteration
 //         (ErrorCorrection.cpp:856-857, :1088-1094) into a per-read record; compiled out otherwise
-template <bool PROF, bool TRACE = false>
+template <bool PROF, bool TRACE = false, bool SORT_REGS = true>
 struct DevWaveT {
     static const int STRIDE = 64;
     int lane;
@@ -211,11 +211,15 @@ struct DevWaveT {
 
     // ascending sort of a[0..n) in LDS (register network up to 256 elements, LDS bitonic above;
     // a[] has room for the next power of two)
+    // SORT_REGS = false: LDS network only -- k_correct sorts on cold paths only (threshold retries, the
+    // fused front end of long single-end reads) and should not carry three unrolled networks
     __device__ __forceinline__ void sort(int *a, int n)
     {
-        if (n <= 64) return bitonic_regs<1>(a, n);
-        if (n <= 128) return bitonic_regs<2>(a, n);
-        if (n <= 256) return bitonic_regs<4>(a, n);
+        if (SORT_REGS) {
+            if (n <= 64) return bitonic_regs<1>(a, n);
+            if (n <= 128) return bitonic_regs<2>(a, n);
+            if (n <= 256) return bitonic_regs<4>(a, n);
+        }
         int n2 = 1;
         while (n2 < n) n2 <<= 1;
         for (int i = n + lane; i < n2; i += 64) a[i] = 2147483647;
@@ -271,9 +275,14 @@ struct DevWaveT {
 };
 typedef DevWaveT<false> DevWave;
 
+#ifndef RC_DEQUEUE
+#define RC_DEQUEUE 8  // reads per work-counter atomic
+#endif
+#define RC_META_WORDS 6  // per read of a dequeued chunk: index, offset, end offset, strong, info, mate's strong
+
 struct rc_lds_layout {
     int cap, cap2;
-    size_t o_counts, o_v, o_isl, o_seg, o_base, o_path, o_best, o_strongb, o_polya, o_qual, o_masks, o_spec, o_pk, total;
+    size_t o_counts, o_v, o_isl, o_seg, o_base, o_path, o_best, o_strongb, o_polya, o_qual, o_masks, o_spec, o_pk, o_meta, total;
     int mask_words;
 };
 
@@ -299,6 +308,8 @@ static __host__ __device__ constexpr inline rc_lds_layout rc_layout(int cap)
     o += (size_t)RC_SPEC * (8 + 4 * 4 + 4 + 4 * 4);
     L.o_pk = o;
     o += (size_t)(cap / 16 + 4) * 4;
+    L.o_meta = o;
+    o += (size_t)RC_DEQUEUE * RC_META_WORDS * 4;
     L.o_counts = o;
     o += (size_t)cap * 4;
     L.o_v = o;
@@ -389,10 +400,8 @@ struct rc_kernel_args {
 };
 
 template <class W>
-__device__ __forceinline__ void rc_load_read(W &w, const rc_kernel_args &A, rc_read_state &S, uint32_t r, int lane, bool with_qual)
+__device__ __forceinline__ void rc_load_read(W &w, const rc_kernel_args &A, rc_read_state &S, uint32_t o, int len, int lane, bool with_qual)
 {
-    const uint32_t o = (uint32_t)w.uni((int)A.off[r]);
-    const int len = w.uni((int)(A.off[r + 1] - o) - 1);
     S.len = len;
     S.kcnt = len >= A.P.k ? len - A.P.k + 1 : 0;
     for (int i = lane; i < len; i += 64) {
@@ -488,14 +497,11 @@ __global__ __launch_bounds__(64) void k_threshold(rc_kernel_args A)
 
 #include "rc_quarter.h"
 
-#ifndef RC_DEQUEUE
-#define RC_DEQUEUE 8  // reads per work-counter atomic
-#endif
 #ifndef RC_HEADS
 #define RC_HEADS 8    // work-queue heads (one per XCD)
 #endif
 #ifndef RC_K3_WAVES
-#define RC_K3_WAVES 6  // waves per SIMD the register allocation of k_correct is held to
+#define RC_K3_WAVES 8  // waves per SIMD the register allocation of k_correct is held to (measured: 5: 104, 6: 92, 7: 86, 8: 81 ms)
 #endif
 
 // CAP = LDS capacity class (bases per read, a multiple of 64): the layout is a compile-time
@@ -516,7 +522,7 @@ __global__ __launch_bounds__(64, rc_k3_waves(CAP)) void k_correct(rc_kernel_args
     __shared__ __attribute__((aligned(16))) uint8_t lds[L.total];
     rc_read_state S;
     rc_carve(lds, L, S);
-    DevWaveT<PROF, TRACE> w;
+    DevWaveT<PROF, TRACE, false> w;
     w.lane = threadIdx.x;
     w.tr_cap = A.trace_cap;
     if (PROF) w.t_last = __builtin_readcyclecounter();
@@ -531,7 +537,8 @@ __global__ __launch_bounds__(64, rc_k3_waves(CAP)) void k_correct(rc_kernel_args
     // for speed, nothing depends on it), takes RC_DEQUEUE entries per atomic, and moves on to the
     // next slice when one is exhausted, so no slice is left behind whatever the placement.
     const uint32_t n_work = A.n_work ? (uint32_t)__builtin_amdgcn_readfirstlane((int)*A.n_work) : A.n;
-    uint32_t chunk_lo = 0, chunk_hi = 0;
+    uint32_t chunk_lo = 0, chunk_hi = 0, chunk_base = 0;
+    uint32_t *meta = reinterpret_cast<uint32_t *>(lds + L.o_meta);
     int head = (int)(blockIdx.x % RC_HEADS), heads_done = 0;
     for (;;) {
         if (chunk_lo >= chunk_hi) {
@@ -555,33 +562,50 @@ __global__ __launch_bounds__(64, rc_k3_waves(CAP)) void k_correct(rc_kernel_args
                 if (PROF && w.lane == 0) atomicMin(A.phase_cycles + 9, (unsigned long long)wall_clock64());
                 break;
             }
+            // everything k_correct needs to know about the chunk's reads before it can load them, fetched
+            // by one lane per read in two dependent round trips per chunk instead of six per read
+            chunk_base = chunk_lo;
+            if ((uint32_t)w.lane < chunk_hi - chunk_lo) {
+                uint32_t ri = chunk_lo + (uint32_t)w.lane;
+                if (A.worklist) ri = A.worklist[ri];
+                uint32_t *mw = meta + w.lane * RC_META_WORDS;
+                mw[0] = ri;
+                mw[1] = A.off[ri];
+                mw[2] = A.off[ri + 1];
+                if (!A.fused_front_end) {
+                    mw[3] = (uint32_t)A.strong[ri];
+                    mw[4] = (uint32_t)A.info[ri];
+                    if (A.mode == 1) {
+                        const uint32_t half = A.n >> 1;
+                        mw[5] = (uint32_t)A.strong[ri < half ? ri + half : ri - half];
+                    } else if (A.mode == 2)
+                        mw[5] = (uint32_t)A.strong[ri ^ 1u];
+                }
+            }
+            w.sync();
         }
-        uint32_t r = chunk_lo++;
-        if (A.worklist) r = (uint32_t)__builtin_amdgcn_readfirstlane((int)A.worklist[r]);
+        const int ci = (int)(chunk_lo - chunk_base);
+        ++chunk_lo;
+        const uint32_t *me = meta + ci * RC_META_WORDS;
+        const uint32_t r = (uint32_t)w.uni((int)me[0]);
+        const uint32_t o = (uint32_t)w.uni((int)me[1]);
         w.phase(0);
         if (TRACE) {
             w.tr = A.trace + (size_t)r * (2 + (size_t)A.trace_cap * RC_TRACE_WORDS);
             if (w.lane == 0) w.tr[0] = w.tr[1] = 0;
             w.sync();
         }
-        rc_load_read(w, A, S, r, w.lane, true);
-        const uint32_t o = (uint32_t)w.uni((int)A.off[r]);
+        rc_load_read(w, A, S, o, w.uni((int)(me[2] - o) - 1), w.lane, true);
         int strong0, info0;
         if (A.fused_front_end) {  // single-end: no mate to wait for, the threshold pass runs right here
             w.phase(1);
             strong0 = rc_front_end(w, S, A.P, &info0);
         } else {
-            strong0 = w.uni(A.strong[r]);
-            info0 = w.uni(A.info[r]);
+            strong0 = w.uni((int)me[3]);
+            info0 = w.uni((int)me[4]);
         }
         int pair_t = -1;
-        if (A.mode == 1) {
-            const uint32_t half = A.n >> 1;
-            const uint32_t mate = r < half ? r + half : r - half;
-            pair_t = rc_min(strong0, w.uni(A.strong[mate]));
-        } else if (A.mode == 2) {
-            pair_t = rc_min(strong0, w.uni(A.strong[r ^ 1u]));
-        }
+        if (A.mode != 0) pair_t = rc_min(strong0, w.uni((int)me[5]));
         w.phase(1);
         if (!A.fused_front_end && S.kcnt > 0 && !(info0 & 4)) rc_polya_flags(w, S, A.P.k);
         const int ret = rc_correct_read(w, S, A.P, pair_t, strong0, info0);

@@ -1047,23 +1047,23 @@ RC_HD int rc_correct_read(W &w, rc_read_state &S, const rc_run_params &P, int pa
                 C.max_fix_cnt = (st - sf + 1) * P.max_fix_per_k / k * 2 + 1;
                 if (C.max_fix_cnt < P.max_fix_per_k) C.max_fix_cnt = P.max_fix_per_k;
                 C.best_bottleneck = -1;
+                int a;  // first base of the anchor k-mer
                 if (RC_U(S.seg[si].lanchor) >= RC_U(S.seg[si].ranchor)) {
                     int extend = (st == len) ? 0 : (k - 1);
-                    int a = sf - k;
+                    a = sf - k;
                     if (a < 0) return -1;  // the reference reads seq[-1] here (undefined)
                     C.dir = 1;
                     C.start = a + k;
                     C.to = st + extend;
-                    rc_search(w, S, P, C, rc_anchor(w, S, k, a), trust);
                 } else {
                     int extend = (sf == 0) ? 0 : (k - 1);
-                    int a = st + 1;
+                    a = st + 1;
                     if (a + k > len) return -1;  // undefined in the reference
                     C.dir = -1;
                     C.start = a - 1;
                     C.to = sf - extend;
-                    rc_search(w, S, P, C, rc_anchor(w, S, k, a), trust);
                 }
+                rc_search(w, S, P, C, rc_anchor(w, S, k, a), trust);  // one body for both directions
                 S.seg[si].top2[0] = C.top2a;
                 S.seg[si].top2[1] = C.top2b;
                 w.sync();
