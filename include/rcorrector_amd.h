@@ -84,6 +84,11 @@ int rc_table_lookup(rc_ctx *ctx, const uint64_t *codes, size_t n, int32_t *count
 /* every stored (canonical code, count) pair, unspecified order -- what `jellyfish dump` would
  * print (run_rcorrector.pl:280); *n_out = number stored (may exceed cap: call again) */
 int rc_table_export(rc_ctx *ctx, uint64_t *codes, int32_t *counts, size_t cap, size_t *n_out);
+/* 64-bit digest of the table's content (every stored canonical code with its count; independent of
+ * the bucket layout): equal digests = replicas that answer every Store::GetCount alike.  The
+ * multi-GPU callers compare it across devices after replicating the table (main.cpp:294-308 loads ONE
+ * Store for all workers). */
+int rc_table_digest(rc_ctx *ctx, uint64_t *digest);
 /* bytes of HBM held by the table, number of buckets, number of stored entries */
 int rc_table_stats(const rc_ctx *ctx, uint64_t *bytes, uint64_t *buckets, uint64_t *entries);
 
@@ -124,6 +129,21 @@ typedef struct {
     int32_t *ret, *l, *m, *h;
 } rc_batch;
 int rc_correct_batch(rc_ctx *ctx, rc_batch *b);
+
+/* The same, asynchronous: up to RC_MAX_SLOTS batches in flight in ONE context, so that the upload
+ * of batch N+1, the kernels of batch N and the download of batch N-1 overlap -- what the reference
+ * gets from filling the next batch while its worker threads correct the current one
+ * (main.cpp:479-516).  rc_submit(slot) starts a batch and returns; the descriptor is copied, the
+ * buffers it points to must stay valid and untouched until rc_wait(slot) returns, after which they
+ * hold the results (and rc_summary() includes the batch).  Batches complete in submission order.
+ * Buffers obtained from rc_host_alloc() are page-locked: the DMA engines read and write them
+ * directly; any other buffer is staged through pinned memory the slot owns (one extra copy each
+ * way).  rc_correct_batch(b) == rc_submit(b, 0); rc_wait(0).  One host thread per context. */
+#define RC_MAX_SLOTS 4
+int rc_submit(rc_ctx *ctx, const rc_batch *b, int slot);
+int rc_wait(rc_ctx *ctx, int slot);
+int rc_host_alloc(rc_ctx *ctx, size_t bytes, void **out);
+int rc_host_free(rc_ctx *ctx, void *p);
 
 /* rc_correct_batch plus everything the reference prints per read under -verbose (VERBOSE,
  * ErrorCorrection.cpp:15,686-689,759-770,856-857,1088-1094,1590-1597), as data; the caller formats
@@ -171,6 +191,12 @@ int rc_sync(rc_ctx *ctx);
 /* ---- measurement ----------------------------------------------------------------------------- */
 /* with profiling on, every kernel launch is bracketed by HIP events on the context's stream */
 int rc_profile_enable(rc_ctx *ctx, int on);
+/* on = 2 additionally runs the instrumented build of the correction kernel (slower; same results),
+ * which counts, over the launches since the last reset: the reads the threshold kernel could not
+ * finish and handed to the correction kernel, their gather rounds (one round = up to 64 table
+ * probes issued together) and the table buckets they read -- the denominators of the kernel's
+ * request-rate figures. */
+int rc_profile_correct_counters(rc_ctx *ctx, uint64_t *reads_listed, uint64_t *gather_rounds, uint64_t *bucket_requests);
 /* kernel 0 = probe, 1 = threshold, 2 = correct; accumulated since the last reset */
 int rc_profile_get(rc_ctx *ctx, int kernel, double *total_ms, uint64_t *launches);
 int rc_profile_reset(rc_ctx *ctx);
@@ -181,7 +207,9 @@ int rc_profile_reset(rc_ctx *ctx);
  * host's bit for bit. */
 int rc_selftest_get_bound(rc_ctx *ctx, const int32_t *c, size_t n, double error_rate, int32_t *out_int, double *out_dbl);
 
-/* summary counters, struct _summary main.cpp:32-36,73-79 */
+/* summary counters, struct _summary main.cpp:32-36,73-79: reads and corrected bases of every batch
+ * this context has corrected through any entry point (accumulated on the device; waits for the
+ * context's kernels) */
 int rc_summary(const rc_ctx *ctx, uint64_t *total_reads, uint64_t *total_corrections);
 
 #ifdef __cplusplus

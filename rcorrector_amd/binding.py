@@ -13,10 +13,10 @@ ABI_SYMBOLS = [
     "rc_create", "rc_destroy", "rc_last_error",
     "rc_table_build", "rc_table_build_device", "rc_table_load_jfdump",
     "rc_table_count_begin", "rc_table_count_add", "rc_table_count_add_device", "rc_table_count_finish",
-    "rc_table_count_reads_device", "rc_table_write_jfdump", "rc_table_share", "rc_table_lookup", "rc_table_export", "rc_table_stats",
+    "rc_table_count_reads_device", "rc_table_write_jfdump", "rc_table_share", "rc_table_lookup", "rc_table_export", "rc_table_digest", "rc_table_stats",
     "rc_estimate_error_rate", "rc_bad_quality_from_hist", "rc_set_run_params",
-    "rc_correct_batch", "rc_correct_batch_traced", "rc_correct_device", "rc_strong_threshold_device", "rc_probe_device", "rc_sync",
-    "rc_profile_enable", "rc_profile_get", "rc_profile_reset", "rc_selftest_get_bound", "rc_summary",
+    "rc_correct_batch", "rc_submit", "rc_wait", "rc_host_alloc", "rc_host_free", "rc_correct_batch_traced", "rc_correct_device", "rc_strong_threshold_device", "rc_probe_device", "rc_sync",
+    "rc_profile_enable", "rc_profile_get", "rc_profile_reset", "rc_profile_correct_counters", "rc_selftest_get_bound", "rc_summary",
 ]
 
 
@@ -96,12 +96,17 @@ def load_library():
     L.rc_table_share.argtypes = [vp, vp]
     L.rc_table_lookup.argtypes = [vp, vp, sz, vp]
     L.rc_table_export.argtypes = [vp, vp, vp, sz, C.POINTER(C.c_size_t)]
+    L.rc_table_digest.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.rc_table_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.rc_estimate_error_rate.argtypes = [vp, C.c_double, C.POINTER(C.c_double)]
     L.rc_bad_quality_from_hist.restype = C.c_char
     L.rc_bad_quality_from_hist.argtypes = [vp, vp, C.c_int32]
     L.rc_set_run_params.argtypes = [vp, C.c_double, C.c_char]
     L.rc_correct_batch.argtypes = [vp, C.POINTER(_Batch)]
+    L.rc_submit.argtypes = [vp, C.POINTER(_Batch), C.c_int]
+    L.rc_wait.argtypes = [vp, C.c_int]
+    L.rc_host_alloc.argtypes = [vp, sz, C.POINTER(C.c_void_p)]
+    L.rc_host_free.argtypes = [vp, vp]
     L.rc_correct_device.argtypes = [vp, C.POINTER(_DeviceBatch)]
     L.rc_probe_device.argtypes = [vp, vp, C.c_uint64, vp]
     L.rc_strong_threshold_device.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint64, C.c_int32, vp]
@@ -109,6 +114,7 @@ def load_library():
     L.rc_profile_enable.argtypes = [vp, C.c_int]
     L.rc_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.rc_profile_reset.argtypes = [vp]
+    L.rc_profile_correct_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.rc_selftest_get_bound.argtypes = [vp, vp, sz, C.c_double, vp, vp]
     L.rc_summary.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     _lib = L
@@ -165,6 +171,9 @@ class Context:
 
     def close(self):
         if getattr(self, "_h", None):
+            for p in getattr(self, "_pinned", []):
+                self._L.rc_host_free(self._h, p)
+            self._pinned = []
             self._L.rc_destroy(self._h)
             self._h = None
 
@@ -238,6 +247,12 @@ class Context:
         self._ck(self._L.rc_table_export(self._h, codes.ctypes.data, counts.ctypes.data, cap, C.byref(n)))
         return codes[:n.value], counts[:n.value]
 
+    def table_digest(self):
+        """64-bit digest of the table's content (layout independent)."""
+        v = C.c_uint64(0)
+        self._ck(self._L.rc_table_digest(self._h, C.byref(v)))
+        return v.value
+
     def table_stats(self):
         b, n, e = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
         self._ck(self._L.rc_table_stats(self._h, C.byref(b), C.byref(n), C.byref(e)))
@@ -260,20 +275,65 @@ class Context:
         self._ck(self._L.rc_set_run_params(self._h, error_rate, bad_quality))
 
     # ---- correction ----
+    @staticmethod
+    def _arena(a, what):
+        # the library reads and (for seq) rewrites these buffers through raw pointers: a wrong dtype or a
+        # strided view would silently be garbage, so refuse instead of converting (seq is corrected in place)
+        if not (isinstance(a, np.ndarray) and a.dtype == np.uint8 and a.flags.c_contiguous):
+            raise TypeError("%s must be a C-contiguous uint8 numpy array" % what)
+        return a
+
+    def _batch(self, mode, seq, qual, off, seq2, qual2, off2, res=None):
+        off = np.ascontiguousarray(off, dtype=np.uint32)
+        n = len(off) - 1
+        total = 2 * n if mode == 1 else n
+        if res is None:
+            res = [np.zeros(total, dtype=np.int32) for _ in range(4)]
+        b = _Batch()
+        b.mode, b.n = mode, n
+        keep = [off, res]
+        b.seq, b.qual, b.off = self._arena(seq, "seq").ctypes.data, self._arena(qual, "qual").ctypes.data, off.ctypes.data
+        if mode == 1:
+            off2 = np.ascontiguousarray(off2, dtype=np.uint32)
+            keep.append(off2)
+            b.seq2, b.qual2, b.off2 = self._arena(seq2, "seq2").ctypes.data, self._arena(qual2, "qual2").ctypes.data, off2.ctypes.data
+        b.ret, b.l, b.m, b.h = (r.ctypes.data for r in res)
+        return b, res, keep
+
     def correct_batch(self, mode, seq, qual, off, seq2=None, qual2=None, off2=None):
         """Host-buffer batch (rc_correct_batch).  seq arenas are corrected IN PLACE.
         Returns (ret, l, m, h)."""
-        n = len(off) - 1
-        total = 2 * n if mode == 1 else n
-        res = [np.zeros(total, dtype=np.int32) for _ in range(4)]
-        b = _Batch()
-        b.mode, b.n = mode, n
-        b.seq, b.qual, b.off = seq.ctypes.data, qual.ctypes.data, off.ctypes.data
-        if mode == 1:
-            b.seq2, b.qual2, b.off2 = seq2.ctypes.data, qual2.ctypes.data, off2.ctypes.data
-        b.ret, b.l, b.m, b.h = (r.ctypes.data for r in res)
+        b, res, _keep = self._batch(mode, seq, qual, off, seq2, qual2, off2)
         self._ck(self._L.rc_correct_batch(self._h, C.byref(b)))
         return tuple(res)
+
+    def submit(self, slot, mode, seq, qual, off, seq2=None, qual2=None, off2=None, res=None):
+        """rc_submit: starts a batch in `slot`; wait(slot) returns (ret, l, m, h).  The arrays must not
+        be touched until then.  res: optional list of four int32 arrays to receive the results
+        (e.g. pinned ones from host_array)."""
+        b, res, keep = self._batch(mode, seq, qual, off, seq2, qual2, off2, res)
+        self._ck(self._L.rc_submit(self._h, C.byref(b), slot))
+        if not hasattr(self, "_inflight"):
+            self._inflight = {}
+        self._inflight[slot] = (res, keep, (seq, qual, seq2, qual2))
+
+    def wait(self, slot):
+        self._ck(self._L.rc_wait(self._h, slot))
+        res, _keep, _arr = self._inflight.pop(slot)
+        return tuple(res)
+
+    def host_array(self, n, dtype=np.uint8):
+        """A page-locked numpy array (rc_host_alloc): rc_submit DMAs straight from / into it.
+        Freed with the context."""
+        dt = np.dtype(dtype)
+        p = C.c_void_p(0)
+        self._ck(self._L.rc_host_alloc(self._h, max(1, n * dt.itemsize), C.byref(p)))
+        if not hasattr(self, "_pinned"):
+            self._pinned = []
+        self._pinned.append(p.value)
+        buf = (C.c_uint8 * (n * dt.itemsize)).from_address(p.value)
+        return np.frombuffer(buf, dtype=dt, count=n)
+
 
     def correct_device(self, mode, n_reads, nbytes, max_read_len, d_seq, d_qual, d_off, d_ret, d_l, d_m, d_h):
         b = _DeviceBatch(mode, n_reads, nbytes, max_read_len, _ptr(d_seq), _ptr(d_qual), _ptr(d_off),
@@ -291,7 +351,14 @@ class Context:
 
     # ---- measurement ----
     def profile(self, on=True):
-        self._ck(self._L.rc_profile_enable(self._h, 1 if on else 0))
+        """on: False/0 off, True/1 kernel timers, 2 also the instrumented correction kernel."""
+        self._ck(self._L.rc_profile_enable(self._h, int(on)))
+
+    def profile_correct_counters(self):
+        """(reads handed to the correction kernel, their gather rounds, table buckets read) since the last reset."""
+        a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        self._ck(self._L.rc_profile_correct_counters(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     def profile_reset(self):
         self._ck(self._L.rc_profile_reset(self._h))

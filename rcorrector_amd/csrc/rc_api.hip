@@ -30,7 +30,23 @@ struct rc_dump_cache {
 
 struct rc_ctx_full : rc_ctx {
     rc_dump_cache dump;
-    uint64_t total_reads = 0, total_corrections = 0;
+};
+
+// pinned host buffer, grow-only
+struct rc_hbuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+// one batch in flight on the asynchronous host-buffer path
+struct rc_slot {
+    bool busy = false;
+    rc_batch b;                      // the caller's descriptor (its buffers stay valid until rc_wait)
+    size_t total_reads = 0, bytes1 = 0, bytes2 = 0;
+    bool seq_pinned = false, res_pinned = false;  // the caller's buffers are page-locked: DMA straight from / to them
+    rc_hbuf p_seq, p_qual, p_off, p_res;           // pinned staging (seq/qual only when the caller's are pageable)
+    rc_dbuf d_seq, d_qual, d_off, d_res;
+    hipEvent_t e_h2d = nullptr, e_k = nullptr, e_done = nullptr;
 };
 
 static thread_local char g_create_err[512];
@@ -116,7 +132,8 @@ rc_ctx *rc_create(const rc_config *cfg, char *errbuf, size_t errbuf_len)
         return fail("rc_create: could not create stream/events");
     }
     ctx->work.bytes = RC_WORK_BYTES;
-    if (const char *e = getenv("RC_PHASE_PROF")) ctx->phase_prof = atoi(e) != 0;
+    (void)hipMemset(ctx->work.p, 0, RC_WORK_BYTES);
+    if (const char *e = getenv("RC_PHASE_PROF")) ctx->phase_prof = ctx->phase_prof_print = atoi(e) != 0;
     if (const char *e = getenv("RC_TABLE_LOAD")) ctx->table_load = atof(e);  // tuning knob
     ctx->env_k2_wave_per_read = getenv("RC_K2_WAVE_PER_READ") != nullptr;  // dev: force the wave-per-read threshold kernel
     ctx->env_no_classify = getenv("RC_NO_CLASSIFY") != nullptr;            // dev: every read goes through k_correct
@@ -135,6 +152,24 @@ void rc_destroy(rc_ctx *c)
                        &ctx->h_seq, &ctx->h_qual, &ctx->h_off, &ctx->h_res, &ctx->trace, &ctx->cls, &ctx->worklist, &ctx->sel_tmp};
     for (rc_dbuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
+    if (ctx->slots) {
+        for (int i = 0; i < RC_MAX_SLOTS; ++i) {
+            rc_slot &sl = ctx->slots[i];
+            if (sl.e_done) (void)hipEventSynchronize(sl.e_done);
+            rc_hbuf *hb[] = {&sl.p_seq, &sl.p_qual, &sl.p_off, &sl.p_res};
+            for (rc_hbuf *h : hb)
+                if (h->p) (void)hipHostFree(h->p);
+            rc_dbuf *db[] = {&sl.d_seq, &sl.d_qual, &sl.d_off, &sl.d_res};
+            for (rc_dbuf *d : db)
+                if (d->p) (void)hipFree(d->p);
+            hipEvent_t ev[] = {sl.e_h2d, sl.e_k, sl.e_done};
+            for (hipEvent_t e : ev)
+                if (e) (void)hipEventDestroy(e);
+        }
+        delete[] ctx->slots;
+    }
+    if (ctx->s_h2d) (void)hipStreamDestroy(ctx->s_h2d);
+    if (ctx->s_d2h) (void)hipStreamDestroy(ctx->s_d2h);
     if (ctx->cnt_keys) (void)hipFree(ctx->cnt_keys);
     if (ctx->cnt_vals) (void)hipFree(ctx->cnt_vals);
     if (ctx->d_buckets && !ctx->buckets_borrowed) (void)hipFree(ctx->d_buckets);
@@ -604,6 +639,26 @@ int rc_table_export(rc_ctx *ctx, uint64_t *codes, int32_t *counts, size_t cap, s
     return RC_OK;
 }
 
+int rc_table_digest(rc_ctx *ctx, uint64_t *digest)
+{
+    if (!ctx || !digest) return RC_ERR_ARG;
+    if (!ctx->d_buckets) {
+        rc_set_error(ctx, "digest: no k-mer table loaded");
+        return RC_ERR_STATE;
+    }
+    RC_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    rc_dev_tmp b;
+    unsigned long long v = 0;
+    RC_CHECK_HIP(ctx, b.alloc(8));
+    RC_CHECK_HIP(ctx, hipMemsetAsync(b.p, 0, 8, ctx->stream));
+    int rc = rc_launch_digest(ctx, b.as<unsigned long long>());
+    if (rc) return rc;
+    RC_CHECK_HIP(ctx, hipMemcpyAsync(&v, b.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *digest = v;
+    return RC_OK;
+}
+
 int rc_table_stats(const rc_ctx *ctx, uint64_t *bytes, uint64_t *buckets, uint64_t *entries)
 {
     if (!ctx) return RC_ERR_ARG;
@@ -765,7 +820,8 @@ int rc_correct_device(rc_ctx *ctx, const rc_device_batch *b)
             return rc;
     }
     if ((rc = rc_launch_correct(ctx, a))) return rc;
-    return RC_OK;
+    // UpdateSummary (main.cpp:73-79), on the device: the counters live in HBM until rc_summary() asks
+    return rc_launch_summary(ctx, a.ret, a.n);
 }
 
 // GetStrongTrustedThreshold (ErrorCorrection.h:26, ErrorCorrection.cpp:1482-1565) for every read of
@@ -806,7 +862,15 @@ int rc_sync(rc_ctx *ctx)
 
 static int correct_batch_impl(rc_ctx *c, rc_batch *b, rc_trace *t);
 
-int rc_correct_batch(rc_ctx *c, rc_batch *b) { return correct_batch_impl(c, b, nullptr); }
+int rc_submit(rc_ctx *c, const rc_batch *b, int slot);
+int rc_wait(rc_ctx *c, int slot);
+
+int rc_correct_batch(rc_ctx *c, rc_batch *b)
+{
+    int rc = rc_submit(c, b, 0);
+    if (rc) return rc;
+    return rc_wait(c, 0);
+}
 
 // rc_correct_batch + what the reference prints under -verbose (VERBOSE, ErrorCorrection.cpp:15):
 // the counts before (:759-770) and after (:1590-1597) come from two extra runs of the probe
@@ -902,9 +966,204 @@ static int correct_batch_impl(rc_ctx *c, rc_batch *b, rc_trace *t)
         }
     }
     RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (size_t i = 0; i < total_reads; ++i) {  // UpdateSummary, main.cpp:73-79
-        ++ctx->total_reads;
-        if (b->ret[i] > 0) ctx->total_corrections += (uint64_t)b->ret[i];
+    return RC_OK;
+}
+
+// ---- asynchronous host-buffer path ---------------------------------------------------------------
+// The reference overlaps the I/O of batch N+1 with the correction of batch N by handing batches to
+// worker threads (main.cpp:479-516).  Here one context keeps up to RC_MAX_SLOTS batches in flight on
+// three streams: H2D(N+1) || kernels(N) || D2H(N-1).  Scratch memory of the kernels is shared --
+// they serialise on the compute stream -- only the arenas and result arrays exist per slot.
+static int hbuf_reserve(rc_ctx *ctx, rc_hbuf *h, size_t bytes)
+{
+    if (bytes <= h->bytes) return RC_OK;
+    if (h->p) (void)hipHostFree(h->p);
+    h->p = nullptr;
+    h->bytes = 0;
+    const size_t want = bytes + bytes / 8 + 4096;
+    RC_CHECK_HIP(ctx, hipHostMalloc(&h->p, want, hipHostMallocDefault));
+    h->bytes = want;
+    return RC_OK;
+}
+
+static bool is_pinned(const void *p)
+{
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();  // pageable memory the runtime has never seen
+        return false;
+    }
+    return at.type == hipMemoryTypeHost;
+}
+
+int rc_host_alloc(rc_ctx *ctx, size_t bytes, void **out)
+{
+    if (!ctx || !out) return RC_ERR_ARG;
+    RC_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    RC_CHECK_HIP(ctx, hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return RC_OK;
+}
+
+int rc_host_free(rc_ctx *ctx, void *p)
+{
+    if (!ctx) return RC_ERR_ARG;
+    if (p) RC_CHECK_HIP(ctx, hipHostFree(p));
+    return RC_OK;
+}
+
+static int slots_init(rc_ctx *ctx)
+{
+    if (ctx->slots) return RC_OK;
+    RC_CHECK_HIP(ctx, hipStreamCreateWithFlags(&ctx->s_h2d, hipStreamNonBlocking));
+    RC_CHECK_HIP(ctx, hipStreamCreateWithFlags(&ctx->s_d2h, hipStreamNonBlocking));
+    ctx->slots = new (std::nothrow) rc_slot[RC_MAX_SLOTS];
+    if (!ctx->slots) return RC_ERR_NOMEM;
+    for (int i = 0; i < RC_MAX_SLOTS; ++i) {
+        rc_slot &sl = ctx->slots[i];
+        RC_CHECK_HIP(ctx, hipEventCreateWithFlags(&sl.e_h2d, hipEventDisableTiming));
+        RC_CHECK_HIP(ctx, hipEventCreateWithFlags(&sl.e_k, hipEventDisableTiming));
+        RC_CHECK_HIP(ctx, hipEventCreateWithFlags(&sl.e_done, hipEventDisableTiming));
+    }
+    return RC_OK;
+}
+
+int rc_submit(rc_ctx *c, const rc_batch *b, int slot)
+{
+    if (!c || !b || slot < 0 || slot >= RC_MAX_SLOTS) return RC_ERR_ARG;
+    rc_ctx_full *ctx = static_cast<rc_ctx_full *>(c);
+    if (b->mode < 0 || b->mode > 2 || (b->n && (!b->seq || !b->qual || !b->off || !b->ret || !b->l || !b->m || !b->h)) ||
+        (b->n && b->mode == 1 && (!b->seq2 || !b->qual2 || !b->off2))) {
+        rc_set_error(ctx, "submit: bad batch descriptor");
+        return RC_ERR_ARG;
+    }
+    RC_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = slots_init(ctx);
+    if (rc) return rc;
+    rc_slot &sl = ctx->slots[slot];
+    if (sl.busy) {
+        rc_set_error(ctx, "submit: slot %d still holds a batch (rc_wait it first)", slot);
+        return RC_ERR_STATE;
+    }
+    sl.b = *b;
+    const size_t n1 = b->n;
+    sl.total_reads = b->mode == 1 ? 2 * n1 : n1;
+    sl.bytes1 = n1 ? b->off[n1] : 0;
+    sl.bytes2 = (n1 && b->mode == 1) ? b->off2[n1] : 0;
+    if (n1 == 0) {
+        sl.busy = true;
+        return RC_OK;
+    }
+    const size_t nbytes = sl.bytes1 + sl.bytes2, total = sl.total_reads;
+    if (nbytes >= (1ull << 32) || total >= (1ull << 32)) {
+        rc_set_error(ctx, "submit: batch too large (split it)");
+        return RC_ERR_ARG;
+    }
+    // offsets of the device arena (arena 1 then arena 2) and the longest read, into pinned memory
+    if ((rc = hbuf_reserve(ctx, &sl.p_off, (total + 1) * 4))) return rc;
+    uint32_t *off = (uint32_t *)sl.p_off.p;
+    int max_len = 0;
+    memcpy(off, b->off, (n1 + 1) * 4);
+    for (size_t i = 0; i < n1; ++i) max_len = std::max(max_len, (int)(b->off[i + 1] - b->off[i]) - 1);
+    if (b->mode == 1) {
+        for (size_t i = 0; i <= n1; ++i) off[n1 + i] = (uint32_t)sl.bytes1 + b->off2[i];
+        for (size_t i = 0; i < n1; ++i) max_len = std::max(max_len, (int)(b->off2[i + 1] - b->off2[i]) - 1);
+    }
+    if ((rc = rc_dbuf_reserve(ctx, &sl.d_seq, nbytes + 64))) return rc;
+    if ((rc = rc_dbuf_reserve(ctx, &sl.d_qual, nbytes + 64))) return rc;
+    if ((rc = rc_dbuf_reserve(ctx, &sl.d_off, (total + 1) * 4))) return rc;
+    if ((rc = rc_dbuf_reserve(ctx, &sl.d_res, total * 16))) return rc;
+    sl.seq_pinned = is_pinned(b->seq) && is_pinned(b->qual) && (b->mode != 1 || (is_pinned(b->seq2) && is_pinned(b->qual2)));
+    sl.res_pinned = is_pinned(b->ret) && is_pinned(b->l) && is_pinned(b->m) && is_pinned(b->h);
+    const char *h_seq1 = b->seq, *h_qual1 = b->qual, *h_seq2 = b->seq2, *h_qual2 = b->qual2;
+    if (!sl.seq_pinned) {  // pageable buffers: through the slot's pinned staging
+        if ((rc = hbuf_reserve(ctx, &sl.p_seq, nbytes))) return rc;
+        if ((rc = hbuf_reserve(ctx, &sl.p_qual, nbytes))) return rc;
+        memcpy(sl.p_seq.p, b->seq, sl.bytes1);
+        memcpy(sl.p_qual.p, b->qual, sl.bytes1);
+        if (b->mode == 1) {
+            memcpy((char *)sl.p_seq.p + sl.bytes1, b->seq2, sl.bytes2);
+            memcpy((char *)sl.p_qual.p + sl.bytes1, b->qual2, sl.bytes2);
+        }
+        h_seq1 = (const char *)sl.p_seq.p;
+        h_qual1 = (const char *)sl.p_qual.p;
+        h_seq2 = h_seq1 + sl.bytes1;
+        h_qual2 = h_qual1 + sl.bytes1;
+    }
+    if (!sl.res_pinned && (rc = hbuf_reserve(ctx, &sl.p_res, total * 16))) return rc;
+    uint8_t *d_seq = (uint8_t *)sl.d_seq.p, *d_qual = (uint8_t *)sl.d_qual.p;
+    // one upload stream: bases and qualities on two streams measured 21 GB/s against 26.6 GB/s on one
+    // (the link, not a DMA engine, is the bound)
+    hipStream_t sq = ctx->s_h2d;
+    RC_CHECK_HIP(ctx, hipMemcpyAsync(d_seq, h_seq1, sl.bytes1, hipMemcpyHostToDevice, ctx->s_h2d));
+    RC_CHECK_HIP(ctx, hipMemcpyAsync(d_qual, h_qual1, sl.bytes1, hipMemcpyHostToDevice, sq));
+    if (b->mode == 1) {
+        RC_CHECK_HIP(ctx, hipMemcpyAsync(d_seq + sl.bytes1, h_seq2, sl.bytes2, hipMemcpyHostToDevice, ctx->s_h2d));
+        RC_CHECK_HIP(ctx, hipMemcpyAsync(d_qual + sl.bytes1, h_qual2, sl.bytes2, hipMemcpyHostToDevice, sq));
+    }
+    RC_CHECK_HIP(ctx, hipMemcpyAsync(sl.d_off.p, off, (total + 1) * 4, hipMemcpyHostToDevice, ctx->s_h2d));
+    RC_CHECK_HIP(ctx, hipEventRecord(sl.e_h2d, ctx->s_h2d));
+    // kernels
+    RC_CHECK_HIP(ctx, hipStreamWaitEvent(ctx->stream, sl.e_h2d, 0));
+    int32_t *d_res = (int32_t *)sl.d_res.p;
+    rc_device_batch db;
+    db.mode = b->mode;
+    db.n_reads = (uint32_t)total;
+    db.nbytes = nbytes;
+    db.max_read_len = max_len;
+    db.d_seq = d_seq;
+    db.d_qual = d_qual;
+    db.d_off = (const uint32_t *)sl.d_off.p;
+    db.d_ret = d_res;
+    db.d_l = d_res + total;
+    db.d_m = d_res + 2 * total;
+    db.d_h = d_res + 3 * total;
+    if ((rc = rc_correct_device(ctx, &db))) return rc;
+    RC_CHECK_HIP(ctx, hipEventRecord(sl.e_k, ctx->stream));
+    // results
+    RC_CHECK_HIP(ctx, hipStreamWaitEvent(ctx->s_d2h, sl.e_k, 0));
+    char *o_seq1 = sl.seq_pinned ? b->seq : (char *)sl.p_seq.p;
+    RC_CHECK_HIP(ctx, hipMemcpyAsync(o_seq1, d_seq, sl.bytes1, hipMemcpyDeviceToHost, ctx->s_d2h));
+    if (b->mode == 1) {
+        char *o_seq2 = sl.seq_pinned ? b->seq2 : (char *)sl.p_seq.p + sl.bytes1;
+        RC_CHECK_HIP(ctx, hipMemcpyAsync(o_seq2, d_seq + sl.bytes1, sl.bytes2, hipMemcpyDeviceToHost, ctx->s_d2h));
+    }
+    if (sl.res_pinned) {
+        RC_CHECK_HIP(ctx, hipMemcpyAsync(b->ret, db.d_ret, total * 4, hipMemcpyDeviceToHost, ctx->s_d2h));
+        RC_CHECK_HIP(ctx, hipMemcpyAsync(b->l, db.d_l, total * 4, hipMemcpyDeviceToHost, ctx->s_d2h));
+        RC_CHECK_HIP(ctx, hipMemcpyAsync(b->m, db.d_m, total * 4, hipMemcpyDeviceToHost, ctx->s_d2h));
+        RC_CHECK_HIP(ctx, hipMemcpyAsync(b->h, db.d_h, total * 4, hipMemcpyDeviceToHost, ctx->s_d2h));
+    } else {
+        RC_CHECK_HIP(ctx, hipMemcpyAsync(sl.p_res.p, d_res, total * 16, hipMemcpyDeviceToHost, ctx->s_d2h));
+    }
+    RC_CHECK_HIP(ctx, hipEventRecord(sl.e_done, ctx->s_d2h));
+    sl.busy = true;
+    return RC_OK;
+}
+
+int rc_wait(rc_ctx *c, int slot)
+{
+    if (!c || slot < 0 || slot >= RC_MAX_SLOTS) return RC_ERR_ARG;
+    rc_ctx_full *ctx = static_cast<rc_ctx_full *>(c);
+    if (!ctx->slots || !ctx->slots[slot].busy) {
+        rc_set_error(ctx, "wait: slot %d holds no batch", slot);
+        return RC_ERR_STATE;
+    }
+    rc_slot &sl = ctx->slots[slot];
+    sl.busy = false;
+    if (sl.b.n == 0) return RC_OK;
+    RC_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    RC_CHECK_HIP(ctx, hipEventSynchronize(sl.e_done));
+    const size_t total = sl.total_reads;
+    if (!sl.seq_pinned) {
+        memcpy(sl.b.seq, sl.p_seq.p, sl.bytes1);
+        if (sl.b.mode == 1) memcpy(sl.b.seq2, (char *)sl.p_seq.p + sl.bytes1, sl.bytes2);
+    }
+    if (!sl.res_pinned) {
+        const int32_t *r = (const int32_t *)sl.p_res.p;
+        memcpy(sl.b.ret, r, total * 4);
+        memcpy(sl.b.l, r + total, total * 4);
+        memcpy(sl.b.m, r + 2 * total, total * 4);
+        memcpy(sl.b.h, r + 3 * total, total * 4);
     }
     return RC_OK;
 }
@@ -914,6 +1173,7 @@ int rc_profile_enable(rc_ctx *ctx, int on)
 {
     if (!ctx) return RC_ERR_ARG;
     ctx->profile = on != 0;
+    if (!ctx->phase_prof_print) ctx->phase_prof = on == 2;
     return RC_OK;
 }
 
@@ -929,6 +1189,16 @@ int rc_profile_reset(rc_ctx *ctx)
 {
     if (!ctx) return RC_ERR_ARG;
     for (auto &t : ctx->timers) t = rc_kernel_timer();
+    ctx->k3_listed = ctx->k3_rounds = ctx->k3_requests = 0;
+    return RC_OK;
+}
+
+int rc_profile_correct_counters(rc_ctx *ctx, uint64_t *reads_listed, uint64_t *gather_rounds, uint64_t *bucket_requests)
+{
+    if (!ctx) return RC_ERR_ARG;
+    if (reads_listed) *reads_listed = ctx->k3_listed;
+    if (gather_rounds) *gather_rounds = ctx->k3_rounds;
+    if (bucket_requests) *bucket_requests = ctx->k3_requests;
     return RC_OK;
 }
 
@@ -953,9 +1223,13 @@ int rc_selftest_get_bound(rc_ctx *ctx, const int32_t *c, size_t n, double error_
 int rc_summary(const rc_ctx *c, uint64_t *total_reads, uint64_t *total_corrections)
 {
     if (!c) return RC_ERR_ARG;
-    const rc_ctx_full *ctx = static_cast<const rc_ctx_full *>(c);
-    if (total_reads) *total_reads = ctx->total_reads;
-    if (total_corrections) *total_corrections = ctx->total_corrections;
+    rc_ctx *ctx = const_cast<rc_ctx *>(c);  // (reads device memory; the counters themselves do not change)
+    unsigned long long v[2] = {0, 0};
+    RC_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    RC_CHECK_HIP(ctx, hipMemcpy(v, (char *)ctx->work.p + RC_WORK_SUMMARY_OFF, sizeof v, hipMemcpyDeviceToHost));
+    if (total_reads) *total_reads = v[0];
+    if (total_corrections) *total_corrections = v[1];
     return RC_OK;
 }
 

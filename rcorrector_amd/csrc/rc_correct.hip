@@ -151,12 +151,13 @@ struct DevWaveT {
     __device__ __forceinline__ uint32_t wave_min_u32(uint32_t x) { return wave_minmax_u32<false>(x); }
     __device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) { return wave_minmax_u32<true>(x); }
 
+    uint32_t n_req = 0;  // PROF builds: bucket reads issued by this lane
     __device__ __forceinline__ int get(rc_kmer km)
     {
-        return km.inv == -1 ? rc_table_lookup(T, rc_canonical(km.code, k)) : 0;
+        return km.inv == -1 ? rc_table_lookup(T, rc_canonical(km.code, k), PROF ? &n_req : nullptr) : 0;
     }
 
-    __device__ __forceinline__ int lookup(uint64_t code) { return rc_table_lookup(T, rc_canonical(code, k)); }
+    __device__ __forceinline__ int lookup(uint64_t code) { return rc_table_lookup(T, rc_canonical(code, k), PROF ? &n_req : nullptr); }
 
     // in-register bitonic network over E*64 elements (element g = e*64 + lane lives in x[e]):
     // strides below 64 exchange through the lane crossbar, strides >= 64 between a lane's own
@@ -654,6 +655,10 @@ __global__ __launch_bounds__(64, rc_k3_waves(CAP)) void k_correct(rc_kernel_args
         atomicMax(A.phase_cycles + 12, (unsigned long long)w.rounds_max);
 #endif
     }
+    if (PROF) {
+        const int req = w.reduce_add((int)w.n_req);
+        if (w.lane == 0) atomicAdd(A.phase_cycles + 13, (unsigned long long)(uint32_t)req);
+    }
 }
 
 static int rc_cap_for(int max_len)
@@ -796,7 +801,7 @@ int rc_launch_correct(rc_ctx *ctx, const rc_device_batch_args &a)
         hipLaunchKernelGGL((k_correct<1024, false, false>), dim3(grid), dim3(64), 0, ctx->stream, A);
     rc_timer_end(ctx, RC_T_CORRECT);
     if (ctx->phase_prof && A.cap_class == 192) {
-        unsigned long long pc[13];
+        unsigned long long pc[14];
         uint32_t nwork = a.n;
         RC_CHECK_HIP(ctx, hipMemcpyAsync(pc, A.phase_cycles, sizeof pc, hipMemcpyDeviceToHost, ctx->stream));
         if (A.n_work) RC_CHECK_HIP(ctx, hipMemcpyAsync(&nwork, A.n_work, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -804,12 +809,42 @@ int rc_launch_correct(rc_ctx *ctx, const rc_device_batch_args &a)
         static const char *names[8] = {"dequeue+load", "polya", "islands/segments", "search", "lower-thresholds", "post-filters", "apply+kmerinfo", "store"};
         unsigned long long tot = 0;
         for (int i = 0; i < 8; ++i) tot += pc[i];
+        ctx->k3_listed += nwork;
+        ctx->k3_rounds += pc[11];
+        ctx->k3_requests += pc[13];
+        if (ctx->phase_prof_print) {
         fprintf(stderr, "[rc phase prof] k_correct, %u reads, cycles/read:", a.n);
         for (int i = 0; i < 8; ++i) fprintf(stderr, " %s=%.0f(%.0f%%)", names[i], (double)pc[i] / a.n, 100.0 * pc[i] / (tot ? tot : 1));
         // wall_clock64 ticks at 100 MHz: when the queue ran dry and when the last wave ended
         fprintf(stderr, "\n[rc phase prof] work list %u of %u reads; queue empty at %.2f ms, last wave done at %.2f ms; gather rounds: %.2f per listed read, worst read %llu\n",
                 nwork, a.n, (double)(pc[9] - pc[8]) / 1e5, (double)(pc[10] - pc[8]) / 1e5, (double)pc[11] / (nwork ? nwork : 1), pc[12]);
+        fprintf(stderr, "[rc phase prof] bucket reads: %.1f per listed read\n", (double)pc[13] / (nwork ? nwork : 1));
+        }
     }
+    RC_CHECK_HIP(ctx, hipGetLastError());
+    return RC_OK;
+}
+
+// UpdateSummary (main.cpp:73-79) over a batch's return values: reads += n, bases += sum of ret > 0
+__global__ __launch_bounds__(256) void k_summary(const int32_t *__restrict__ ret, uint32_t n, unsigned long long *__restrict__ out)
+{
+    unsigned long long acc = 0;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const int r = ret[i];
+        if (r > 0) acc += (unsigned long long)r;
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out + 1, acc);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(out, (unsigned long long)n);
+}
+
+int rc_launch_summary(rc_ctx *ctx, const int32_t *d_ret, uint32_t n)
+{
+    if (n == 0) return RC_OK;
+    unsigned grid = (n + 255u) / 256u;
+    if (grid > 2048u) grid = 2048u;
+    hipLaunchKernelGGL(k_summary, dim3(grid), dim3(256), 0, ctx->stream, d_ret, n,
+                       (unsigned long long *)((char *)ctx->work.p + RC_WORK_SUMMARY_OFF));
     RC_CHECK_HIP(ctx, hipGetLastError());
     return RC_OK;
 }

@@ -5,13 +5,15 @@
 // Store::GetCount on a canonical code (Store.h:59-66): one 64-byte bucket = four 16-byte loads
 // of the same sector; the five {key,count} slots and the meta dword are picked out of registers.
 // Of two equal keys the first in probe order wins (the build places the later Put first).
-__device__ __forceinline__ int rc_table_lookup(const rc_table_view &T, uint64_t canon)
+// n_req (optional): incremented once per bucket read (profiling builds of k_correct)
+__device__ __forceinline__ int rc_table_lookup(const rc_table_view &T, uint64_t canon, uint32_t *n_req = nullptr)
 {
     uint32_t b = rc_home(canon, T.nb_home);
     const uint32_t klo = (uint32_t)canon, khi = (uint32_t)(canon >> 32);
     for (;;) {
         const uint4 *p = reinterpret_cast<const uint4 *>(T.buckets + (size_t)b * RC_BUCKET_DWORDS);
         uint32_t d[RC_BUCKET_DWORDS];
+        if (n_req) ++*n_req;
 #pragma unroll
         for (int q = 0; q < RC_BUCKET_DWORDS / 4; ++q) {
             const uint4 v = p[q];

@@ -47,6 +47,8 @@ struct rc_dbuf {
     size_t bytes = 0;
 };
 
+#define RC_MAX_SLOTS 4
+
 struct rc_kernel_timer {
     double ms = 0;       // accumulated
     uint64_t launches = 0;
@@ -61,7 +63,9 @@ struct rc_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool profile = false;
-    bool phase_prof = false;  // RC_PHASE_PROF=1: per-phase cycle accounting in k_correct (dev aid)
+    bool phase_prof = false;  // the instrumented build of k_correct runs (RC_PHASE_PROF=1 or rc_profile_enable(ctx, 2))
+    bool phase_prof_print = false;  // ... and prints its per-phase cycle accounting (RC_PHASE_PROF=1, dev aid)
+    uint64_t k3_listed = 0, k3_rounds = 0, k3_requests = 0;  // accumulated by the instrumented build
     rc_kernel_timer timers[RC_T_COUNT];
 
     rc_run_params P;
@@ -100,7 +104,11 @@ struct rc_ctx {
     int env_k3_grid_waves = 0;  // dev: persistent k_correct waves per SIMD actually launched (0 = as compiled)
     rc_dbuf stack;    // search stack frames
     rc_dbuf work;     // work counters
-    rc_dbuf h_seq, h_qual, h_off, h_res;  // device staging for the host-buffer entry point
+    rc_dbuf h_seq, h_qual, h_off, h_res;  // device staging for the host-buffer entry point (traced path)
+
+    // asynchronous host-buffer path (rc_submit / rc_wait): copy streams and per-slot staging
+    hipStream_t s_h2d = nullptr, s_d2h = nullptr;
+    struct rc_slot *slots = nullptr;  // RC_MAX_SLOTS of them, created on first use
 
     char err[512];
 };
@@ -125,6 +133,7 @@ int rc_launch_selftest_bound(rc_ctx *ctx, const int32_t *d_c, size_t n, double e
 int rc_launch_export(rc_ctx *ctx, uint64_t *d_codes, int32_t *d_counts, unsigned long long *d_n, size_t cap);
 int rc_table_entries_in_dump_order(rc_ctx *ctx, std::vector<uint64_t> *codes, std::vector<int32_t> *counts);
 int rc_launch_last_base_variants(rc_ctx *ctx, const uint64_t *d_codes, size_t n, int32_t *d_max2);
+int rc_launch_digest(rc_ctx *ctx, unsigned long long *d_out);
 int rc_launch_compact(rc_ctx *ctx, const uint8_t *d_flags, uint32_t n, uint32_t *d_list, uint32_t *d_count);
 
 // rc_correct.hip
@@ -139,9 +148,11 @@ struct rc_device_batch_args {
 };
 int rc_launch_threshold(rc_ctx *ctx, const rc_device_batch_args &a, bool classify);
 int rc_launch_correct(rc_ctx *ctx, const rc_device_batch_args &a);
+int rc_launch_summary(rc_ctx *ctx, const int32_t *d_ret, uint32_t n);
 
 // layout of rc_ctx::work (bytes): the RC_HEADS queue heads of k_correct, 128 B apart, then the
 // length of the work list, then the phase counters of PROF builds
 #define RC_WORK_BYTES 2048
 #define RC_WORK_NWORK_OFF 1024
 #define RC_WORK_PHASE_OFF 1152
+#define RC_WORK_SUMMARY_OFF 1536  // 2 x uint64: reads, corrected bases (never reset)

@@ -224,6 +224,46 @@ __global__ void k_export(const uint32_t *__restrict__ buckets, size_t nslots, ui
     }
 }
 
+// order-independent 64-bit digest of the table's CONTENT (what Store::GetCount can return): the sum
+// over live entries of mix(code, count) -- two tables with the same digest answer every probe alike
+// whatever their bucket layout (load factor, build order)
+__global__ void k_digest(const uint32_t *__restrict__ buckets, size_t nslots, uint32_t nb_home, unsigned long long *__restrict__ out)
+{
+    size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long v = 0;
+    if (s < nslots) {
+        const uint32_t *w = buckets + (s / RC_BUCKET_SLOTS) * RC_BUCKET_DWORDS + (s % RC_BUCKET_SLOTS) * 3;
+        if (w[2] != 0) {
+            const uint64_t key = ((uint64_t)w[1] << 32) | w[0];
+            size_t b = rc_home(key, nb_home);
+            bool live = false;
+            for (;;) {  // first slot of the probe sequence that holds the key (k_export's rule)
+                const uint32_t *q = buckets + b * RC_BUCKET_DWORDS;
+                bool found = false;
+                for (int i = 0; i < RC_BUCKET_SLOTS; ++i)
+                    if (q[3 * i + 2] != 0 && q[3 * i] == w[0] && q[3 * i + 1] == w[1]) {
+                        live = b * RC_BUCKET_SLOTS + (size_t)i == s;
+                        found = true;
+                        break;
+                    }
+                if (found) break;
+                ++b;
+            }
+            if (live) v = rc_dump_order_key(key ^ rc_dump_order_key((uint64_t)w[2] + 0x9E3779B97F4A7C15ull));
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(out, v);
+}
+
+int rc_launch_digest(rc_ctx *ctx, unsigned long long *d_out)
+{
+    const size_t nslots = (size_t)ctx->nb_alloc * RC_BUCKET_SLOTS;
+    hipLaunchKernelGGL(k_digest, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_buckets, nslots, ctx->nb_home, d_out);
+    RC_CHECK_HIP(ctx, hipGetLastError());
+    return RC_OK;
+}
+
 int rc_launch_export(rc_ctx *ctx, uint64_t *d_codes, int32_t *d_counts, unsigned long long *d_n, size_t cap)
 {
     const size_t nslots = (size_t)ctx->nb_alloc * RC_BUCKET_SLOTS;

@@ -339,6 +339,8 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     assert d["config"]["reads_per_gpu"] == 400000 and "x2" in d["config"]["parallelism"]
     assert abs(d["value"] - 2 * 400000 * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 1e-6
     assert 0.2 < d["config"]["reads_corrected_frac"] < 0.9
+    # every rank rebuilt the same replicated table (deterministic generator) and the digests were compared
+    assert d["config"]["table_replicas_identical"] is True and len(d["config"]["table_digest"]) == 16
 
 
 @pytest.mark.gpu
@@ -361,3 +363,58 @@ def test_jfdump_loader_on_quirky_dumps(gpu_ctx_factory, oracle, seed, tmp_path):
     got_c, got_n = ctx.table_export()
     o1, o2 = np.argsort(got_c), np.argsort(codes)
     assert np.array_equal(got_c[o1], codes[o2]) and np.array_equal(got_n[o1], counts[o2])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pinned", [False, True])
+def test_submit_wait_slots_in_flight_equal_synchronous(gpu_ctx_factory, oracle, pinned):
+    """rc_submit / rc_wait: several batches in flight in one context (pageable buffers staged through
+    the slots' pinned memory, or page-locked buffers used directly) give what the oracle gives for
+    each batch, in any completion order of the waits, and the device-side summary adds them up."""
+    d = datasets.make("pe_k23")
+    want = datasets.run_oracle(oracle, d)
+    ctx = _table(gpu_ctx_factory, d)
+    n = len(d["seqs1"])
+    cuts = [0, n // 5, n // 2, n // 2, n]   # four batches, one of them empty
+    of1, of2 = oracle.pack_reads(d["seqs1"])[1], oracle.pack_reads(d["seqs2"])[1]
+    subs = []
+    for s in range(4):
+        lo, hi = cuts[s], cuts[s + 1]
+        a1, o1 = oracle.pack_reads(d["seqs1"][lo:hi]); q1, _ = oracle.pack_reads(d["quals1"][lo:hi])
+        a2, o2 = oracle.pack_reads(d["seqs2"][lo:hi]); q2, _ = oracle.pack_reads(d["quals2"][lo:hi])
+        res = None
+        if pinned:
+            def pin(x):
+                y = ctx.host_array(len(x), x.dtype)
+                y[:] = x
+                return y
+            a1, q1, a2, q2 = pin(a1), pin(q1), pin(a2), pin(q2)
+            res = [ctx.host_array(2 * (hi - lo), np.int32) for _ in range(4)]
+        ctx.submit(s, 1, a1, q1, o1, a2, q2, o2, res=res)
+        subs.append((lo, hi, a1, a2))
+    with pytest.raises(Exception):
+        ctx.submit(0, 1, subs[0][2], subs[0][2], np.zeros(1, np.uint32), subs[0][3], subs[0][3], np.zeros(1, np.uint32))  # slot busy
+    for s in (2, 0, 3, 1):
+        lo, hi, a1, a2 = subs[s]
+        ret, l, m, h = ctx.wait(s)
+        m_ = hi - lo
+        for got, w in ((ret, want[0]), (l, want[1]), (m, want[2]), (h, want[3])):
+            assert np.array_equal(got[:m_], w[lo:hi]) and np.array_equal(got[m_:], w[n + lo:n + hi]), "slot %d" % s
+        assert np.array_equal(np.asarray(a1), want[4][of1[lo]:of1[hi]]) and np.array_equal(np.asarray(a2), want[5][of2[lo]:of2[hi]])
+    reads, cors = ctx.summary()
+    assert reads == 2 * n and cors == int(want[0][want[0] > 0].sum())
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_correct_batch_refuses_wrong_dtype(gpu_ctx_factory, oracle):
+    d = datasets.make("se_k23")
+    ctx = _table(gpu_ctx_factory, d)
+    a, off = oracle.pack_reads(d["seqs1"])
+    qa, _ = oracle.pack_reads(d["quals1"])
+    with pytest.raises(TypeError):
+        ctx.correct_batch(0, a.astype(np.int32), qa, off)
+    with pytest.raises(TypeError):
+        ctx.correct_batch(0, a[::2], qa, off)
+    ret = ctx.correct_batch(0, a, qa, off.astype(np.int64))[0]   # offsets are converted
+    assert (ret > 0).sum() > 0

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--cli-args", default="")
     ap.add_argument("--paired", action="store_true", help="paired-end: --reads counts both mates, files x_1.fq / x_2.fq")
     ap.add_argument("--count", action="store_true", help="also run every variant without -c (k-mers counted by the CLI)")
+    ap.add_argument("--json", action="store_true", help="print one JSON line for the first variant (bench.py --e2e)")
     a = ap.parse_args()
     os.makedirs(a.dir, exist_ok=True)
     dev = torch.device("cuda", 0)
@@ -82,6 +83,8 @@ def main():
     cli = os.path.join(ROOT, "rcorrector_amd", "rcorrector")
     env = dict(os.environ, RC_TIMING="1")
     import hashlib
+    import json
+    first = None
     for variant in a.cli_args.split(";"):
         for dump in ([["-c", "x.jf"], []] if a.count else [["-c", "x.jf"]]):
             import shutil
@@ -94,7 +97,16 @@ def main():
             sys.stderr.write(p.stderr.decode())
             md5 = hashlib.md5(open(a.dir + "/out/" + first_out, "rb").read()).hexdigest()
             print("CLI [%s %s] wall %.2f s -> %.2f M reads/s end to end, output md5 %s" % (
-                " ".join(dump) or "(counting)", variant, dt, n / dt / 1e6, md5))
+                " ".join(dump) or "(counting)", variant, dt, n / dt / 1e6, md5), file=sys.stderr if a.json else sys.stdout)
+            if first is None:
+                timing = [ln for ln in p.stderr.decode().splitlines() if ln.startswith("[rc timing]")]
+                first = {"metric": "end-to-end corrected reads/sec (FASTQ files -> .cor.fq, %d bp %s, k=%d, rcorrector binary, 1 GPU)"
+                         % (L, "paired-end" if a.paired else "single-end", k),
+                         "value": n / dt, "unit": "reads/s", "reads": n, "wall_s": dt, "table_kmers": nk,
+                         "includes": "process start, HIP init, dump parse + table build, ERROR_RATE, bad-quality scan, read -> correct -> write",
+                         "rc_timing": timing, "output_md5": md5}
+    if a.json:
+        print(json.dumps(first))
 
 
 if __name__ == "__main__":
