@@ -79,6 +79,11 @@ int rc_table_write_jfdump(rc_ctx *ctx, const char *path, int64_t *n_written);
  * The reference shares one Store between all worker threads (main.cpp:451); this lets several
  * contexts -- several batches in flight on one GPU -- do the same instead of replicating it. */
 int rc_table_share(rc_ctx *dst, const rc_ctx *src);
+/* dst gets its own copy of src's table: the bucket array goes device to device (over xGMI when the
+ * contexts sit on different GPUs) -- the replication step of a multi-GPU run; the dump is parsed and the
+ * table built once (main.cpp:294-308 loads one Store for all workers).  rc_estimate_error_rate() keeps
+ * working on src only (dst has no dump order of its own until asked: it falls back to the table's). */
+int rc_table_replicate(rc_ctx *dst, const rc_ctx *src);
 /* Store::GetCount (Store.h:59-66) for n valid k-mer codes (host arrays) */
 int rc_table_lookup(rc_ctx *ctx, const uint64_t *codes, size_t n, int32_t *counts_out);
 /* every stored (canonical code, count) pair, unspecified order -- what `jellyfish dump` would

@@ -13,7 +13,7 @@ ABI_SYMBOLS = [
     "rc_create", "rc_destroy", "rc_last_error",
     "rc_table_build", "rc_table_build_device", "rc_table_load_jfdump",
     "rc_table_count_begin", "rc_table_count_add", "rc_table_count_add_device", "rc_table_count_finish",
-    "rc_table_count_reads_device", "rc_table_write_jfdump", "rc_table_share", "rc_table_lookup", "rc_table_export", "rc_table_digest", "rc_table_stats",
+    "rc_table_count_reads_device", "rc_table_write_jfdump", "rc_table_share", "rc_table_replicate", "rc_table_lookup", "rc_table_export", "rc_table_digest", "rc_table_stats",
     "rc_estimate_error_rate", "rc_bad_quality_from_hist", "rc_set_run_params",
     "rc_correct_batch", "rc_submit", "rc_wait", "rc_host_alloc", "rc_host_free", "rc_correct_batch_traced", "rc_correct_device", "rc_strong_threshold_device", "rc_probe_device", "rc_sync",
     "rc_profile_enable", "rc_profile_get", "rc_profile_reset", "rc_profile_correct_counters", "rc_selftest_get_bound", "rc_summary",
@@ -94,6 +94,7 @@ def load_library():
     L.rc_table_count_finish.argtypes = [vp, C.c_int, C.POINTER(C.c_int64)]
     L.rc_table_write_jfdump.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64)]
     L.rc_table_share.argtypes = [vp, vp]
+    L.rc_table_replicate.argtypes = [vp, vp]
     L.rc_table_lookup.argtypes = [vp, vp, sz, vp]
     L.rc_table_export.argtypes = [vp, vp, vp, sz, C.POINTER(C.c_size_t)]
     L.rc_table_digest.argtypes = [vp, C.POINTER(C.c_uint64)]
@@ -231,6 +232,10 @@ class Context:
         """Use `other`'s table (same device) instead of an own copy; keeps `other` alive."""
         self._ck(self._L.rc_table_share(self._h, other._h))
         self._table_owner = other
+
+    def replicate_table_of(self, other):
+        """An own copy of `other`'s table, device to device (rc_table_replicate)."""
+        self._ck(self._L.rc_table_replicate(self._h, other._h))
 
     def lookup(self, codes):
         codes = np.ascontiguousarray(codes, dtype=np.uint64)

@@ -485,6 +485,34 @@ int rc_table_share(rc_ctx *dst, const rc_ctx *src)
     return RC_OK;
 }
 
+int rc_table_replicate(rc_ctx *dst, const rc_ctx *src)
+{
+    if (!dst || !src || dst == src) return RC_ERR_ARG;
+    if (dst->k != src->k) {
+        rc_set_error(dst, "table_replicate: contexts must have the same k");
+        return RC_ERR_ARG;
+    }
+    if (!src->d_buckets) {
+        rc_set_error(dst, "table_replicate: the source context has no table");
+        return RC_ERR_STATE;
+    }
+    RC_CHECK_HIP(dst, hipSetDevice(src->device));
+    RC_CHECK_HIP(dst, hipStreamSynchronize(src->stream));
+    RC_CHECK_HIP(dst, hipSetDevice(dst->device));
+    if (dst->d_buckets && !dst->buckets_borrowed) (void)hipFree(dst->d_buckets);
+    dst->d_buckets = nullptr;
+    dst->buckets_borrowed = false;
+    static_cast<rc_ctx_full *>(dst)->dump.valid = false;
+    RC_CHECK_HIP(dst, hipMalloc((void **)&dst->d_buckets, src->table_bytes));
+    // the bucket array is the table: one copy over the direct xGMI link between the two GPUs
+    RC_CHECK_HIP(dst, hipMemcpyPeer(dst->d_buckets, dst->device, src->d_buckets, src->device, src->table_bytes));
+    dst->nb_home = src->nb_home;
+    dst->nb_alloc = src->nb_alloc;
+    dst->n_entries = src->n_entries;
+    dst->table_bytes = src->table_bytes;
+    return RC_OK;
+}
+
 int rc_table_count_reads_device(rc_ctx *ctx, const uint8_t *d_seq, size_t nbytes, int min_count, int64_t *n_kmers)
 {
     if (!ctx || !d_seq) return RC_ERR_ARG;

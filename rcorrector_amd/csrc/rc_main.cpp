@@ -789,6 +789,9 @@ int main(int argc, char **argv)
     }
     g_verbose = verbose;
     if (g_trace_iter < 1) g_trace_iter = 1;
+    // -verbose carries RC_TRACE_ITER_WORDS x trace-iter words per read through host and device
+    // (9 KB per read at the default 64 iterations): small batches, or a real data set needs tens of GB
+    if (verbose && batch_reads > (1u << 16)) batch_reads = 1u << 16;
     if (gpus < 1) gpus = 1;
     if (inflight < 1) inflight = 1;
     if (inflight > 8) inflight = 8;
@@ -821,6 +824,8 @@ int main(int argc, char **argv)
         } else if (!strcmp("-p", argv[i])) {
             open_file(files.back(), argv[i + 1], true, false, od);
             open_file(mates.back(), argv[i + 2], true, false, od);
+            if (files.back().fastq != mates.back().fastq)
+                die("rcorrector: %s and %s are a FASTQ and a FASTA file: the mates of a pair must have the same format\n", argv[i + 1], argv[i + 2]);
             i += 2;
         } else {
             open_file(files.back(), argv[i + 1], false, true, od);
@@ -832,16 +837,18 @@ int main(int argc, char **argv)
     const int nctx = gpus * inflight;
     std::vector<rc_ctx *> ctx((size_t)nctx, nullptr);
     char err[512];
+    // RC_SHARED_GPU=1 (tests): every "GPU" is device 0, so that the -gpus N path -- one table replica
+    // per GPU, batches dealt to whichever context is free -- runs on a one-GPU box
+    const bool shared_gpu = getenv("RC_SHARED_GPU") != nullptr;
     for (int c = 0; c < nctx; ++c) {
-        rc_config cfg = {c % gpus, k, max_fix_per_k};
+        rc_config cfg = {shared_gpu ? 0 : c % gpus, k, max_fix_per_k};
         ctx[c] = rc_create(&cfg, err, sizeof err);
         if (!ctx[c]) die("rcorrector: %s\n", err);
     }
     const double t_start = now_s();
     int64_t stored = 0;
-    if (dump) {
-        for (int g = 0; g < gpus; ++g)
-            if (rc_table_load_jfdump(ctx[g], dump, &stored)) die("rcorrector: %s\n", rc_last_error(ctx[g]));
+    if (dump) {  // main.cpp:294-308: ONE Store, loaded once
+        if (rc_table_load_jfdump(ctx[0], dump, &stored)) die("rcorrector: %s\n", rc_last_error(ctx[0]));
     } else {
         // no -c: stages 0-2 of run_rcorrector.pl:262-281 on the GPU -- count the canonical k-mers of
         // every input file (mates included), keep count >= 2, build the table
@@ -852,13 +859,14 @@ int main(int argc, char **argv)
         }
         count_inputs(ctx[0], inputs, &stored);
         if (g_timing) fprintf(stderr, "[rc timing] k-mer counting pass over %zu file(s): %.2f s\n", inputs.size(), now_s() - t_start);
-        if (gpus > 1) {  // replicate: one export, one build per further GPU
-            std::vector<uint64_t> codes((size_t)stored + 1);
-            std::vector<int32_t> counts((size_t)stored + 1);
-            size_t n = 0;
-            if (rc_table_export(ctx[0], codes.data(), counts.data(), codes.size(), &n)) die("rcorrector: %s\n", rc_last_error(ctx[0]));
-            for (int g = 1; g < gpus; ++g)
-                if (rc_table_build(ctx[g], codes.data(), counts.data(), n)) die("rcorrector: %s\n", rc_last_error(ctx[g]));
+    }
+    if (gpus > 1) {  // replicate the bucket array device to device (xGMI) and make sure the replicas agree
+        uint64_t d0 = 0;
+        if (rc_table_digest(ctx[0], &d0)) die("rcorrector: %s\n", rc_last_error(ctx[0]));
+        for (int g = 1; g < gpus; ++g) {
+            uint64_t dg = 0;
+            if (rc_table_replicate(ctx[g], ctx[0]) || rc_table_digest(ctx[g], &dg)) die("rcorrector: %s\n", rc_last_error(ctx[g]));
+            if (dg != d0) die("rcorrector: the k-mer table replica on GPU %d differs from the original\n", g);
         }
     }
     if (write_dump && rc_table_write_jfdump(ctx[0], write_dump, nullptr)) die("rcorrector: %s\n", rc_last_error(ctx[0]));
@@ -961,17 +969,20 @@ int main(int argc, char **argv)
             for (size_t s = 0; s < S; ++s) th.emplace_back([&, s]() { fmt(s, s + 1); });
             for (auto &x : th) x.join();
         }
-        if (f.out_gz && !g_stdout) {  // deflate every slice into its own gzip member, in parallel
+        // compression is a property of each output file (Reads::AddReadFile picks it per input name):
+        // `-p a.fq.gz b.fq` writes a gzip stream for the first mates and plain text for the second
+        const bool gz1 = f.out_gz && !g_stdout, gz2 = j->mode == 1 && mates[(size_t)j->file].out_gz && !g_stdout;
+        if (gz1 || gz2) {  // deflate every slice into its own gzip member, in parallel
             std::vector<std::vector<char>> z1(S), z2(S);
             std::vector<std::thread> th;
             for (size_t s = 0; s < S; ++s)
                 th.emplace_back([&, s]() {
-                    if (!o1[s].empty()) gzip_member(o1[s], z1[s]);
-                    if (!o2[s].empty()) gzip_member(o2[s], z2[s]);
+                    if (gz1 && !o1[s].empty()) gzip_member(o1[s], z1[s]);
+                    if (gz2 && !o2[s].empty()) gzip_member(o2[s], z2[s]);
                 });
             for (auto &x : th) x.join();
-            o1.swap(z1);
-            o2.swap(z2);
+            if (gz1) o1.swap(z1);
+            if (gz2) o2.swap(z2);
         }
     };
 

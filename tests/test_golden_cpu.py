@@ -75,3 +75,13 @@ def test_oracle_verbose_transcript_matches_reference(oracle_cli, name, tmp_path)
     p = gu.run_fixture(oracle_cli, name, tmp_path, extra=["-verbose"])
     assert p.stdout == want
     assert want.count(b"strong trust threshold=") >= want.count(b"Before correction:")
+
+
+def test_fasta_fixture_oracle_equals_reference_batch_path(oracle_cli, oracle, tmp_path):
+    """FASTA input (Reads.h:108-162): pinned to the reference's -t > 1 path (its -t 1 loop crashes on
+    FASTA, see make_golden.py); the oracle must write the same bytes, and so must a fresh reference run."""
+    p = gu.run_fixture(oracle_cli, "fa_se_k23", tmp_path)
+    gu.assert_same_as_reference("fa_se_k23", tmp_path, p.stderr)
+    if os.path.exists(oracle.REF_BIN):
+        p = gu.run_fixture(oracle.REF_BIN, "fa_se_k23", tmp_path / "r")
+        gu.assert_same_as_reference("fa_se_k23", tmp_path / "r", p.stderr)

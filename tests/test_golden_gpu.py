@@ -154,3 +154,75 @@ def test_cli_empty_and_one_base_reads(oracle, tmp_path):
             k = next(i for i in range(min(len(a), len(b))) if a[i] != b[i]) if any(x != y for x, y in zip(a, b)) else min(len(a), len(b))
             raise AssertionError("%s differs at line %d: gpu %r vs cpu %r (context %r)" % (what, k, a[k:k + 2], b[k:k + 2], b[max(0, k - 3):k]))
     assert b"@r3 l:0 m:0 h:0 unfixable_error\n\n+\n\n" in outs[0][0]
+
+
+@pytest.mark.parametrize("name", ["fx_pe_k23", "fx_se_k23", "fx_il_k23", "fx_k31_mc8"])
+@pytest.mark.parametrize("with_dump", [True, False])
+def test_cli_two_gpu_path_equals_one_gpu(name, with_dump, tmp_path):
+    """`-gpus 2`: the dump is parsed (or the k-mers counted) ONCE, the bucket array is replicated device
+    to device, the digests are compared, and batches are dealt to whichever context is free; the output
+    must be what `-gpus 1` writes, byte for byte (the reference: one Store for all workers,
+    main.cpp:294-308,451).  RC_SHARED_GPU=1 puts both "GPUs" on device 0 so that this runs on a one-GPU box."""
+    d = os.path.join(gu.GOLDEN, name)
+    args = open(os.path.join(d, "cmd.txt")).read().split()
+    if not with_dump:
+        i = args.index("-c")
+        args = args[:i] + args[i + 2:]
+    import subprocess
+    outs = []
+    for gpus in (1, 2):
+        od = tmp_path / ("g%d" % gpus)
+        p = subprocess.run([CLI] + args + ["-od", str(od), "-gpus", str(gpus), "-batch", "64", "-inflight", "1"], cwd=d,
+                           env=dict(os.environ, RC_SHARED_GPU="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert p.returncode == 0, p.stderr.decode()
+        outs.append((p.stderr, {f: open(od / f, "rb").read() for f in sorted(os.listdir(od))}))
+    assert outs[0][0] == outs[1][0]
+    assert outs[0][1] == outs[1][1] and outs[0][1]
+    if with_dump:
+        gu.assert_same_as_reference(name, tmp_path / "g2", outs[1][0])
+
+
+def test_cli_mixed_plain_and_gz_pair(tmp_path):
+    """`-p a.fq.gz b.fq`: each output takes its compression from its own input name (Reads::AddReadFile,
+    Reads.h:140-147): a gzip stream for the first mates, plain text for the second -- and the other way round."""
+    src = os.path.join(gu.GOLDEN, "fx_pe_k23")
+    for gz_first in (True, False):
+        work = tmp_path / ("in%d" % gz_first)
+        work.mkdir()
+        names = []
+        for n, z in (("reads_1.fq", gz_first), ("reads_2.fq", not gz_first)):
+            if z:
+                with open(os.path.join(src, n), "rb") as f, gzip.open(work / (n + ".gz"), "wb") as g:
+                    shutil.copyfileobj(f, g)
+                names.append(str(work / (n + ".gz")))
+            else:
+                shutil.copy(os.path.join(src, n), work / n)
+                names.append(str(work / n))
+        out = tmp_path / ("out%d" % gz_first)
+        gu.run_fixture(CLI, "fx_pe_k23", out, args_override=["-p", names[0], names[1], "-k", "23", "-c", os.path.join(src, "dump.jf"), "-batch", "100"])
+        for n, z in (("reads_1", gz_first), ("reads_2", not gz_first)):
+            want = open(os.path.join(src, "ref", n + ".cor.fq"), "rb").read()
+            if z:
+                assert gzip.open(out / (n + ".cor.fq.gz"), "rb").read() == want
+            else:
+                assert open(out / (n + ".cor.fq"), "rb").read() == want
+
+
+def test_cli_refuses_a_fastq_fasta_pair(tmp_path):
+    import subprocess
+    src = os.path.join(gu.GOLDEN, "fx_pe_k23")
+    fa = tmp_path / "m.fa"
+    lines = open(os.path.join(src, "reads_2.fq"), "rb").read().split(b"\n")
+    with open(fa, "wb") as f:
+        for i in range(0, len(lines) - 1, 4):
+            f.write(b">" + lines[i][1:] + b"\n" + lines[i + 1] + b"\n")
+    p = subprocess.run([CLI, "-p", os.path.join(src, "reads_1.fq"), str(fa), "-k", "23", "-c", os.path.join(src, "dump.jf"), "-od", str(tmp_path)],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode != 0 and b"same format" in p.stderr
+
+
+def test_cli_fasta_input(tmp_path):
+    """FASTA in -> .cor.fa out (no quality information: the vetoes see qual[0] == 0, the marker of the
+    reference's batch path, Reads.h:241): the bytes the reference writes at -t 2."""
+    p = gu.run_fixture(CLI, "fa_se_k23", tmp_path, extra=["-batch", "96"])
+    gu.assert_same_as_reference("fa_se_k23", tmp_path, p.stderr)
