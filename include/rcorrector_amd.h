@@ -94,6 +94,11 @@ int rc_table_export(rc_ctx *ctx, uint64_t *codes, int32_t *counts, size_t cap, s
  * multi-GPU callers compare it across devices after replicating the table (main.cpp:294-308 loads ONE
  * Store for all workers). */
 int rc_table_digest(rc_ctx *ctx, uint64_t *digest);
+/* slot layout the last build chose: 0 = WIDE (5 x 12-byte {code, count} slots per 64-byte bucket, any k
+ * and count), 1 = PACKED (8 x 8-byte {remainder, count} slots: the code is implied by the bucket it
+ * hashes to; taken when k, the counts (< 2^27) and the placement allow -- a third less HBM per k-mer).
+ * Same answers either way (rc_table_digest is layout independent).  < 0: no table. */
+int rc_table_layout(const rc_ctx *ctx);
 /* bytes of HBM held by the table, number of buckets, number of stored entries */
 int rc_table_stats(const rc_ctx *ctx, uint64_t *bytes, uint64_t *buckets, uint64_t *entries);
 

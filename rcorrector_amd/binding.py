@@ -13,7 +13,7 @@ ABI_SYMBOLS = [
     "rc_create", "rc_destroy", "rc_last_error",
     "rc_table_build", "rc_table_build_device", "rc_table_load_jfdump",
     "rc_table_count_begin", "rc_table_count_add", "rc_table_count_add_device", "rc_table_count_finish",
-    "rc_table_count_reads_device", "rc_table_write_jfdump", "rc_table_share", "rc_table_replicate", "rc_table_lookup", "rc_table_export", "rc_table_digest", "rc_table_stats",
+    "rc_table_count_reads_device", "rc_table_write_jfdump", "rc_table_share", "rc_table_replicate", "rc_table_lookup", "rc_table_export", "rc_table_digest", "rc_table_layout", "rc_table_stats",
     "rc_estimate_error_rate", "rc_bad_quality_from_hist", "rc_set_run_params",
     "rc_correct_batch", "rc_submit", "rc_wait", "rc_host_alloc", "rc_host_free", "rc_correct_batch_traced", "rc_correct_device", "rc_strong_threshold_device", "rc_probe_device", "rc_sync",
     "rc_profile_enable", "rc_profile_get", "rc_profile_reset", "rc_profile_correct_counters", "rc_selftest_get_bound", "rc_summary",
@@ -98,6 +98,7 @@ def load_library():
     L.rc_table_lookup.argtypes = [vp, vp, sz, vp]
     L.rc_table_export.argtypes = [vp, vp, vp, sz, C.POINTER(C.c_size_t)]
     L.rc_table_digest.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.rc_table_layout.argtypes = [vp]
     L.rc_table_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.rc_estimate_error_rate.argtypes = [vp, C.c_double, C.POINTER(C.c_double)]
     L.rc_bad_quality_from_hist.restype = C.c_char
@@ -257,6 +258,13 @@ class Context:
         v = C.c_uint64(0)
         self._ck(self._L.rc_table_digest(self._h, C.byref(v)))
         return v.value
+
+    def table_layout(self):
+        """0 = WIDE slots, 1 = PACKED slots (rc_table_layout)."""
+        r = self._L.rc_table_layout(self._h)
+        if r < 0:
+            raise RcorrectorError("no table")
+        return r
 
     def table_stats(self):
         b, n, e = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)

@@ -80,6 +80,8 @@ rc_table_view rc_view(const rc_ctx *ctx)
     v.buckets = ctx->d_buckets;
     v.nb_home = ctx->nb_home;
     v.nbuckets_alloc = ctx->nb_alloc;
+    v.layout = ctx->layout;
+    v.k = ctx->k;
     return v;
 }
 
@@ -134,7 +136,8 @@ rc_ctx *rc_create(const rc_config *cfg, char *errbuf, size_t errbuf_len)
     ctx->work.bytes = RC_WORK_BYTES;
     (void)hipMemset(ctx->work.p, 0, RC_WORK_BYTES);
     if (const char *e = getenv("RC_PHASE_PROF")) ctx->phase_prof = ctx->phase_prof_print = atoi(e) != 0;
-    if (const char *e = getenv("RC_TABLE_LOAD")) ctx->table_load = atof(e);  // tuning knob
+    if (const char *e = getenv("RC_TABLE_LOAD")) ctx->table_load = ctx->table_load_packed = atof(e);  // tuning knob
+    if (const char *e = getenv("RC_TABLE_LAYOUT")) ctx->layout_pref = strcmp(e, "wide") != 0;         // dev: A/B the slot layouts
     ctx->env_k2_wave_per_read = getenv("RC_K2_WAVE_PER_READ") != nullptr;  // dev: force the wave-per-read threshold kernel
     ctx->env_no_classify = getenv("RC_NO_CLASSIFY") != nullptr;            // dev: every read goes through k_correct
     ctx->env_timing = getenv("RC_TIMING") != nullptr;
@@ -479,6 +482,7 @@ int rc_table_share(rc_ctx *dst, const rc_ctx *src)
     dst->d_buckets = src->d_buckets;
     dst->buckets_borrowed = true;
     dst->nb_home = src->nb_home;
+    dst->layout = src->layout;
     dst->nb_alloc = src->nb_alloc;
     dst->n_entries = src->n_entries;
     dst->table_bytes = src->table_bytes;
@@ -507,6 +511,7 @@ int rc_table_replicate(rc_ctx *dst, const rc_ctx *src)
     // the bucket array is the table: one copy over the direct xGMI link between the two GPUs
     RC_CHECK_HIP(dst, hipMemcpyPeer(dst->d_buckets, dst->device, src->d_buckets, src->device, src->table_bytes));
     dst->nb_home = src->nb_home;
+    dst->layout = src->layout;
     dst->nb_alloc = src->nb_alloc;
     dst->n_entries = src->n_entries;
     dst->table_bytes = src->table_bytes;
@@ -685,6 +690,13 @@ int rc_table_digest(rc_ctx *ctx, uint64_t *digest)
     RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *digest = v;
     return RC_OK;
+}
+
+int rc_table_layout(const rc_ctx *ctx)
+{
+    if (!ctx) return RC_ERR_ARG;
+    if (!ctx->d_buckets) return RC_ERR_STATE;
+    return ctx->layout;
 }
 
 int rc_table_stats(const rc_ctx *ctx, uint64_t *bytes, uint64_t *buckets, uint64_t *entries)

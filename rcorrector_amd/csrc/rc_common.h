@@ -27,25 +27,33 @@
 #define RC_INF 1000000000        // utils.h:10
 #define RC_INT_MIN (-2147483647 - 1)
 
-// ---- table bucket: 64 B = 5 x {key_lo,key_hi,count} + 1 meta dword -------------------------
-// count == 0 marks an empty slot (stored counts are >= 2 by construction, main.cpp:299).
-// meta bit0 = "some key whose home is <= this bucket lives in a later bucket" (probe goes on).
-// RC_BUCKET128: 128-byte buckets of 10 slots (the fabric fetches 128 B per L2 miss anyway)
-#if defined(RC_BUCKET128)
-#define RC_BUCKET_SLOTS 10
-#define RC_BUCKET_DWORDS 32
-#define RC_BUCKET_BYTES 128
-#else
-#define RC_BUCKET_SLOTS 5
+// ---- table buckets: 64 B, one HBM sector per probe; two slot layouts -------------------------
+// WIDE   (layout 0): 5 x {key_lo, key_hi, count} + 1 meta dword.  count == 0 marks an empty slot
+//   (stored counts are >= 2 by construction, main.cpp:299); meta bit0 = "some key whose home is <=
+//   this bucket lives in a later bucket" (probe goes on).  Any k, any count.
+// PACKED (layout 1): 8 x {rem, word}.  The canonical code goes through a bijection of the 2k-bit
+//   key space; the home bucket is the top of (mixed * nb_home) and `rem` the next 32 bits of that
+//   product, which together identify the code as long as nb_home >= 2^(2k-32) (rc_packed_addr).
+//   word = count (27 bits) | displacement bucket - home (4 bits, 0..14; 15 = empty slot) | bit 31: the
+//   continue flag, kept in the bucket's last slot.  A third less memory per k-mer: more of the table within the reach
+//   of the TLB and the Infinity Cache.  Chosen per table when k, the counts and the placement allow.
 #define RC_BUCKET_DWORDS 16
 #define RC_BUCKET_BYTES 64
-#endif
+#define RC_WIDE_SLOTS 5
+#define RC_PACKED_SLOTS 8
+#define RC_PACKED_COUNT_MASK 0x07FFFFFFu
+#define RC_PACKED_MAX_DISP 14            // displacement 15 marks an empty slot
+#define RC_PACKED_EMPTY_WORD 0x78000000u
 
 struct rc_table_view {
     const uint32_t *buckets;  // nbuckets_alloc * 16 dwords, 64-B aligned
-    uint32_t nb_home;         // number of home buckets (any value; home = mulhi(hash, nb_home))
+    uint32_t nb_home;         // number of home buckets (any value)
     uint32_t nbuckets_alloc;  // home buckets + slack (no wrap-around)
+    int layout;               // 0 wide, 1 packed
+    int k;
 };
+
+RC_HD int rc_layout_slots(int layout) { return layout ? RC_PACKED_SLOTS : RC_WIDE_SLOTS; }
 
 RC_HD uint64_t rc_kmer_mask(int k) { return k >= 32 ? ~0ull : ((1ull << (2 * k)) - 1ull); }
 
@@ -110,6 +118,114 @@ RC_HD uint32_t rc_hash(uint64_t key)
 RC_HD uint32_t rc_home(uint64_t key, uint32_t nb_home)
 {
     return (uint32_t)(((uint64_t)rc_hash(key) * (uint64_t)nb_home) >> 32);
+}
+
+// ---- PACKED layout addressing ---------------------------------------------------------------------
+// The code goes through a bijection of [0, 2^2k) built from 32-bit multiplies only (the probe
+// kernels are bound by VALU issue, and a 64-bit multiply is four quarter-rate instructions):
+// for 2k <= 32 two rounds of "odd multiply modulo 2^2k, xor-shift by k"; for 2k > 32 an unbalanced
+// Feistel network over the low 32 bits and the 2k-32 bits above them.  rc_unmix2k undoes it.
+#define RC_MIX_A 0x9E3779B1u
+#define RC_MIX_B 0x85EBCA77u
+#define RC_MIX_C 0xC2B2AE3Du
+#define RC_MIX_D 0x27D4EB2Fu
+#define RC_MIX_E 0x165667B1u
+RC_HD uint64_t rc_mix2k(uint64_t c, int k)
+{
+    const int kb = 2 * k;
+    if (kb <= 32) {
+        const uint32_t M = kb == 32 ? ~0u : ((1u << kb) - 1u);
+        uint32_t x = (uint32_t)c;
+        x = (x * RC_MIX_A) & M;
+        x ^= x >> k;
+        x = (x * RC_MIX_B) & M;
+        x ^= x >> k;
+        return x;
+    }
+    const int sh = 64 - kb;  // = 32 - (bits of hi), 0..31
+    uint32_t lo = (uint32_t)c, hi = (uint32_t)(c >> 32);
+    hi ^= (lo * RC_MIX_A) >> sh;
+    lo = (lo ^ (hi * RC_MIX_B)) * RC_MIX_C;
+    hi ^= (lo * RC_MIX_D) >> sh;
+    lo ^= hi * RC_MIX_E;
+    return ((uint64_t)hi << 32) | lo;
+}
+RC_HD uint64_t rc_unmix2k(uint64_t m, int k)
+{
+    const int kb = 2 * k;
+    if (kb <= 32) {
+        const uint32_t M = kb == 32 ? ~0u : ((1u << kb) - 1u);
+        uint32_t x = (uint32_t)m;
+        x ^= x >> k;
+        x = (x * 0xB6C92F47u) & M;  // inverses modulo 2^32 of RC_MIX_B, RC_MIX_A
+        x ^= x >> k;
+        x = (x * 0x0E8B2F51u) & M;
+        return x;
+    }
+    const int sh = 64 - kb;
+    uint32_t lo = (uint32_t)m, hi = (uint32_t)(m >> 32);
+    lo ^= hi * RC_MIX_E;
+    hi ^= (lo * RC_MIX_D) >> sh;
+    lo = (lo * 0xA89ED915u) ^ (hi * RC_MIX_B);  // inverse modulo 2^32 of RC_MIX_C
+    hi ^= (lo * RC_MIX_A) >> sh;
+    return ((uint64_t)hi << 32) | lo;
+}
+RC_HD uint32_t rc_mulhi32(uint32_t a, uint32_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umulhi(a, b);
+#else
+    return (uint32_t)(((uint64_t)a * b) >> 32);
+#endif
+}
+// home bucket and remainder of a canonical code: P = (mixed << (64 - 2k)) * nb_home as a 96-bit
+// number, home = P >> 64, rem = bits 32..63 of P.  Codes that share a home differ by at least
+// 2^(64-2k) * nb_home in P, so by at least one unit of rem when nb_home >= 2^(2k-32).
+RC_HD void rc_packed_addr(uint64_t canon, int k, uint32_t nb_home, uint32_t *home, uint32_t *rem)
+{
+    const int kb = 2 * k;
+    const uint64_t m = rc_mix2k(canon, k);
+    if (kb <= 32) {
+        const uint32_t a = (uint32_t)m << (32 - kb);
+        *home = rc_mulhi32(a, nb_home);
+        *rem = a * nb_home;
+        return;
+    }
+    const int sh = 64 - kb;
+    const uint32_t lo = (uint32_t)m, hi = (uint32_t)(m >> 32);
+    const uint32_t a = sh ? ((hi << sh) | (lo >> (32 - sh))) : hi, b = lo << sh;  // m << sh as two words
+    const uint32_t tl = a * nb_home, th = rc_mulhi32(a, nb_home), u = rc_mulhi32(b, nb_home);
+    const uint32_t sum = tl + u;
+    *home = th + (sum < tl ? 1u : 0u);
+    *rem = sum;
+}
+// the inverse: the canonical code stored as (home, rem).  With m = mixed code, m * nb_home =
+// home * 2^2k + f and rem = the top 32 bits of the 2k-bit fraction f, so m = ceil(N / nb_home) for
+// N = home * 2^2k + (rem aligned to the top of 2k bits) -- a 96-bit by 32-bit long division.
+RC_HD uint64_t rc_packed_key(uint32_t home, uint32_t rem, int k, uint32_t nb_home)
+{
+    const int kb = 2 * k;
+    uint64_t hi, lo;  // N = hi * 2^64 + lo
+    if (kb >= 32) {
+        const uint64_t v = ((uint64_t)home << 32) | rem;
+        const int sh = kb - 32;
+        hi = sh ? (v >> (64 - sh)) : 0;
+        lo = v << sh;
+    } else {
+        hi = 0;
+        lo = ((uint64_t)home << kb) | (rem >> (32 - kb));
+    }
+    const uint64_t nb = nb_home;
+    uint64_t r = hi % nb;  // hi / nb == 0: the quotient is below 2^2k <= 2^64
+    uint64_t t = (r << 32) | (lo >> 32);
+    const uint64_t q1 = t / nb;
+    r = t % nb;
+    t = (r << 32) | (lo & 0xFFFFFFFFull);
+    const uint64_t q0 = t / nb;
+    r = t % nb;
+    uint64_t m = (q1 << 32) | q0;
+    if (r) ++m;
+    return rc_unmix2k(m, k);
 }
 
 // ---- rolling code with invalid tracker (KmerCode.cpp:7-42) ---------------------------------

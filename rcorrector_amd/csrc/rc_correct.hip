@@ -249,11 +249,13 @@ struct DevWaveT {
     }
     __device__ __forceinline__ void stack_top(int idx, rc_frame &f)
     {
-        // all loads go out before the first value is used (one round trip, not thirteen)
-        const volatile uint32_t *p = reinterpret_cast<const volatile uint32_t *>(stack + idx);
+        // all loads go out before the first value is used (one round trip, not thirteen).  The frame
+        // was written by lane 0 of this very wave: workgroup-scope loads (served by the XCD's L2,
+        // past the CU's L1) see it -- system-scope (volatile) loads went all the way to memory
+        const uint32_t *p = reinterpret_cast<const uint32_t *>(stack + idx);
         uint32_t d[13];
 #pragma unroll
-        for (int q = 0; q < 13; ++q) d[q] = p[q];
+        for (int q = 0; q < 13; ++q) d[q] = __hip_atomic_load(p + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         static_assert(sizeof(rc_frame) == 56 && offsetof(rc_frame, mask) == 48, "rc_frame layout");
         f.code = ((uint64_t)(uint32_t)uni((int)d[1]) << 32) | (uint32_t)uni((int)d[0]);
         f.inv = uni((int)d[2]);

@@ -3,11 +3,36 @@
 #include "rc_common.h"
 
 // Store::GetCount on a canonical code (Store.h:59-66): one 64-byte bucket = four 16-byte loads
-// of the same sector; the five {key,count} slots and the meta dword are picked out of registers.
-// Of two equal keys the first in probe order wins (the build places the later Put first).
+// of the same sector; the slots are picked out of registers.  Of two equal keys the first in
+// probe order wins (the build places the later Put first).  T.layout is wave-uniform.
 // n_req (optional): incremented once per bucket read (profiling builds of k_correct)
 __device__ __forceinline__ int rc_table_lookup(const rc_table_view &T, uint64_t canon, uint32_t *n_req = nullptr)
 {
+    // The slots are compared as 64-bit words, from the last slot to the first, so that the first slot in
+    // probe order is assigned last and wins without a test (two instructions per slot: the probe
+    // kernels are bound by VALU issue).
+    if (T.layout) {  // PACKED: 8 x {rem, count | disp << 27}, continue flag in the last slot's bit 31
+        uint32_t b, rem;
+        rc_packed_addr(canon, T.k, T.nb_home, &b, &rem);
+        for (uint32_t disp = 0;; ++disp, ++b) {
+            const uint4 *p = reinterpret_cast<const uint4 *>(T.buckets + (size_t)b * RC_BUCKET_DWORDS);
+            uint64_t d[RC_PACKED_SLOTS];
+            if (n_req) ++*n_req;
+#pragma unroll
+            for (int q = 0; q < RC_BUCKET_DWORDS / 4; ++q) {
+                const uint4 v = p[q];
+                d[2 * q + 0] = ((uint64_t)v.y << 32) | v.x;
+                d[2 * q + 1] = ((uint64_t)v.w << 32) | v.z;
+            }
+            // an empty slot carries displacement 15, which no entry has: rem and displacement decide
+            const uint64_t want = ((uint64_t)(disp << 27) << 32) | rem;
+            int r = 0;
+#pragma unroll
+            for (int s2 = RC_PACKED_SLOTS - 1; s2 >= 0; --s2)
+                r = (d[s2] & 0x78000000FFFFFFFFull) == want ? (int)((uint32_t)(d[s2] >> 32) & RC_PACKED_COUNT_MASK) : r;
+            if (r != 0 || !(d[RC_PACKED_SLOTS - 1] >> 63) || disp == RC_PACKED_MAX_DISP) return r;
+        }
+    }
     uint32_t b = rc_home(canon, T.nb_home);
     const uint32_t klo = (uint32_t)canon, khi = (uint32_t)(canon >> 32);
     for (;;) {
@@ -22,12 +47,59 @@ __device__ __forceinline__ int rc_table_lookup(const rc_table_view &T, uint64_t 
             d[4 * q + 2] = v.z;
             d[4 * q + 3] = v.w;
         }
+        // (an empty slot is {0, 0, 0}: it can only "match" the all-A code, with the count 0 of a miss)
         int r = 0;
 #pragma unroll
-        for (int s2 = 0; s2 < RC_BUCKET_SLOTS; ++s2)
-            r = (d[3 * s2] == klo && d[3 * s2 + 1] == khi && r == 0) ? (int)d[3 * s2 + 2] : r;
+        for (int s2 = RC_WIDE_SLOTS - 1; s2 >= 0; --s2)
+            r = (d[3 * s2] == klo && d[3 * s2 + 1] == khi) ? (int)d[3 * s2 + 2] : r;  // (as one 64-bit compare the
+                                                                                       // compiler re-slices the bucket read into a load per slot)
         if (r != 0 || !(d[RC_BUCKET_DWORDS - 1] & 1u)) return r;
         ++b;
     }
 }
 
+// the live entry stored in slot s of bucket b, if any: its canonical code and count.  A key that was
+// Put more than once occupies several slots; the one a probe reaches first (the latest Put,
+// Store.h:55) is the table's entry, the others are dead.
+__device__ __forceinline__ bool rc_table_slot_entry(const rc_table_view &T, size_t b, int s, uint64_t *key, int32_t *count)
+{
+    const uint32_t *w = T.buckets + b * RC_BUCKET_DWORDS;
+    uint64_t kk;
+    int32_t cc;
+    if (T.layout) {
+        const uint32_t word = w[2 * s + 1];
+        cc = (int32_t)(word & RC_PACKED_COUNT_MASK);
+        if (cc == 0) return false;
+        kk = rc_packed_key((uint32_t)(b - ((word >> 27) & 15u)), w[2 * s], T.k, T.nb_home);
+    } else {
+        cc = (int32_t)w[3 * s + 2];
+        if (cc == 0) return false;
+        kk = ((uint64_t)w[3 * s + 1] << 32) | w[3 * s];
+    }
+    // walk the probe sequence from the key's home: live iff this slot is the first match
+    uint32_t hb, rem = 0;
+    if (T.layout)
+        rc_packed_addr(kk, T.k, T.nb_home, &hb, &rem);
+    else
+        hb = rc_home(kk, T.nb_home);
+    const int S = rc_layout_slots(T.layout);
+    for (size_t bb = hb;; ++bb) {
+        const uint32_t *q = T.buckets + bb * RC_BUCKET_DWORDS;
+        for (int i = 0; i < S; ++i) {
+            bool match;
+            if (T.layout) {
+                const uint32_t word = q[2 * i + 1];
+                match = (word & RC_PACKED_COUNT_MASK) != 0 && q[2 * i] == rem && ((word >> 27) & 15u) == (uint32_t)(bb - hb);
+            } else {
+                match = q[3 * i + 2] != 0 && q[3 * i] == (uint32_t)kk && q[3 * i + 1] == (uint32_t)(kk >> 32);
+            }
+            if (match) {
+                if (bb != b || i != s) return false;  // shadowed by an earlier slot
+                *key = kk;
+                *count = cc;
+                return true;
+            }
+        }
+        if (bb > b) return false;  // (not reached: the slot itself matches at the latest)
+    }
+}

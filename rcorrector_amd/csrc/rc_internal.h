@@ -75,7 +75,10 @@ struct rc_ctx {
     uint32_t *d_buckets = nullptr;
     bool buckets_borrowed = false;  // rc_table_share: another context owns d_buckets
     uint32_t nb_home = 0;
-    double table_load = 0.50;  // target slot load factor of the next build
+    double table_load = 0.50;  // target slot load factor of the next build (WIDE layout)
+    double table_load_packed = 0.50;  // ... (PACKED layout)
+    int layout = 0;       // slot layout of the table (rc_common.h): 0 WIDE, 1 PACKED
+    int layout_pref = 1;  // 0: always WIDE (RC_TABLE_LAYOUT=wide)
     uint32_t nb_alloc = 0;
     size_t n_entries = 0;   // accepted entries (duplicates included)
     size_t table_bytes = 0;

@@ -26,37 +26,139 @@
 
 // ---- K0: build -----------------------------------------------------------------------------
 __global__ void k_home_and_index(const uint64_t *__restrict__ canon, uint32_t *__restrict__ home,
-                                 uint32_t *__restrict__ idx, size_t n, uint32_t nb_home)
+                                 uint32_t *__restrict__ idx, size_t n, uint32_t nb_home, int layout, int k)
 {
     size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     size_t i = n - 1 - j;  // reversed input order (see header)
-    home[j] = rc_home(canon[i], nb_home);
+    uint32_t h, rem;
+    if (layout)
+        rc_packed_addr(canon[i], k, nb_home, &h, &rem);
+    else
+        h = rc_home(canon[i], nb_home);
+    home[j] = h;
     idx[j] = (uint32_t)i;
 }
 
-__global__ void k_slot_seed(const uint32_t *__restrict__ home_sorted, long long *__restrict__ q, size_t n)
+__global__ void k_slot_seed(const uint32_t *__restrict__ home_sorted, long long *__restrict__ q, size_t n, int slots)
 {
     size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
-    q[j] = (long long)RC_BUCKET_SLOTS * home_sorted[j] - (long long)j;
+    q[j] = (long long)slots * home_sorted[j] - (long long)j;
 }
 
-__global__ void k_scatter(const uint32_t *__restrict__ home_sorted, const uint32_t *__restrict__ idx_sorted,
-                          const long long *__restrict__ qmax, const uint64_t *__restrict__ canon,
-                          const int32_t *__restrict__ counts, uint32_t *__restrict__ buckets, size_t n)
+// what rules the PACKED layout out for a given input: a count of 2^27 or more, or a key pushed
+// more than 14 buckets past its home.  flags[0] |= 1 / 2.
+__global__ void k_packed_feasible(const uint32_t *__restrict__ home_sorted, const long long *__restrict__ qmax,
+                                  const int32_t *__restrict__ counts, size_t n, unsigned *__restrict__ flags)
 {
     size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     const long long p = qmax[j] + (long long)j;
-    const uint32_t b = (uint32_t)(p / RC_BUCKET_SLOTS), s = (uint32_t)(p % RC_BUCKET_SLOTS);
+    unsigned f = 0;
+    if ((uint32_t)counts[j] > RC_PACKED_COUNT_MASK) f |= 1u;  // (counts are indexed by input, any order does)
+    if ((uint32_t)(p / RC_PACKED_SLOTS) - home_sorted[j] > RC_PACKED_MAX_DISP) f |= 2u;
+    if (f) atomicOr(flags, f);
+}
+
+__global__ void k_scatter(const uint32_t *__restrict__ home_sorted, const uint32_t *__restrict__ idx_sorted,
+                          const long long *__restrict__ qmax, const uint64_t *__restrict__ canon,
+                          const int32_t *__restrict__ counts, uint32_t *__restrict__ buckets, size_t n, uint32_t nb_home, int layout, int k)
+{
+    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const long long p = qmax[j] + (long long)j;
+    const int S = rc_layout_slots(layout);
+    const uint32_t b = (uint32_t)(p / S), s = (uint32_t)(p % S);
     const uint32_t i = idx_sorted[j];
     const uint64_t key = canon[i];
-    uint32_t *w = buckets + (size_t)b * RC_BUCKET_DWORDS + s * 3;
-    w[0] = (uint32_t)key;
-    w[1] = (uint32_t)(key >> 32);
-    w[2] = (uint32_t)counts[i];
-    if (s == 0 && home_sorted[j] < b) buckets[(size_t)(b - 1) * RC_BUCKET_DWORDS + (RC_BUCKET_DWORDS - 1)] = 1u;
+    if (layout) {
+        uint32_t h, rem;
+        rc_packed_addr(key, k, nb_home, &h, &rem);
+        uint32_t *w = buckets + (size_t)b * RC_BUCKET_DWORDS + s * 2;
+        w[0] = rem;
+        // the last slot's bit 31 is the bucket's continue flag, set (atomically: another thread may own
+        // that slot) by whoever lands in slot 0 of the next bucket with an earlier home
+        atomicAnd(w + 1, 0x80000000u);  // (the slot starts as RC_PACKED_EMPTY_WORD; the flag bit may already be set)
+        atomicOr(w + 1, ((uint32_t)counts[i] & RC_PACKED_COUNT_MASK) | ((b - h) << 27));
+        if (s == 0 && h < b) atomicOr(buckets + (size_t)(b - 1) * RC_BUCKET_DWORDS + (RC_BUCKET_DWORDS - 1), 0x80000000u);
+    } else {
+        uint32_t *w = buckets + (size_t)b * RC_BUCKET_DWORDS + s * 3;
+        w[0] = (uint32_t)key;
+        w[1] = (uint32_t)(key >> 32);
+        w[2] = (uint32_t)counts[i];
+        if (s == 0 && home_sorted[j] < b) buckets[(size_t)(b - 1) * RC_BUCKET_DWORDS + (RC_BUCKET_DWORDS - 1)] = 1u;
+    }
+}
+
+// one attempt at one layout; *ok = false (PACKED only) if a count or a displacement does not fit
+static int build_attempt(rc_ctx *ctx, const uint64_t *d_canon, const int32_t *d_counts, size_t n, int layout, uint32_t nb_home, bool *ok)
+{
+    *ok = true;
+    const int S = rc_layout_slots(layout);
+    int bits = 0;
+    while ((1ull << bits) < (uint64_t)nb_home) ++bits;
+    long long p_last = -1;
+    rc_dev_tmp b_home, b_home_s, b_idx, b_idx_s, b_q, b_qm, b_tmp, b_flags;
+    const unsigned B = 256;
+    const unsigned G = (unsigned)((n + B - 1) / B);
+    if (n > 0) {
+        size_t tmp_sort = 0, tmp_scan = 0;
+        RC_CHECK_HIP(ctx, b_home.alloc(n * 4));
+        RC_CHECK_HIP(ctx, b_home_s.alloc(n * 4));
+        RC_CHECK_HIP(ctx, b_idx.alloc(n * 4));
+        RC_CHECK_HIP(ctx, b_idx_s.alloc(n * 4));
+        RC_CHECK_HIP(ctx, b_q.alloc(n * 8));
+        RC_CHECK_HIP(ctx, b_qm.alloc(n * 8));
+        RC_CHECK_HIP(ctx, b_flags.alloc(8));
+        uint32_t *home = b_home.as<uint32_t>(), *home_s = b_home_s.as<uint32_t>();
+        uint32_t *idx = b_idx.as<uint32_t>(), *idx_s = b_idx_s.as<uint32_t>();
+        long long *q = b_q.as<long long>(), *qm = b_qm.as<long long>();
+        hipLaunchKernelGGL(k_home_and_index, dim3(G), dim3(B), 0, ctx->stream, d_canon, home, idx, n, nb_home, layout, ctx->k);
+        RC_CHECK_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp_sort, home, home_s, idx, idx_s, n, 0, bits > 0 ? bits : 1, ctx->stream));
+        RC_CHECK_HIP(ctx, rocprim::inclusive_scan(nullptr, tmp_scan, q, qm, n, rocprim::maximum<long long>(), ctx->stream));
+        RC_CHECK_HIP(ctx, b_tmp.alloc(tmp_sort > tmp_scan ? tmp_sort : tmp_scan));
+        RC_CHECK_HIP(ctx, rocprim::radix_sort_pairs(b_tmp.p, tmp_sort, home, home_s, idx, idx_s, n, 0, bits > 0 ? bits : 1, ctx->stream));
+        hipLaunchKernelGGL(k_slot_seed, dim3(G), dim3(B), 0, ctx->stream, home_s, q, n, S);
+        RC_CHECK_HIP(ctx, rocprim::inclusive_scan(b_tmp.p, tmp_scan, q, qm, n, rocprim::maximum<long long>(), ctx->stream));
+        long long q_last = 0;
+        unsigned flags = 0;
+        if (layout) {
+            RC_CHECK_HIP(ctx, hipMemsetAsync(b_flags.p, 0, 8, ctx->stream));
+            hipLaunchKernelGGL(k_packed_feasible, dim3(G), dim3(B), 0, ctx->stream, home_s, qm, d_counts, n, b_flags.as<unsigned>());
+            RC_CHECK_HIP(ctx, hipMemcpyAsync(&flags, b_flags.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        RC_CHECK_HIP(ctx, hipMemcpyAsync(&q_last, qm + (n - 1), 8, hipMemcpyDeviceToHost, ctx->stream));
+        RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (flags) {
+            *ok = false;
+            return RC_OK;
+        }
+        p_last = q_last + (long long)(n - 1);
+    }
+    uint64_t need = (uint64_t)(p_last / S) + 2;  // +1 empty bucket after the last used
+    uint64_t nb_alloc = need > (uint64_t)nb_home + 1 ? need : (uint64_t)nb_home + 1;
+    if (nb_alloc >= (1ull << 32)) {
+        rc_set_error(ctx, "table build: bucket count overflow");
+        return RC_ERR_ARG;
+    }
+    ctx->nb_home = nb_home;
+    ctx->layout = layout;
+    ctx->nb_alloc = (uint32_t)nb_alloc;
+    ctx->table_bytes = (size_t)nb_alloc * RC_BUCKET_BYTES;
+    RC_CHECK_HIP(ctx, hipMalloc((void **)&ctx->d_buckets, ctx->table_bytes));
+    if (layout)
+        RC_CHECK_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)ctx->d_buckets, (int)RC_PACKED_EMPTY_WORD, ctx->table_bytes / 4, ctx->stream));
+    else
+        RC_CHECK_HIP(ctx, hipMemsetAsync(ctx->d_buckets, 0, ctx->table_bytes, ctx->stream));
+    if (n > 0) {
+        hipLaunchKernelGGL(k_scatter, dim3(G), dim3(B), 0, ctx->stream, b_home_s.as<uint32_t>(), b_idx_s.as<uint32_t>(),
+                           b_qm.as<long long>(), d_canon, d_counts, ctx->d_buckets, n, nb_home, layout, ctx->k);
+        RC_CHECK_HIP(ctx, hipGetLastError());
+    }
+    RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->n_entries = n;
+    return RC_OK;
 }
 
 int rc_build_table_from_device_pairs(rc_ctx *ctx, const uint64_t *d_canon, const int32_t *d_counts, size_t n)
@@ -71,64 +173,29 @@ int rc_build_table_from_device_pairs(rc_ctx *ctx, const uint64_t *d_canon, const
     // home buckets: n / (slots * load).  Random 64-byte gathers on MI355X are request-rate bound
     // (~55 G/s, tools/microbench_gather.hip) and fall off a cliff once the table outgrows the TLB
     // reach (~2 GiB), so a dense table wins: fewer bytes => more MALL/L2 hits per probe.
-    double load = ctx->table_load;
-    if (!(load > 0.05 && load <= 0.95)) load = 0.50;
-    uint64_t want = (uint64_t)((double)n / (RC_BUCKET_SLOTS * load)) + 1;
-    if (want < 64) want = 64;
-    if (want >= (1ull << 32) - 8) {
+    auto buckets_for = [&](int slots, double load, double dflt) -> uint64_t {
+        if (!(load > 0.05 && load <= 0.95)) load = dflt;
+        uint64_t want = (uint64_t)((double)n / (slots * load)) + 1;
+        return want < 64 ? 64 : want;
+    };
+    const uint64_t wide = buckets_for(RC_WIDE_SLOTS, ctx->table_load, 0.50);
+    // PACKED needs nb_home >= 2^(2k-32) for (home, rem) to identify a code; it is used when that
+    // floor does not make the table larger than the WIDE one would be (small tables and k >= 28 stay WIDE)
+    uint64_t packed = buckets_for(RC_PACKED_SLOTS, ctx->table_load_packed, 0.50);
+    const int kb = 2 * ctx->k;
+    if (kb > 32 && packed < (1ull << (kb - 32))) packed = 1ull << (kb - 32);
+    if (ctx->layout_pref != 0 && packed <= wide && packed < (1ull << 32) - 8) {
+        bool ok = false;
+        int rc = build_attempt(ctx, d_canon, d_counts, n, 1, (uint32_t)packed, &ok);
+        if (rc) return rc;
+        if (ok) return RC_OK;  // else: a count >= 2^27 or a chain longer than 15 buckets -- WIDE takes anything
+    }
+    if (wide >= (1ull << 32) - 8) {
         rc_set_error(ctx, "table build: bucket count overflow");
         return RC_ERR_ARG;
     }
-    uint32_t nb_home = (uint32_t)want;
-    ctx->nb_home = nb_home;
-    int bits = 0;
-    while ((1ull << bits) < (uint64_t)nb_home) ++bits;
-
-    long long p_last = -1;
-    rc_dev_tmp b_home, b_home_s, b_idx, b_idx_s, b_q, b_qm, b_tmp;
-    const unsigned B = 256;
-    const unsigned G = (unsigned)((n + B - 1) / B);
-    if (n > 0) {
-        size_t tmp_sort = 0, tmp_scan = 0;
-        RC_CHECK_HIP(ctx, b_home.alloc(n * 4));
-        RC_CHECK_HIP(ctx, b_home_s.alloc(n * 4));
-        RC_CHECK_HIP(ctx, b_idx.alloc(n * 4));
-        RC_CHECK_HIP(ctx, b_idx_s.alloc(n * 4));
-        RC_CHECK_HIP(ctx, b_q.alloc(n * 8));
-        RC_CHECK_HIP(ctx, b_qm.alloc(n * 8));
-        uint32_t *home = b_home.as<uint32_t>(), *home_s = b_home_s.as<uint32_t>();
-        uint32_t *idx = b_idx.as<uint32_t>(), *idx_s = b_idx_s.as<uint32_t>();
-        long long *q = b_q.as<long long>(), *qm = b_qm.as<long long>();
-        hipLaunchKernelGGL(k_home_and_index, dim3(G), dim3(B), 0, ctx->stream, d_canon, home, idx, n, ctx->nb_home);
-        RC_CHECK_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp_sort, home, home_s, idx, idx_s, n, 0, bits > 0 ? bits : 1, ctx->stream));
-        RC_CHECK_HIP(ctx, rocprim::inclusive_scan(nullptr, tmp_scan, q, qm, n, rocprim::maximum<long long>(), ctx->stream));
-        RC_CHECK_HIP(ctx, b_tmp.alloc(tmp_sort > tmp_scan ? tmp_sort : tmp_scan));
-        RC_CHECK_HIP(ctx, rocprim::radix_sort_pairs(b_tmp.p, tmp_sort, home, home_s, idx, idx_s, n, 0, bits > 0 ? bits : 1, ctx->stream));
-        hipLaunchKernelGGL(k_slot_seed, dim3(G), dim3(B), 0, ctx->stream, home_s, q, n);
-        RC_CHECK_HIP(ctx, rocprim::inclusive_scan(b_tmp.p, tmp_scan, q, qm, n, rocprim::maximum<long long>(), ctx->stream));
-        long long q_last = 0;
-        RC_CHECK_HIP(ctx, hipMemcpyAsync(&q_last, qm + (n - 1), 8, hipMemcpyDeviceToHost, ctx->stream));
-        RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        p_last = q_last + (long long)(n - 1);
-    }
-    uint64_t need = (uint64_t)(p_last / RC_BUCKET_SLOTS) + 2;  // +1 empty bucket after the last used
-    uint64_t nb_alloc = need > (uint64_t)nb_home + 1 ? need : (uint64_t)nb_home + 1;
-    if (nb_alloc >= (1ull << 32)) {
-        rc_set_error(ctx, "table build: bucket count overflow");
-        return RC_ERR_ARG;
-    }
-    ctx->nb_alloc = (uint32_t)nb_alloc;
-    ctx->table_bytes = (size_t)nb_alloc * RC_BUCKET_BYTES;
-    RC_CHECK_HIP(ctx, hipMalloc((void **)&ctx->d_buckets, ctx->table_bytes));
-    RC_CHECK_HIP(ctx, hipMemsetAsync(ctx->d_buckets, 0, ctx->table_bytes, ctx->stream));
-    if (n > 0) {
-        hipLaunchKernelGGL(k_scatter, dim3(G), dim3(B), 0, ctx->stream, b_home_s.as<uint32_t>(), b_idx_s.as<uint32_t>(),
-                           b_qm.as<long long>(), d_canon, d_counts, ctx->d_buckets, n);
-        RC_CHECK_HIP(ctx, hipGetLastError());
-    }
-    RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->n_entries = n;
-    return RC_OK;
+    bool ok = false;
+    return build_attempt(ctx, d_canon, d_counts, n, 0, (uint32_t)wide, &ok);
 }
 
 // forward (or canonical) reference codes -> canonical, in place
@@ -191,66 +258,35 @@ int rc_launch_last_base_variants(rc_ctx *ctx, const uint64_t *d_codes, size_t n,
 }
 
 // every stored (canonical code, count) pair, in unspecified order (jf_dump writer / test support)
-__global__ void k_export(const uint32_t *__restrict__ buckets, size_t nslots, uint32_t nb_home, uint64_t *__restrict__ codes,
+__global__ void k_export(rc_table_view T, size_t nslots, uint64_t *__restrict__ codes,
                          int32_t *__restrict__ counts, unsigned long long *__restrict__ n_out, size_t cap)
 {
     size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nslots) return;
-    const uint32_t *w = buckets + (s / RC_BUCKET_SLOTS) * RC_BUCKET_DWORDS + (s % RC_BUCKET_SLOTS) * 3;
-    if (w[2] == 0) return;
-    // a key that was Put more than once occupies several slots; the one a probe reaches first (the
-    // latest Put, Store.h:55) is the table's entry, the others are dead: walk the probe sequence
-    // from the key's home bucket and keep this slot only if it is the first match
-    {
-        const uint64_t key = ((uint64_t)w[1] << 32) | w[0];
-        size_t b = rc_home(key, nb_home);
-        for (;;) {
-            const uint32_t *q = buckets + b * RC_BUCKET_DWORDS;
-            bool found = false;
-            for (int i = 0; i < RC_BUCKET_SLOTS; ++i)
-                if (q[3 * i + 2] != 0 && q[3 * i] == w[0] && q[3 * i + 1] == w[1]) {
-                    if (b * RC_BUCKET_SLOTS + (size_t)i != s) return;  // shadowed by an earlier slot
-                    found = true;
-                    break;
-                }
-            if (found) break;
-            ++b;  // (the slot exists, so the walk ends at it at the latest)
-        }
-    }
+    const int S = rc_layout_slots(T.layout);
+    uint64_t key;
+    int32_t cnt;
+    if (!rc_table_slot_entry(T, s / S, (int)(s % S), &key, &cnt)) return;
     unsigned long long at = atomicAdd(n_out, 1ull);
     if (at < cap) {
-        codes[at] = ((uint64_t)w[1] << 32) | w[0];
-        counts[at] = (int32_t)w[2];
+        codes[at] = key;
+        counts[at] = cnt;
     }
 }
 
 // order-independent 64-bit digest of the table's CONTENT (what Store::GetCount can return): the sum
 // over live entries of mix(code, count) -- two tables with the same digest answer every probe alike
-// whatever their bucket layout (load factor, build order)
-__global__ void k_digest(const uint32_t *__restrict__ buckets, size_t nslots, uint32_t nb_home, unsigned long long *__restrict__ out)
+// whatever their bucket layout (slot format, load factor, build order)
+__global__ void k_digest(rc_table_view T, size_t nslots, unsigned long long *__restrict__ out)
 {
     size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long v = 0;
     if (s < nslots) {
-        const uint32_t *w = buckets + (s / RC_BUCKET_SLOTS) * RC_BUCKET_DWORDS + (s % RC_BUCKET_SLOTS) * 3;
-        if (w[2] != 0) {
-            const uint64_t key = ((uint64_t)w[1] << 32) | w[0];
-            size_t b = rc_home(key, nb_home);
-            bool live = false;
-            for (;;) {  // first slot of the probe sequence that holds the key (k_export's rule)
-                const uint32_t *q = buckets + b * RC_BUCKET_DWORDS;
-                bool found = false;
-                for (int i = 0; i < RC_BUCKET_SLOTS; ++i)
-                    if (q[3 * i + 2] != 0 && q[3 * i] == w[0] && q[3 * i + 1] == w[1]) {
-                        live = b * RC_BUCKET_SLOTS + (size_t)i == s;
-                        found = true;
-                        break;
-                    }
-                if (found) break;
-                ++b;
-            }
-            if (live) v = rc_dump_order_key(key ^ rc_dump_order_key((uint64_t)w[2] + 0x9E3779B97F4A7C15ull));
-        }
+        const int S = rc_layout_slots(T.layout);
+        uint64_t key;
+        int32_t cnt;
+        if (rc_table_slot_entry(T, s / S, (int)(s % S), &key, &cnt))
+            v = rc_dump_order_key(key ^ rc_dump_order_key((uint64_t)(uint32_t)cnt + 0x9E3779B97F4A7C15ull));
     }
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     if ((threadIdx.x & 63) == 0 && v) atomicAdd(out, v);
@@ -258,16 +294,16 @@ __global__ void k_digest(const uint32_t *__restrict__ buckets, size_t nslots, ui
 
 int rc_launch_digest(rc_ctx *ctx, unsigned long long *d_out)
 {
-    const size_t nslots = (size_t)ctx->nb_alloc * RC_BUCKET_SLOTS;
-    hipLaunchKernelGGL(k_digest, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_buckets, nslots, ctx->nb_home, d_out);
+    const size_t nslots = (size_t)ctx->nb_alloc * rc_layout_slots(ctx->layout);
+    hipLaunchKernelGGL(k_digest, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, ctx->stream, rc_view(ctx), nslots, d_out);
     RC_CHECK_HIP(ctx, hipGetLastError());
     return RC_OK;
 }
 
 int rc_launch_export(rc_ctx *ctx, uint64_t *d_codes, int32_t *d_counts, unsigned long long *d_n, size_t cap)
 {
-    const size_t nslots = (size_t)ctx->nb_alloc * RC_BUCKET_SLOTS;
-    hipLaunchKernelGGL(k_export, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_buckets, nslots, ctx->nb_home, d_codes, d_counts, d_n, cap);
+    const size_t nslots = (size_t)ctx->nb_alloc * rc_layout_slots(ctx->layout);
+    hipLaunchKernelGGL(k_export, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, ctx->stream, rc_view(ctx), nslots, d_codes, d_counts, d_n, cap);
     RC_CHECK_HIP(ctx, hipGetLastError());
     return RC_OK;
 }

@@ -418,3 +418,49 @@ def test_correct_batch_refuses_wrong_dtype(gpu_ctx_factory, oracle):
         ctx.correct_batch(0, a[::2], qa, off)
     ret = ctx.correct_batch(0, a, qa, off.astype(np.int64))[0]   # offsets are converted
     assert (ret > 0).sum() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [11, 16, 17, 23, 25])
+def test_table_packed_and_wide_layouts_hold_the_same_table(k, monkeypatch):
+    """The two slot layouts (rc_common.h) of the k-mer table answer every lookup alike, export the same
+    (code, count) set and have the same content digest; PACKED is chosen when k, the counts and the
+    placement allow it, WIDE takes over when a count needs more than 27 bits."""
+    rng = np.random.Generator(np.random.PCG64(100 + k))
+    n = 300000
+    mask = np.uint64((1 << (2 * k)) - 1)
+    fwd = rng.integers(0, 1 << 62, size=n, dtype=np.uint64) & mask
+    can = np.unique(np.minimum(fwd, _revcomp_codes(fwd, k)))
+    counts = rng.integers(2, 1 << 20, size=len(can)).astype(np.int32)
+    counts[2000:2007] = [2, (1 << 27) - 1, 3, 100, 2, 65535, 1 << 26]
+    # duplicates: the later Put wins (Store.h:55)
+    codes = np.concatenate([can, can[:1000]])
+    cnts = np.concatenate([counts, counts[:1000] + 1])
+    want = counts.copy()
+    want[:1000] += 1
+    probes = np.concatenate([can, rng.integers(0, 1 << 62, size=50000, dtype=np.uint64) & mask])
+    res = {}
+    for layout in ("packed", "wide"):
+        monkeypatch.setenv("RC_TABLE_LAYOUT", layout)
+        ctx = rcorrector_amd.Context(k=k, device=0)
+        ctx.table_build(codes, cnts)
+        ec, en = ctx.table_export()
+        o = np.argsort(ec)
+        res[layout] = (ctx.table_layout(), ctx.lookup(probes), ec[o], en[o], ctx.table_digest(), ctx.table_stats()["bytes"])
+        ctx.close()
+    assert res["wide"][0] == 0
+    min_buckets = 1 << max(0, 2 * k - 32)
+    if min_buckets <= len(codes) / (5 * 0.5):
+        assert res["packed"][0] == 1 and res["packed"][5] < res["wide"][5]
+    for a, b in zip(res["packed"][1:5], res["wide"][1:5]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(res["wide"][1][:len(can)], want)
+    assert np.array_equal(res["wide"][2], can) and np.array_equal(res["wide"][3], want)
+    # one count that does not fit 27 bits: the build falls back to WIDE by itself
+    monkeypatch.setenv("RC_TABLE_LAYOUT", "packed")
+    ctx = rcorrector_amd.Context(k=k, device=0)
+    cnts2 = cnts.copy()
+    cnts2[len(can) // 2] = 1 << 27
+    ctx.table_build(codes, cnts2)
+    assert ctx.table_layout() == 0 and ctx.lookup(can[len(can) // 2:len(can) // 2 + 1])[0] == 1 << 27
+    ctx.close()
