@@ -1098,17 +1098,25 @@ RC_HD int rc_correct_read(W &w, rc_read_state &S, const rc_run_params &P, int pa
         // lower the thresholds, :1247-1289
         w.phase(4);
         rc_masked_sorted(w, S);
+        // the scan of :1258-1277 from the top of the sorted counts: a "drop" at i is v[i] <= strong with
+        // v[i] > 2 v[i-1] && v[i] > 10, or v[i-1] == 0 && v[i] >= 5; the scan stops at the highest drop
+        // below strong (at index 0 if there is none) and any drop at all lowers the thresholds to v[stop]
         bool has_drop = false;
-        for (i = kcnt - 1; i >= 1; --i) {
-            int vi = RC_U(S.v[i]), vp = RC_U(S.v[i - 1]);
-            if (vi > strong) continue;
-            if (vi > 2 * vp && vi > 10) {
+        i = 0;
+        for (int b0 = ((kcnt - 1) >> 6) << 6; b0 >= 0; b0 -= 64) {
+            const int st = strong;
+            const uint64_t dm = w.ballot64(b0, kcnt, [&](int q) {
+                if (q < 1) return false;
+                const int vi = S.v[q], vp = S.v[q - 1];
+                return vi <= st && ((vi > 2 * vp && vi > 10) || (vp == 0 && vi >= 5));
+            });
+            const uint64_t bm = dm & w.ballot64(b0, kcnt, [&](int q) { return S.v[q] < st; });
+            if (bm) {  // drops above the stop (in this chunk) count too
                 has_drop = true;
-                if (vi < strong) break;
-            } else if (vp == 0 && vi >= 5) {
-                has_drop = true;
-                if (vi < strong) break;
+                i = b0 + 63 - rc_clz64(bm);
+                break;
             }
+            if (dm) has_drop = true;
         }
         if (has_drop) {
             ++iter;
@@ -1135,59 +1143,47 @@ RC_HD int rc_correct_read(W &w, rc_read_state &S, const rc_run_params &P, int pa
     const int badq = P.bad_qual;
     const int q0 = RC_U(S.qual[0]);
     for (int i = 1; i < cnt; ++i) {  // pairwise veto, :1314-1398
+        // two neighbouring fixes pp < pi within one k-mer span: compare the weakest k-mer that covers
+        // only one of them with the weakest that covers both (k-mers reaching the fix before pp or the
+        // one after pi are left out).  All candidate k-mers lie in [pp-k+1, pi] -- at most 2k-1 <= 63 of
+        // them, one per lane -- so the three scans of the reference are two wave minima.
         const int pi = RC_U(S.v[i]), pp = RC_U(S.v[i - 1]);
         if (q0 != 0 && (RC_U(S.qual[pi]) <= badq && RC_U(S.qual[pp]) <= badq)) continue;
-        if (pi - pp + 1 <= k) {
-            int min_single = RC_INF, min_double = RC_INF, taga = -1, tagb = -1;
-            const int pprev = i >= 2 ? RC_U(S.v[i - 2]) : -1;
-            const int pnext = i < cnt - 1 ? RC_U(S.v[i + 1]) : -1;
-            int j = pp - k + 1;
-            if (j < 0) j = 0;
-            for (; j < kcnt; ++j) {
-                if (i >= 2 && j <= pprev) continue;
-                if (i < cnt - 1 && j + k - 1 >= pnext) break;
-                if (j + k - 1 >= pi) break;
-                int cj = RC_U(S.counts[j]);
-                if (cj < min_single) {
-                    min_single = cj;
-                    taga = j;
-                }
+        if (pi - pp + 1 > k) continue;
+        int lo = pp - k + 1;                     // first k-mer that covers pp ...
+        if (lo < 0) lo = 0;
+        if (i >= 2) {                            // ... and starts after the previous fix
+            const int pprev = RC_U(S.v[i - 2]);
+            if (lo < pprev + 1) lo = pprev + 1;
+        }
+        int hi = kcnt;                           // k-mers must end before the next fix
+        if (i < cnt - 1) {
+            const int pnext = RC_U(S.v[i + 1]);
+            if (hi > pnext - k + 1) hi = pnext - k + 1;
+        }
+        uint32_t ms = 0xFFFFFFFFu, md = 0xFFFFFFFFu;
+        w.for_lanes64(pp - k + 1, hi, [&](int j, int) {
+            if (j < lo || j > pi) return;
+            const uint32_t c = (uint32_t)S.counts[j];
+            if (j + k - 1 >= pi && j <= pp)      // covers both fixes
+                md = c < md ? c : md;
+            else                                 // covers pp only (ends before pi) or pi only (starts after pp)
+                ms = c < ms ? c : ms;
+        });
+        ms = w.wave_min_u32(ms);
+        md = w.wave_min_u32(md);
+        if (ms == 0xFFFFFFFFu || md == 0xFFFFFFFFu) continue;
+        const int min_single = (int)ms, min_double = (int)md;
+        if (min_single > 1 && min_double > 1 && min_single > min_double / 2 && min_single < 2 * min_double) {
+            // drop both, and every fix chained to them by gaps of at most k
+            S.best[pi] = -1;
+            S.best[pp] = -1;
+            for (int jj = i - 2; jj >= 0 && RC_U(S.v[jj + 1]) - RC_U(S.v[jj]) + 1 <= k; --jj) S.best[RC_U(S.v[jj])] = -1;
+            while (i + 1 < cnt && RC_U(S.v[i + 1]) - RC_U(S.v[i]) + 1 <= k) {
+                S.best[RC_U(S.v[i + 1])] = -1;
+                ++i;
             }
-            for (; j < kcnt; ++j) {
-                if (i < cnt - 1 && j + k - 1 >= pnext) break;
-                if (j > pp) break;
-                int cj = RC_U(S.counts[j]);
-                if (cj < min_double) {
-                    min_double = cj;
-                    tagb = j;
-                }
-            }
-            for (; j < kcnt; ++j) {
-                if (i < cnt - 1 && j + k - 1 >= pnext) break;
-                if (j > pi) break;
-                int cj = RC_U(S.counts[j]);
-                if (cj < min_single) {
-                    min_single = cj;
-                    taga = j;
-                }
-            }
-            (void)taga;
-            (void)tagb;
-            if (min_single != RC_INF && min_double != RC_INF && min_single > 1 && min_double > 1 &&
-                min_single > min_double / 2 && min_single < 2 * min_double) {
-                S.best[pi] = -1;
-                S.best[pp] = -1;
-                int jj = i - 2;
-                while (jj >= 0 && S.v[jj + 1] - S.v[jj] + 1 <= k) {
-                    S.best[S.v[jj]] = -1;
-                    --jj;
-                }
-                while (i + 1 < cnt && S.v[i + 1] - S.v[i] + 1 <= k) {
-                    S.best[S.v[i + 1]] = -1;
-                    ++i;
-                }
-                w.sync();
-            }
+            w.sync();
         }
     }
 
@@ -1207,17 +1203,20 @@ RC_HD int rc_correct_read(W &w, rc_read_state &S, const rc_run_params &P, int pa
     }
 
     if (total_fix >= P.max_fix_per_k) {  // density veto, :1432-1466, weights x2
-        // prefix weights in v[0..len]
-        int acc = 0;
-        S.v[0] = 0;
-        for (int i = 0; i < len; ++i) {
-            if (S.base[i] != 4 && S.best[i] != -1) acc += ((int)S.qual[i] > badq) ? 2 : 1;
-            S.v[i + 1] = acc;
+        // a fix on a non-N base weighs 1, or 2 where the quality is good; a k-window heavier than
+        // 2 MAX_FIX_PER_K rejects the read.  Two bit masks (the letter masks m_a / m_t are no longer
+        // needed at this point and serve as scratch) turn the window sums into popcounts.
+        const int nw = (len + 63) >> 6;
+        for (int c = 0; c <= nw; ++c) {
+            const uint64_t f = w.ballot64(c << 6, len, [&](int q) { return S.base[q] != 4 && S.best[q] != -1; });
+            const uint64_t g = f & w.ballot64(c << 6, len, [&](int q) { return (int)S.qual[q] > badq; });
+            S.m_a[c] = f;
+            S.m_t[c] = g;
         }
         w.sync();
         int bad = 0;
         for (int i = w.lane; i < kcnt; i += W::STRIDE)
-            if (S.v[i + k] - S.v[i] > 2 * P.max_fix_per_k) bad = 1;
+            if (rc_popc64(rc_window(S.m_a, i, k)) + rc_popc64(rc_window(S.m_t, i, k)) > 2 * P.max_fix_per_k) bad = 1;
         if (w.reduce_add(bad)) return -1;
     }
 
