@@ -148,12 +148,18 @@ int rc_correct_batch(rc_ctx *ctx, rc_batch *b);
  * hold the results (and rc_summary() includes the batch).  Batches complete in submission order.
  * Buffers obtained from rc_host_alloc() are page-locked: the DMA engines read and write them
  * directly; any other buffer is staged through pinned memory the slot owns (one extra copy each
- * way).  rc_correct_batch(b) == rc_submit(b, 0); rc_wait(0).  One host thread per context. */
+ * way).  rc_correct_batch(b) == rc_submit(b, 0); rc_wait(0).  Calls on one context come from one
+ * thread at a time, with one exception: rc_wait(slot) only touches its slot and may run on another
+ * thread while the next rc_submit (a different slot) is issued -- how `rcorrector` keeps several
+ * worker threads busy on one context. */
 #define RC_MAX_SLOTS 4
 int rc_submit(rc_ctx *ctx, const rc_batch *b, int slot);
 int rc_wait(rc_ctx *ctx, int slot);
 int rc_host_alloc(rc_ctx *ctx, size_t bytes, void **out);
 int rc_host_free(rc_ctx *ctx, void *p);
+/* ... or page-lock memory the caller already owns (page-aligned, whole pages) */
+int rc_host_register(void *p, size_t bytes);
+int rc_host_unregister(void *p);
 
 /* rc_correct_batch plus everything the reference prints per read under -verbose (VERBOSE,
  * ErrorCorrection.cpp:15,686-689,759-770,856-857,1088-1094,1590-1597), as data; the caller formats

@@ -1051,6 +1051,19 @@ int rc_host_free(rc_ctx *ctx, void *p)
     return RC_OK;
 }
 
+// page-locks caller memory (any allocation, whole pages) so that rc_submit can DMA straight from / to it
+int rc_host_register(void *p, size_t bytes)
+{
+    if (!p || !bytes) return RC_ERR_ARG;
+    return hipHostRegister(p, bytes, hipHostRegisterPortable) == hipSuccess ? RC_OK : RC_ERR_HIP;
+}
+
+int rc_host_unregister(void *p)
+{
+    if (!p) return RC_ERR_ARG;
+    return hipHostUnregister(p) == hipSuccess ? RC_OK : RC_ERR_HIP;
+}
+
 static int slots_init(rc_ctx *ctx)
 {
     if (ctx->slots) return RC_OK;

@@ -10,11 +10,12 @@
 //
 // Host pipeline: one reader thread cuts the input into batches of whole records
 // (block reads, memchr line index, parallel packing into the SoA arenas of the C ABI), one worker
-// per GPU runs rc_correct_batch, one writer thread formats in parallel and writes in input order.
+// threads per GPU run rc_submit / rc_wait on page-locked arenas, one writer thread formats in parallel and writes in input order.
 //
 // Extra flags (not in the reference): -gpus N shards batches over N GPUs (table replicated),
-// -batch N sets the reads per batch, -inflight N the batches in flight per GPU (contexts sharing one
-// table; keeps the GPU busy while a batch's slowest reads finish).  -t sets the host threads used
+// -batch N sets the reads per batch, -inflight N the batches in flight per GPU (worker threads sharing
+// the GPU's context through rc_submit / rc_wait slots: upload, kernels and download of consecutive
+// batches overlap, and the GPU stays busy while a batch's slowest reads finish).  -t sets the host threads used
 // for packing / formatting.
 // -verbose prints the reference's per-read transcript (the -t 1 order) from rc_correct_batch_traced;
 // -write-dump FILE keeps the k-mer table as jellyfish-dump text; without -c the k-mers are counted here.
@@ -107,6 +108,40 @@ struct Buf {
             exit(1);
         }
         cap = nc;
+    }
+};
+
+// A batch arena the DMA engines read and write directly: ordinary heap memory, page-locked through
+// the library (rc_host_register) whenever it is (re)allocated.  Jobs are recycled through a pool,
+// so the registration is paid a handful of times per run.
+struct PinBuf {
+    char *p = nullptr;
+    size_t cap = 0;
+    bool pinned = false;
+    PinBuf() = default;
+    PinBuf(const PinBuf &) = delete;
+    PinBuf &operator=(const PinBuf &) = delete;
+    ~PinBuf()
+    {
+        if (pinned) rc_host_unregister(p);
+        free(p);
+    }
+    char *data() { return p; }
+    const char *data() const { return p; }
+    void need(size_t n)
+    {
+        if (n <= cap) return;
+        if (pinned) rc_host_unregister(p);
+        pinned = false;
+        free(p);  // (the old content is never needed: an arena is packed from scratch)
+        const size_t nc = std::max(n + (n >> 3) + (1u << 16), cap + cap / 2);
+        p = (char *)aligned_alloc(4096, (nc + 4095) & ~(size_t)4095);
+        if (!p) {
+            fprintf(stderr, "rcorrector: out of memory (%zu bytes)\n", nc);
+            exit(1);
+        }
+        cap = nc;
+        pinned = rc_host_register(p, (nc + 4095) & ~(size_t)4095) == 0;  // not pinned: the library stages the copy
     }
 };
 
@@ -442,7 +477,7 @@ static void gzip_member(const std::vector<char> &in, std::vector<char> &out)
 struct Arena {  // one file's share of a batch
     Block blk;
     int lpr = 4;  // lines per record
-    Buf seq, qual;
+    PinBuf seq, qual;
     std::vector<uint32_t> off;
     size_t n() const { return blk.records; }
     const char *line(size_t rec, int which, uint32_t *len) const
@@ -724,7 +759,7 @@ static void print_help()
             "MI355X build only:\n"
             "\t-gpus INT: number of GPUs to shard the reads over, k-mer table replicated (default: 1)\n"
             "\t-batch INT: reads per GPU batch (default: 1048576)\n"
-            "\t-inflight INT: batches in flight per GPU (default: 2)\n"
+            "\t-inflight INT: batches in flight per GPU, 1-4 (default: 2)\n"
             "\t-write-dump STRING: also write the k-mer table as a jellyfish-dump text file\n"
             "\t-verbose-iter INT: threshold iterations recorded per read for -verbose (default: 64)\n");
 }
@@ -833,15 +868,18 @@ int main(int argc, char **argv)
         }
     }
 
-    // contexts: `inflight` per GPU; the table is replicated across GPUs and shared within one
-    const int nctx = gpus * inflight;
+    // one context per GPU (the table is replicated across GPUs); `inflight` worker threads per GPU keep
+    // that many batches in flight in it through rc_submit / rc_wait, one slot each
+    if (inflight > RC_MAX_SLOTS) inflight = RC_MAX_SLOTS;
+    const int nctx = gpus, nworkers = gpus * inflight;
+    std::vector<std::mutex> submit_mu((size_t)gpus);  // rc_submit calls on one context are serialised
     std::vector<rc_ctx *> ctx((size_t)nctx, nullptr);
     char err[512];
     // RC_SHARED_GPU=1 (tests): every "GPU" is device 0, so that the -gpus N path -- one table replica
     // per GPU, batches dealt to whichever context is free -- runs on a one-GPU box
     const bool shared_gpu = getenv("RC_SHARED_GPU") != nullptr;
     for (int c = 0; c < nctx; ++c) {
-        rc_config cfg = {shared_gpu ? 0 : c % gpus, k, max_fix_per_k};
+        rc_config cfg = {shared_gpu ? 0 : c, k, max_fix_per_k};
         ctx[c] = rc_create(&cfg, err, sizeof err);
         if (!ctx[c]) die("rcorrector: %s\n", err);
     }
@@ -870,8 +908,6 @@ int main(int argc, char **argv)
         }
     }
     if (write_dump && rc_table_write_jfdump(ctx[0], write_dump, nullptr)) die("rcorrector: %s\n", rc_last_error(ctx[0]));
-    for (int c = gpus; c < nctx; ++c)
-        if (rc_table_share(ctx[c], ctx[c % gpus])) die("rcorrector: %s\n", rc_last_error(ctx[c]));
     fprintf(stderr, "Stored %d kmers\n", (int)stored);
     double rate = 0.01;
     if (rc_estimate_error_rate(ctx[0], wk, &rate)) die("rcorrector: %s\n", rc_last_error(ctx[0]));
@@ -932,7 +968,7 @@ int main(int argc, char **argv)
     std::vector<std::shared_ptr<Job>> pool;  // finished jobs: their buffers are reused (no fresh page faults)
     std::deque<std::shared_ptr<Job>> q;  // one queue for all workers: whichever context is free takes the next batch
     bool closing = false, reader_done = false;
-    const size_t max_in_flight = (size_t)(nctx + 2);
+    const size_t max_in_flight = (size_t)(nworkers + 2);
 
     // the output records of a finished batch, formatted (and deflated for .gz outputs) in slices by
     // the worker that ran it; the writer thread only writes
@@ -987,8 +1023,9 @@ int main(int argc, char **argv)
     };
 
     std::vector<std::thread> workers;
-    for (int g = 0; g < nctx; ++g) {
-        workers.emplace_back([&, g]() {
+    for (int wk = 0; wk < nworkers; ++wk) {
+        workers.emplace_back([&, wk]() {
+            const int g = wk % gpus, slot = wk / gpus;
             for (;;) {
                 std::shared_ptr<Job> j;
                 {
@@ -1042,9 +1079,15 @@ int main(int argc, char **argv)
                     tr.flags = j->tr_flags.data();
                     tr.n_iter = j->tr_niter.data();
                     tr.iter = j->tr_iter.data();
+                    std::lock_guard<std::mutex> lk(submit_mu[(size_t)g]);
                     rc = rc_correct_batch_traced(ctx[g], &rb, &tr);
                 } else {
-                    rc = rc_correct_batch(ctx[g], &rb);
+                    {   // upload + kernels + download are queued here; the wait below overlaps with the other
+                        // workers' packing, submitting and formatting
+                        std::lock_guard<std::mutex> lk(submit_mu[(size_t)g]);
+                        rc = rc_submit(ctx[g], &rb, slot);
+                    }
+                    if (!rc) rc = rc_wait(ctx[g], slot);
                 }
                 const double tf0 = now_s();
                 if (!rc) format_job(*j);
@@ -1203,7 +1246,7 @@ int main(int argc, char **argv)
                 t_setup - t_start, t_loop_end - t_setup, g_threads);
     if (g_timing)
         fprintf(stderr, "[rc timing] stage totals: read+index %.2f s (reader thread); pack %.2f s + correct_batch %.2f s + format %.2f s (sum over %d worker threads); write %.2f s (writer thread)\n",
-                g_t_read, g_t_pack, g_t_gpu, g_t_format, nctx, g_t_write);
+                g_t_read, g_t_pack, g_t_gpu, g_t_format, nworkers, g_t_write);
     if (g_timing)
         fprintf(stderr, "[rc timing] blocked: reader %.2f s (no free slot), workers %.2f s (no batch), writer %.2f s (next batch not done)\n", g_w_reader, g_w_worker, g_w_writer);
     fprintf(stderr, "Processed %llu reads\n\tCorrected %llu bases.\n", (unsigned long long)total_reads, (unsigned long long)total_cor);
