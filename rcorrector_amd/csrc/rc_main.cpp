@@ -758,6 +758,8 @@ static void print_help()
             "\t-verbose: output some correction information to stdout (default: not used)\n"
             "MI355X build only:\n"
             "\t-gpus INT: number of GPUs to shard the reads over, k-mer table replicated (default: 1)\n"
+            "\twithout -c the k-mers are counted here (exact counts >= 2); ERROR_RATE is then estimated over this program's own\n"
+            "\t\tdump order, not Jellyfish's: self-consistent, not byte-comparable with a jellyfish + reference run on large inputs\n"
             "\t-batch INT: reads per GPU batch (default: 1048576)\n"
             "\t-inflight INT: batches in flight per GPU, 1-4 (default: 2)\n"
             "\t-write-dump STRING: also write the k-mer table as a jellyfish-dump text file\n"
