@@ -116,6 +116,17 @@ char rc_bad_quality_from_hist(const int32_t first_hist[300], const int32_t last_
 /* sets ERROR_RATE and badQualityThreshold for subsequent corrections */
 int rc_set_run_params(rc_ctx *ctx, double error_rate, char bad_quality);
 
+/* Quality as one bit per base.  The correction only ever compares a quality with badQualityThreshold
+ * (the vetoes, ErrorCorrection.cpp:1313-1466) and tests qual[0] != 0, so a host that is bound by the
+ * upload can ship bits instead of bytes: with on != 0 every quality arena handed to this context
+ * (rc_batch.qual / qual2, rc_device_batch.d_qual) is a bit array over the arena, bit (p & 7) of byte
+ * p >> 3 = the quality character at arena byte p is greater than the threshold -- 19 instead of 151
+ * bytes per 150-base read over PCIe.  rc_pack_quality_bits() makes such an array from a byte arena
+ * (nbytes = the arena's size; bits has (nbytes + 7) / 8 bytes).  FASTQ input only (the FASTA marker
+ * qual[0] == 0 cannot be expressed); same results as with bytes. */
+int rc_set_quality_bits(rc_ctx *ctx, int on);
+void rc_pack_quality_bits(const char *qual, size_t nbytes, char bad_quality, uint8_t *bits);
+
 /* ---- correction (ErrorCorrection.h:12-28) ------------------------------------------------------ */
 /* Batch in host memory.  Replaces struct _ErrorCorrectionThreadArg + the pthread fan-out of
  * main.cpp:439-523 / the inline loop main.cpp:368-438: one call = one batch through

@@ -14,7 +14,7 @@ ABI_SYMBOLS = [
     "rc_table_build", "rc_table_build_device", "rc_table_load_jfdump",
     "rc_table_count_begin", "rc_table_count_add", "rc_table_count_add_device", "rc_table_count_finish",
     "rc_table_count_reads_device", "rc_table_write_jfdump", "rc_table_share", "rc_table_replicate", "rc_table_lookup", "rc_table_export", "rc_table_digest", "rc_table_layout", "rc_table_stats",
-    "rc_estimate_error_rate", "rc_bad_quality_from_hist", "rc_set_run_params",
+    "rc_estimate_error_rate", "rc_bad_quality_from_hist", "rc_set_run_params", "rc_set_quality_bits", "rc_pack_quality_bits",
     "rc_correct_batch", "rc_submit", "rc_wait", "rc_host_alloc", "rc_host_free", "rc_host_register", "rc_host_unregister", "rc_correct_batch_traced", "rc_correct_device", "rc_strong_threshold_device", "rc_probe_device", "rc_sync",
     "rc_profile_enable", "rc_profile_get", "rc_profile_reset", "rc_profile_correct_counters", "rc_selftest_get_bound", "rc_summary",
 ]
@@ -104,6 +104,9 @@ def load_library():
     L.rc_bad_quality_from_hist.restype = C.c_char
     L.rc_bad_quality_from_hist.argtypes = [vp, vp, C.c_int32]
     L.rc_set_run_params.argtypes = [vp, C.c_double, C.c_char]
+    L.rc_set_quality_bits.argtypes = [vp, C.c_int]
+    L.rc_pack_quality_bits.restype = None
+    L.rc_pack_quality_bits.argtypes = [vp, sz, C.c_char, vp]
     L.rc_correct_batch.argtypes = [vp, C.POINTER(_Batch)]
     L.rc_submit.argtypes = [vp, C.POINTER(_Batch), C.c_int]
     L.rc_wait.argtypes = [vp, C.c_int]
@@ -286,6 +289,20 @@ class Context:
         if isinstance(bad_quality, int):
             bad_quality = bytes([bad_quality & 0xFF])
         self._ck(self._L.rc_set_run_params(self._h, error_rate, bad_quality))
+
+    def set_quality_bits(self, on=True):
+        """Quality arenas handed to this context are bit arrays (rc_set_quality_bits)."""
+        self._ck(self._L.rc_set_quality_bits(self._h, 1 if on else 0))
+
+    def pack_quality_bits(self, qual, bad_quality, out=None):
+        """uint8 quality arena -> bit array (bit p = qual[p] > bad_quality), rc_pack_quality_bits."""
+        qual = self._arena(qual, "qual")
+        if isinstance(bad_quality, int):
+            bad_quality = bytes([bad_quality & 0xFF])
+        if out is None:
+            out = np.zeros((qual.size + 7) // 8, dtype=np.uint8)
+        self._L.rc_pack_quality_bits(qual.ctypes.data, qual.size, bad_quality, out.ctypes.data)
+        return out
 
     # ---- correction ----
     @staticmethod

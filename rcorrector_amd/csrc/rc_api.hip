@@ -806,6 +806,29 @@ int rc_set_run_params(rc_ctx *ctx, double error_rate, char bad_quality)
     return RC_OK;
 }
 
+int rc_set_quality_bits(rc_ctx *ctx, int on)
+{
+    if (!ctx) return RC_ERR_ARG;
+    ctx->qual_bits = on != 0;
+    return RC_OK;
+}
+
+void rc_pack_quality_bits(const char *qual, size_t nbytes, char bad_quality, uint8_t *bits)
+{
+    const signed char bq = (signed char)bad_quality;
+    size_t p = 0;
+    for (; p + 8 <= nbytes; p += 8) {
+        unsigned v = 0;
+        for (int j = 0; j < 8; ++j) v |= (unsigned)((signed char)qual[p + j] > bq) << j;
+        bits[p >> 3] = (uint8_t)v;
+    }
+    if (p < nbytes) {
+        unsigned v = 0;
+        for (int j = 0; p + j < nbytes; ++j) v |= (unsigned)((signed char)qual[p + j] > bq) << j;
+        bits[p >> 3] = (uint8_t)v;
+    }
+}
+
 // ---- correction ------------------------------------------------------------------------------
 int rc_probe_device(rc_ctx *ctx, const uint8_t *d_seq, uint64_t nbytes, int32_t *d_counts)
 {
@@ -814,7 +837,13 @@ int rc_probe_device(rc_ctx *ctx, const uint8_t *d_seq, uint64_t nbytes, int32_t 
     return rc_launch_probe(ctx, d_seq, (size_t)nbytes, d_counts);
 }
 
-int rc_correct_device(rc_ctx *ctx, const rc_device_batch *b)
+static int correct_device_impl(rc_ctx *ctx, const rc_device_batch *b, uint32_t qual_split, uint32_t qual_base2);
+
+int rc_correct_device(rc_ctx *ctx, const rc_device_batch *b) { return correct_device_impl(ctx, b, 0xFFFFFFFFu, 0); }
+
+// qual_split / qual_base2 (quality-bit mode only): arena bytes from qual_split on have their bits at
+// byte qual_base2 of d_qual -- the second arena of a paired host batch, whose bit array is separate
+static int correct_device_impl(rc_ctx *ctx, const rc_device_batch *b, uint32_t qual_split, uint32_t qual_base2)
 {
     if (!ctx || !b) return RC_ERR_ARG;
     if (b->n_reads == 0) return RC_OK;
@@ -836,6 +865,9 @@ int rc_correct_device(rc_ctx *ctx, const rc_device_batch *b)
     a.n = b->n_reads;
     a.seq = b->d_seq;
     a.qual = b->d_qual;
+    a.qual_bits = ctx->qual_bits ? 1 : 0;
+    a.qual_split = qual_split;
+    a.qual_base2 = qual_base2;
     a.off = b->d_off;
     a.ret = b->d_ret;
     a.l = b->d_l;
@@ -922,6 +954,10 @@ int rc_correct_batch_traced(rc_ctx *c, rc_batch *b, rc_trace *t)
     if (t->max_iter < 1 || !t->counts_before || !t->counts_after || !t->flags || !t->n_iter || !t->iter) {
         rc_set_error(c, "correct_batch_traced: bad trace descriptor");
         return RC_ERR_ARG;
+    }
+    if (c->qual_bits) {
+        rc_set_error(c, "correct_batch_traced: not available in quality-bit mode");
+        return RC_ERR_STATE;
     }
     c->trace_cap = t->max_iter;
     int rc = correct_batch_impl(c, b, t);
@@ -1121,8 +1157,13 @@ int rc_submit(rc_ctx *c, const rc_batch *b, int slot)
         for (size_t i = 0; i <= n1; ++i) off[n1 + i] = (uint32_t)sl.bytes1 + b->off2[i];
         for (size_t i = 0; i < n1; ++i) max_len = std::max(max_len, (int)(b->off2[i + 1] - b->off2[i]) - 1);
     }
+    // quality arenas: a byte per base, or (rc_set_quality_bits) a bit per arena byte, arena 2's bits in
+    // a region of their own
+    const bool qbits = ctx->qual_bits;
+    const size_t q1 = qbits ? (sl.bytes1 + 7) / 8 : sl.bytes1, q2 = qbits ? (sl.bytes2 + 7) / 8 : sl.bytes2;
+    const size_t qbase2 = qbits ? ((q1 + 15) & ~(size_t)15) : sl.bytes1;
     if ((rc = rc_dbuf_reserve(ctx, &sl.d_seq, nbytes + 64))) return rc;
-    if ((rc = rc_dbuf_reserve(ctx, &sl.d_qual, nbytes + 64))) return rc;
+    if ((rc = rc_dbuf_reserve(ctx, &sl.d_qual, qbase2 + q2 + 64))) return rc;
     if ((rc = rc_dbuf_reserve(ctx, &sl.d_off, (total + 1) * 4))) return rc;
     if ((rc = rc_dbuf_reserve(ctx, &sl.d_res, total * 16))) return rc;
     sl.seq_pinned = is_pinned(b->seq) && is_pinned(b->qual) && (b->mode != 1 || (is_pinned(b->seq2) && is_pinned(b->qual2)));
@@ -1130,17 +1171,17 @@ int rc_submit(rc_ctx *c, const rc_batch *b, int slot)
     const char *h_seq1 = b->seq, *h_qual1 = b->qual, *h_seq2 = b->seq2, *h_qual2 = b->qual2;
     if (!sl.seq_pinned) {  // pageable buffers: through the slot's pinned staging
         if ((rc = hbuf_reserve(ctx, &sl.p_seq, nbytes))) return rc;
-        if ((rc = hbuf_reserve(ctx, &sl.p_qual, nbytes))) return rc;
+        if ((rc = hbuf_reserve(ctx, &sl.p_qual, qbase2 + q2))) return rc;
         memcpy(sl.p_seq.p, b->seq, sl.bytes1);
-        memcpy(sl.p_qual.p, b->qual, sl.bytes1);
+        memcpy(sl.p_qual.p, b->qual, q1);
         if (b->mode == 1) {
             memcpy((char *)sl.p_seq.p + sl.bytes1, b->seq2, sl.bytes2);
-            memcpy((char *)sl.p_qual.p + sl.bytes1, b->qual2, sl.bytes2);
+            memcpy((char *)sl.p_qual.p + qbase2, b->qual2, q2);
         }
         h_seq1 = (const char *)sl.p_seq.p;
         h_qual1 = (const char *)sl.p_qual.p;
         h_seq2 = h_seq1 + sl.bytes1;
-        h_qual2 = h_qual1 + sl.bytes1;
+        h_qual2 = h_qual1 + qbase2;
     }
     if (!sl.res_pinned && (rc = hbuf_reserve(ctx, &sl.p_res, total * 16))) return rc;
     uint8_t *d_seq = (uint8_t *)sl.d_seq.p, *d_qual = (uint8_t *)sl.d_qual.p;
@@ -1148,10 +1189,10 @@ int rc_submit(rc_ctx *c, const rc_batch *b, int slot)
     // (the link, not a DMA engine, is the bound)
     hipStream_t sq = ctx->s_h2d;
     RC_CHECK_HIP(ctx, hipMemcpyAsync(d_seq, h_seq1, sl.bytes1, hipMemcpyHostToDevice, ctx->s_h2d));
-    RC_CHECK_HIP(ctx, hipMemcpyAsync(d_qual, h_qual1, sl.bytes1, hipMemcpyHostToDevice, sq));
+    RC_CHECK_HIP(ctx, hipMemcpyAsync(d_qual, h_qual1, q1, hipMemcpyHostToDevice, sq));
     if (b->mode == 1) {
         RC_CHECK_HIP(ctx, hipMemcpyAsync(d_seq + sl.bytes1, h_seq2, sl.bytes2, hipMemcpyHostToDevice, ctx->s_h2d));
-        RC_CHECK_HIP(ctx, hipMemcpyAsync(d_qual + sl.bytes1, h_qual2, sl.bytes2, hipMemcpyHostToDevice, sq));
+        RC_CHECK_HIP(ctx, hipMemcpyAsync(d_qual + qbase2, h_qual2, q2, hipMemcpyHostToDevice, sq));
     }
     RC_CHECK_HIP(ctx, hipMemcpyAsync(sl.d_off.p, off, (total + 1) * 4, hipMemcpyHostToDevice, ctx->s_h2d));
     RC_CHECK_HIP(ctx, hipEventRecord(sl.e_h2d, ctx->s_h2d));
@@ -1170,7 +1211,7 @@ int rc_submit(rc_ctx *c, const rc_batch *b, int slot)
     db.d_l = d_res + total;
     db.d_m = d_res + 2 * total;
     db.d_h = d_res + 3 * total;
-    if ((rc = rc_correct_device(ctx, &db))) return rc;
+    if ((rc = correct_device_impl(ctx, &db, qbits && b->mode == 1 ? (uint32_t)sl.bytes1 : 0xFFFFFFFFu, (uint32_t)qbase2))) return rc;
     RC_CHECK_HIP(ctx, hipEventRecord(sl.e_k, ctx->stream));
     // results
     RC_CHECK_HIP(ctx, hipStreamWaitEvent(ctx->s_d2h, sl.e_k, 0));

@@ -383,7 +383,9 @@ struct rc_kernel_args {
     int mode;
     uint32_t n;
     uint8_t *seq;
-    const uint8_t *qual;
+    const uint8_t *qual;   // one byte per arena byte, or (qual_bits) one BIT per arena byte: quality > badQualityThreshold
+    int qual_bits;
+    uint32_t qual_split, qual_base2;  // bit mode: arena bytes >= qual_split have their bits at byte qual_base2 on (second arena of a host batch)
     const uint32_t *off;
     const int32_t *counts;  // K1 output, indexed like seq
     int32_t *strong, *info;
@@ -410,7 +412,20 @@ __device__ __forceinline__ void rc_load_read(W &w, const rc_kernel_args &A, rc_r
     for (int i = lane; i < len; i += 64) {
         S.base[i] = (unsigned char)rc_base_code(A.seq[o + i]);
         S.counts[i] = i < S.kcnt ? A.counts[o + i] : 0;
-        if (with_qual) S.qual[i] = (signed char)A.qual[o + i];
+        if (with_qual) {
+            if (A.qual_bits) {
+                // the vetoes only compare a quality with badQualityThreshold (ErrorCorrection.cpp:1313-1466) and
+                // test qual[0] != 0 (FASTQ marker): a bit per base stands in for the byte
+                uint32_t p = o + (uint32_t)i;
+                const uint8_t *qb = A.qual;
+                if (p >= A.qual_split) {
+                    p -= A.qual_split;
+                    qb += A.qual_base2;
+                }
+                S.qual[i] = ((qb[p >> 3] >> (p & 7u)) & 1u) ? (signed char)127 : (signed char)-128;
+            } else
+                S.qual[i] = (signed char)A.qual[o + i];
+        }
     }
     w.sync();
     rc_build_masks(w, S);
@@ -698,6 +713,9 @@ static int fill_args(rc_ctx *ctx, const rc_device_batch_args &a, rc_kernel_args 
     A.n = a.n;
     A.seq = a.seq;
     A.qual = a.qual;
+    A.qual_bits = a.qual_bits;
+    A.qual_split = a.qual_split;
+    A.qual_base2 = a.qual_base2;
     A.off = a.off;
     A.counts = (const int32_t *)ctx->counts.p;
     A.strong = (int32_t *)ctx->strong.p;

@@ -70,6 +70,7 @@ struct rc_ctx {
 
     rc_run_params P;
     bool params_set = false;
+    bool qual_bits = false;  // quality arenas are bit arrays (rc_set_quality_bits)
 
     // k-mer table in HBM
     uint32_t *d_buckets = nullptr;
@@ -144,7 +145,9 @@ struct rc_device_batch_args {
     int mode;            // 0 single, 1 paired (reads [0,n/2) are mates of [n/2,n)), 2 interleaved
     uint32_t n;          // reads
     uint8_t *seq;        // arena, reads NUL-terminated
-    const uint8_t *qual; // same offsets
+    const uint8_t *qual; // same offsets (or one bit per arena byte, see rc_set_quality_bits)
+    int qual_bits = 0;
+    uint32_t qual_split = 0xFFFFFFFFu, qual_base2 = 0;
     const uint32_t *off; // n+1
     int32_t *ret, *l, *m, *h;
     int max_len;         // longest read in the batch (bases)

@@ -464,3 +464,36 @@ def test_table_packed_and_wide_layouts_hold_the_same_table(k, monkeypatch):
     ctx.table_build(codes, cnts2)
     assert ctx.table_layout() == 0 and ctx.lookup(can[len(can) // 2:len(can) // 2 + 1])[0] == 1 << 27
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["se_k23", "pe_var", "il_k23", "nrich"])
+def test_quality_bits_give_the_same_results_as_quality_bytes(gpu_ctx_factory, oracle, name):
+    """rc_set_quality_bits: the vetoes only compare qualities with badQualityThreshold, so a bit per base
+    (packed by rc_pack_quality_bits) must reproduce the oracle exactly as the byte arenas do -- here with
+    a threshold in the middle of the qualities the data sets use ('#' < 'H' < 'I'), ragged paired arenas
+    (the second arena's bits live in a region of their own) and both host entry points."""
+    d = datasets.make(name)
+    want = datasets.run_oracle(oracle, d)
+    ctx = _table(gpu_ctx_factory, d)
+    ctx.set_quality_bits(True)
+    a, off = oracle.pack_reads(d["seqs1"])
+    qa, _ = oracle.pack_reads(d["quals1"])
+    qb = ctx.pack_quality_bits(qa, b"H")
+    assert qb.size == (qa.size + 7) // 8 and np.array_equal(np.unpackbits(qb, bitorder="little")[:qa.size], (qa.view(np.int8) > ord("H")).astype(np.uint8))
+    if d["mode"] == 1:
+        a2, off2 = oracle.pack_reads(d["seqs2"])
+        qa2, _ = oracle.pack_reads(d["quals2"])
+        got = ctx.correct_batch(1, a, qb, off, a2, ctx.pack_quality_bits(qa2, b"H"), off2) + (a, a2)
+    else:
+        got = ctx.correct_batch(d["mode"], a, qb, off) + (a,)
+    for w, g, what in zip(want, got, ["ret", "l", "m", "h", "seq1", "seq2"]):
+        assert np.array_equal(w, g), "%s differs on %s in quality-bit mode" % (what, name)
+    ctx.set_quality_bits(False)
+    a, off = oracle.pack_reads(d["seqs1"])
+    if d["mode"] == 1:
+        a2, _ = oracle.pack_reads(d["seqs2"])
+        got = ctx.correct_batch(1, a, qa, off, a2, qa2, off2)
+    else:
+        got = ctx.correct_batch(d["mode"], a, qa, off)
+    assert np.array_equal(got[0], want[0])
