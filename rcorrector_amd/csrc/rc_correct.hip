@@ -21,7 +21,7 @@ struct DevWaveT {
     int lane;
     unsigned long long t_last = 0;
     int cur_phase = 0;
-    unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // 0-7 phases of a read, 8-15 inside the search
 #ifdef RC_EXP_ROUNDS  // dev builds: gather rounds per read, reported in place of l (tools/rounds_hist.py)
     int rounds = 0;
     __device__ __forceinline__ void stat(int i, int v)
@@ -666,6 +666,7 @@ __global__ __launch_bounds__(64, rc_k3_waves(CAP)) void k_correct(rc_kernel_args
     if (PROF && w.lane == 0) {
         w.phase(7);
         for (int i = 0; i < 8; ++i) atomicAdd(A.phase_cycles + i, w.acc[i]);
+        for (int i = 8; i < 16; ++i) atomicAdd(A.phase_cycles + 8 + i, w.acc[i]);  // slots 16..23
         atomicMax(A.phase_cycles + 10, (unsigned long long)wall_clock64());
 #ifndef RC_EXP_ROUNDS
         atomicAdd(A.phase_cycles + 11, (unsigned long long)w.rounds_sum);
@@ -795,7 +796,7 @@ int rc_launch_correct(rc_ctx *ctx, const rc_device_batch_args &a)
     A.stack = (rc_frame *)ctx->stack.p;
     // queue heads and phase counters to zero; the work-list length (written by the compaction) stays
     RC_CHECK_HIP(ctx, hipMemsetAsync(ctx->work.p, 0, RC_WORK_NWORK_OFF, ctx->stream));
-    RC_CHECK_HIP(ctx, hipMemsetAsync((char *)ctx->work.p + RC_WORK_PHASE_OFF, 0, 128, ctx->stream));
+    RC_CHECK_HIP(ctx, hipMemsetAsync((char *)ctx->work.p + RC_WORK_PHASE_OFF, 0, 192, ctx->stream));
     RC_CHECK_HIP(ctx, hipMemsetAsync((char *)ctx->work.p + RC_WORK_PHASE_OFF + 64, 0xff, 16, ctx->stream));  // the two minima
     A.phase_cycles = (unsigned long long *)((char *)ctx->work.p + RC_WORK_PHASE_OFF);
     if (ctx->cls_ready) {
@@ -821,7 +822,7 @@ int rc_launch_correct(rc_ctx *ctx, const rc_device_batch_args &a)
         hipLaunchKernelGGL((k_correct<1024, false, false>), dim3(grid), dim3(64), 0, ctx->stream, A);
     rc_timer_end(ctx, RC_T_CORRECT);
     if (ctx->phase_prof && A.cap_class == 192) {
-        unsigned long long pc[14];
+        unsigned long long pc[24];
         uint32_t nwork = a.n;
         RC_CHECK_HIP(ctx, hipMemcpyAsync(pc, A.phase_cycles, sizeof pc, hipMemcpyDeviceToHost, ctx->stream));
         if (A.n_work) RC_CHECK_HIP(ctx, hipMemcpyAsync(&nwork, A.n_work, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -839,6 +840,10 @@ int rc_launch_correct(rc_ctx *ctx, const rc_device_batch_args &a)
         fprintf(stderr, "\n[rc phase prof] work list %u of %u reads; queue empty at %.2f ms, last wave done at %.2f ms; gather rounds: %.2f per listed read, worst read %llu\n",
                 nwork, a.n, (double)(pc[9] - pc[8]) / 1e5, (double)(pc[10] - pc[8]) / 1e5, (double)pc[11] / (nwork ? nwork : 1), pc[12]);
         fprintf(stderr, "[rc phase prof] bucket reads: %.1f per listed read\n", (double)pc[13] / (nwork ? nwork : 1));
+        static const char *sn[8] = {"node entry+pop", "refill (gather round)", "keep-run", "single node", "gap windows", "jump", "terminal", "-"};
+        fprintf(stderr, "[rc phase prof] inside the search, cycles/read:");
+        for (int i = 0; i < 7; ++i) fprintf(stderr, " %s=%.0f", sn[i], (double)pc[16 + i] / a.n);
+        fprintf(stderr, "\n");
         }
     }
     RC_CHECK_HIP(ctx, hipGetLastError());

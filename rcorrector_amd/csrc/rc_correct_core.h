@@ -614,6 +614,7 @@ RC_HD void rc_search(W &w, rc_read_state &S, const rc_run_params &P, rc_search_c
     Z.dir = dir;
 
     for (;;) {
+        w.phase(8);
         if (!have) {
             if (sp == 0) break;
             rc_frame f;
@@ -657,18 +658,22 @@ RC_HD void rc_search(W &w, rc_read_state &S, const rc_run_params &P, rc_search_c
             continue;
         }
         if (dir > 0 ? (pos >= C.to) : (pos < C.to)) {
+            w.phase(14);
             rc_search_terminal(w, S, C, pos, t, fix_cnt, bottleneck);
             have = false;
             continue;
         }
 
         rc_cnt4 cnt;
+        w.phase(9);
         const int j0 = rc_probe4_cached(w, S, Z, kc, dir, pos, C.to, k, cnt);
+        w.phase(10);
         // descend along "keep the base" for as many cached nodes as take that branch
         if (rc_keep_run(w, S, P, Z, j0, dir, kc, pos, t, fix_cnt, bottleneck, sp) > 0) {
             have = true;
             continue;
         }
+        w.phase(11);
         int threshold = RC_U(rc_pos_threshold(cnt, t, P.error_rate));  // :287 / :525
         const int b = RC_U(S.base[pos]);
         const bool bvalid = b < 4;
@@ -696,6 +701,7 @@ RC_HD void rc_search(W &w, rc_read_state &S, const rc_run_params &P, rc_search_c
                 // k probes (the k-th probe's answer is never used) or at the segment end.  All
                 // candidate windows are probed in one gather round; the first hit is the one the
                 // sequential loop would have stopped at.
+                w.phase(12);
                 rc_kmer tmp = rc_extend(kc, k, dir, b);
                 int m = dir > 0 ? (C.to - 1 - pos) : (pos - C.to);  // positions left in range
                 if (m > k - 1) m = k - 1;
@@ -772,6 +778,7 @@ RC_HD void rc_search(W &w, rc_read_state &S, const rc_run_params &P, rc_search_c
             }
         } else {
             // jump over an unfixable stretch, :393-441 / :629-677
+            w.phase(13);
             rc_kmer tmp = kc;
             int i, c1 = 0;
             int thr = threshold;
@@ -1064,6 +1071,7 @@ RC_HD int rc_correct_read(W &w, rc_read_state &S, const rc_run_params &P, int pa
                     C.to = sf - extend;
                 }
                 rc_search(w, S, P, C, rc_anchor(w, S, k, a), trust);  // one body for both directions
+                w.phase(3);
                 S.seg[si].top2[0] = C.top2a;
                 S.seg[si].top2[1] = C.top2b;
                 w.sync();

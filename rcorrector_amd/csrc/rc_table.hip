@@ -146,7 +146,7 @@ static int build_attempt(rc_ctx *ctx, const uint64_t *d_canon, const int32_t *d_
     ctx->layout = layout;
     ctx->nb_alloc = (uint32_t)nb_alloc;
     ctx->table_bytes = (size_t)nb_alloc * RC_BUCKET_BYTES;
-    RC_CHECK_HIP(ctx, hipMalloc((void **)&ctx->d_buckets, ctx->table_bytes));
+    RC_CHECK_HIP(ctx, hipMalloc((void **)&ctx->d_buckets, ctx->table_bytes));  // (hipDeviceMallocContiguous: no effect on the TLB cliff, measured)
     if (layout)
         RC_CHECK_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)ctx->d_buckets, (int)RC_PACKED_EMPTY_WORD, ctx->table_bytes / 4, ctx->stream));
     else
