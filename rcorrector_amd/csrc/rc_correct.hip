@@ -242,21 +242,53 @@ struct DevWaveT {
         }
     }
 
+    // Search stack.  The first lstack_n frames live in LDS -- in the sort buffer v[], which nothing
+    // touches while a search runs -- so that a push or a pop is a handful of LDS operations; deeper
+    // frames (rare) go to the wave's HBM scratch, where every push has to wait for its store.
+    uint32_t *lstack = nullptr;
+    int lstack_n = 0;
+    static constexpr int FRAME_DWORDS = (int)(sizeof(rc_frame) / 4);
     __device__ __forceinline__ void stack_push(int sp, const rc_frame &f)
     {
+        if (sp < lstack_n) {
+            if (lane == 0) {
+                uint32_t *d = lstack + sp * FRAME_DWORDS;
+                d[0] = (uint32_t)f.code;
+                d[1] = (uint32_t)(f.code >> 32);
+                d[2] = (uint32_t)f.inv;
+                d[3] = (uint32_t)f.pos;
+                d[4] = (uint32_t)f.t;
+                d[5] = (uint32_t)f.threshold;
+                d[6] = (uint32_t)f.fix_cnt;
+                d[7] = (uint32_t)f.bottleneck;
+                d[8] = (uint32_t)f.cnt.c0;
+                d[9] = (uint32_t)f.cnt.c1;
+                d[10] = (uint32_t)f.cnt.c2;
+                d[11] = (uint32_t)f.cnt.c3;
+                d[12] = (uint32_t)f.mask;
+            }
+            sync();
+            return;
+        }
         if (lane == 0) stack[sp] = f;
         __threadfence_block();
     }
     __device__ __forceinline__ void stack_top(int idx, rc_frame &f)
     {
-        // all loads go out before the first value is used (one round trip, not thirteen).  The frame
-        // was written by lane 0 of this very wave: workgroup-scope loads (served by the XCD's L2,
-        // past the CU's L1) see it -- system-scope (volatile) loads went all the way to memory
-        const uint32_t *p = reinterpret_cast<const uint32_t *>(stack + idx);
-        uint32_t d[13];
-#pragma unroll
-        for (int q = 0; q < 13; ++q) d[q] = __hip_atomic_load(p + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         static_assert(sizeof(rc_frame) == 56 && offsetof(rc_frame, mask) == 48, "rc_frame layout");
+        uint32_t d[13];
+        if (idx < lstack_n) {
+            const uint32_t *p = lstack + idx * FRAME_DWORDS;
+#pragma unroll
+            for (int q = 0; q < 13; ++q) d[q] = p[q];
+        } else {
+            // all loads go out before the first value is used (one round trip, not thirteen).  The frame
+            // was written by lane 0 of this very wave: workgroup-scope loads (served by the XCD's L2,
+            // past the CU's L1) see it -- system-scope (volatile) loads went all the way to memory
+            const uint32_t *p = reinterpret_cast<const uint32_t *>(stack + idx);
+#pragma unroll
+            for (int q = 0; q < 13; ++q) d[q] = __hip_atomic_load(p + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
         f.code = ((uint64_t)(uint32_t)uni((int)d[1]) << 32) | (uint32_t)uni((int)d[0]);
         f.inv = uni((int)d[2]);
         f.pos = uni((int)d[3]);
@@ -272,6 +304,11 @@ struct DevWaveT {
     }
     __device__ __forceinline__ void stack_set_mask(int idx, int mask)
     {
+        if (idx < lstack_n) {
+            if (lane == 0) lstack[idx * FRAME_DWORDS + 12] = (uint32_t)mask;
+            sync();
+            return;
+        }
         if (lane == 0) stack[idx].mask = mask;
         __threadfence_block();
     }
@@ -547,6 +584,8 @@ __global__ __launch_bounds__(64, rc_k3_waves(CAP)) void k_correct(rc_kernel_args
     w.T = A.T;
     w.k = A.P.k;
     w.stack = A.stack + (size_t)blockIdx.x * A.stack_frames;
+    w.lstack = reinterpret_cast<uint32_t *>(S.v);
+    w.lstack_n = (int)((size_t)L.cap2 * 4 / sizeof(rc_frame));
     if (PROF && w.lane == 0) atomicMin(A.phase_cycles + 8, (unsigned long long)wall_clock64());
     // Work distribution.  The reference hands out read indices from one mutex-protected counter
     // (ErrorCorrection.cpp:87-90); one device-scope atomic word sustains only ~88 dequeues/us on
