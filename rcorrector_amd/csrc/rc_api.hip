@@ -141,6 +141,7 @@ rc_ctx *rc_create(const rc_config *cfg, char *errbuf, size_t errbuf_len)
     ctx->env_k2_wave_per_read = getenv("RC_K2_WAVE_PER_READ") != nullptr;  // dev: force the wave-per-read threshold kernel
     ctx->env_no_classify = getenv("RC_NO_CLASSIFY") != nullptr;            // dev: every read goes through k_correct
     ctx->env_timing = getenv("RC_TIMING") != nullptr;
+    if (const char *e = getenv("RC_LOCALITY")) ctx->locality_mode = !strcmp(e, "force") ? 1 : (!strcmp(e, "off") ? -1 : 0);  // tests / A-B
     if (const char *e = getenv("RC_K3_GRID_WAVES")) ctx->env_k3_grid_waves = atoi(e);
     return ctx;
 }
@@ -152,7 +153,8 @@ void rc_destroy(rc_ctx *c)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     rc_dbuf *bufs[] = {&ctx->counts, &ctx->strong, &ctx->info, &ctx->stack, &ctx->work,
-                       &ctx->h_seq, &ctx->h_qual, &ctx->h_off, &ctx->h_res, &ctx->trace, &ctx->cls, &ctx->worklist, &ctx->sel_tmp};
+                       &ctx->h_seq, &ctx->h_qual, &ctx->h_off, &ctx->h_res, &ctx->trace, &ctx->cls, &ctx->worklist, &ctx->sel_tmp,
+                       &ctx->loc_a, &ctx->loc_list};
     for (rc_dbuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (ctx->slots) {
@@ -874,7 +876,14 @@ static int correct_device_impl(rc_ctx *ctx, const rc_device_batch *b, uint32_t q
     a.m = b->d_m;
     a.h = b->d_h;
     a.max_len = b->max_read_len;
-    if ((rc = rc_launch_probe(ctx, b->d_seq, (size_t)b->nbytes, (int32_t *)ctx->counts.p))) return rc;
+    // large batches over a table that does not fit the caches are probed in min-hash order (rc_table.hip),
+    // so that overlapping reads meet in the L2 / Infinity Cache
+    if (ctx->locality_mode >= 0 && (ctx->locality_mode > 0 || (a.n >= (1u << 18) && ctx->table_bytes > ((size_t)128 << 20))) &&
+        a.max_len + 8 <= 4000) {
+        if ((rc = rc_launch_locality_order(ctx, a, (size_t)b->nbytes))) return rc;
+        if ((rc = rc_launch_probe_list(ctx, a, (size_t)b->nbytes, (int32_t *)ctx->counts.p))) return rc;
+    } else if ((rc = rc_launch_probe(ctx, b->d_seq, (size_t)b->nbytes, (int32_t *)ctx->counts.p)))
+        return rc;
     // thresholds: mates need each other's before either can be corrected, so paired / interleaved
     // batches always run the threshold kernel first; single-end batches do too when every read fits
     // the four-reads-per-wave kernel (cheaper there than inside k_correct), else k_correct computes them

@@ -102,6 +102,8 @@ struct rc_ctx {
     rc_dbuf cls;      // uint8 per read: 1 = still needs k_correct (written by the threshold kernel)
     rc_dbuf worklist; // uint32 per read: the reads with cls == 1, ascending
     rc_dbuf sel_tmp;  // rocPRIM scratch of the compaction
+    rc_dbuf loc_a, loc_list;  // locality order of a batch (rc_launch_locality_order)
+    int locality_mode = 0;  // 0: large batches over large tables, 1: always (RC_LOCALITY=force), -1: never (RC_LOCALITY=off)
     bool cls_ready = false;  // cls / worklist describe this batch
     // getenv() results, read once at rc_create
     bool env_k2_wave_per_read = false, env_no_classify = false, env_timing = false;
@@ -138,6 +140,8 @@ int rc_launch_export(rc_ctx *ctx, uint64_t *d_codes, int32_t *d_counts, unsigned
 int rc_table_entries_in_dump_order(rc_ctx *ctx, std::vector<uint64_t> *codes, std::vector<int32_t> *counts);
 int rc_launch_last_base_variants(rc_ctx *ctx, const uint64_t *d_codes, size_t n, int32_t *d_max2);
 int rc_launch_digest(rc_ctx *ctx, unsigned long long *d_out);
+int rc_launch_locality_order(rc_ctx *ctx, const struct rc_device_batch_args &a, size_t nbytes);
+int rc_launch_probe_list(rc_ctx *ctx, const struct rc_device_batch_args &a, size_t nbytes, int32_t *d_counts);
 int rc_launch_compact(rc_ctx *ctx, const uint8_t *d_flags, uint32_t n, uint32_t *d_list, uint32_t *d_count);
 
 // rc_correct.hip

@@ -389,6 +389,101 @@ int rc_launch_compact(rc_ctx *ctx, const uint8_t *d_flags, uint32_t n, uint32_t 
     return RC_OK;
 }
 
+// ---- locality order of a batch -------------------------------------------------------------------
+// Reads arrive in sequencer order, i.e. random with respect to the transcripts they come from, so the
+// ~130 probes of a read hit ~130 unrelated buckets and nearly every one of them is an HBM access.
+// Reads that overlap share most of their k-mers: probed next to each other, they meet in the L2 /
+// Infinity Cache instead.  Large batches are therefore PROBED in "min-hash order": key of a unit (a
+// read, or a pair through its first mate) = the smallest hash over its canonical k-mers, so units that
+// contain the same k-mer as their minimum -- overlapping reads -- become neighbours in the list
+// k_probe_list walks.  Nothing is moved: counts land at the reads' own positions, and the threshold
+// and correction kernels run as ever.
+#define RC_KEY_TILE 40960  // bytes of reads staged per 256-thread workgroup of k_unit_key
+__global__ __launch_bounds__(256) void k_unit_key(const uint8_t *__restrict__ seq, size_t nbytes, const uint32_t *__restrict__ off,
+                                                  uint32_t n_units, int mode, int k, uint32_t units_per_block,
+                                                  uint32_t *__restrict__ keys, uint32_t *__restrict__ idx)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_raw[RC_KEY_TILE + 48];
+    const uint32_t u0 = blockIdx.x * units_per_block;
+    if (u0 >= n_units) return;
+    const uint32_t nu = n_units - u0 < units_per_block ? n_units - u0 : units_per_block;
+    const uint32_t r0 = mode == 2 ? 2u * u0 : u0, r1 = mode == 2 ? 2u * (u0 + nu) : u0 + nu;
+    const size_t b0 = off[r0], b1 = off[r1], a0 = b0 & ~(size_t)15;
+    // the tile's bytes, coalesced (a thread-per-read walk over global memory touches a line per lane per load)
+    for (size_t c = threadIdx.x; a0 + 16 * c < b1; c += 256) {
+        const size_t g = a0 + 16 * c;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (g + 16 <= nbytes) {
+            v = *reinterpret_cast<const uint4 *>(seq + g);
+        } else {
+            uint32_t w[4] = {0, 0, 0, 0};
+            for (size_t q = 0; g + q < nbytes; ++q) w[q >> 2] |= (uint32_t)seq[g + q] << (8 * (q & 3));
+            v = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        *reinterpret_cast<uint4 *>(s_raw + 16 * c) = v;
+    }
+    __syncthreads();
+    if (threadIdx.x >= nu) return;
+    const uint32_t u = u0 + threadIdx.x;
+    const uint32_t r = mode == 2 ? 2u * u : u;  // the unit's first mate
+    const uint32_t o = (uint32_t)(off[r] - a0);
+    const int len = (int)(off[r + 1] - off[r]) - 1;
+    const uint64_t mask = rc_kmer_mask(k);
+    uint64_t fw = 0, rv = 0;
+    uint32_t best = 0xFFFFFFFFu;
+    int valid = 0;
+    for (int i = 0; i < len; ++i) {
+        const uint32_t c = s_raw[o + i];
+        int b = -1;
+        b = c == 'A' ? 0 : b;
+        b = c == 'C' ? 1 : b;
+        b = c == 'G' ? 2 : b;
+        b = c == 'T' ? 3 : b;
+        valid = b < 0 ? 0 : valid + 1;
+        fw = ((fw << 2) | (uint64_t)(b & 3)) & mask;
+        rv = (rv >> 2) | ((uint64_t)(3 - (b & 3)) << (2 * (k - 1)));
+        if (valid >= k) {
+            const uint32_t h = rc_hash(fw < rv ? fw : rv);
+            best = h < best ? h : best;
+        }
+    }
+    keys[u] = best;
+    idx[u] = u;
+}
+
+// list[i] = the reads in the order k_probe_list takes them: sorted units, the mates of a pair together
+__global__ void k_probe_order(const uint32_t *__restrict__ unit_sorted, uint32_t n, int mode, uint32_t *__restrict__ list)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (mode == 1)
+        list[i] = unit_sorted[i >> 1] + ((i & 1u) ? (n >> 1) : 0u);
+    else if (mode == 2)
+        list[i] = 2u * unit_sorted[i >> 1] + (i & 1u);
+    else
+        list[i] = unit_sorted[i];
+}
+
+int rc_launch_locality_order(rc_ctx *ctx, const rc_device_batch_args &a, size_t nbytes)
+{
+    const uint32_t n = a.n, n_units = a.mode ? n >> 1 : n;
+    int rc;
+    if ((rc = rc_dbuf_reserve(ctx, &ctx->loc_a, (size_t)n_units * 16 + 256))) return rc;  // keys, keys', idx, idx'
+    if ((rc = rc_dbuf_reserve(ctx, &ctx->loc_list, (size_t)n * 4 + 256))) return rc;
+    uint32_t *keys = (uint32_t *)ctx->loc_a.p, *keys2 = keys + n_units, *idx = keys2 + n_units, *idx2 = idx + n_units;
+    uint32_t upb = (uint32_t)(RC_KEY_TILE / ((size_t)(a.max_len + 1) * (a.mode == 2 ? 2 : 1)));
+    if (upb > 256) upb = 256;
+    if (upb < 1) upb = 1;
+    hipLaunchKernelGGL(k_unit_key, dim3((n_units + upb - 1) / upb), dim3(256), 0, ctx->stream, a.seq, nbytes, a.off, n_units, a.mode, ctx->k, upb, keys, idx);
+    size_t t1 = 0;
+    RC_CHECK_HIP(ctx, rocprim::radix_sort_pairs(nullptr, t1, keys, keys2, idx, idx2, (size_t)n_units, 0, 32, ctx->stream));
+    if ((rc = rc_dbuf_reserve(ctx, &ctx->sel_tmp, t1))) return rc;
+    RC_CHECK_HIP(ctx, rocprim::radix_sort_pairs(ctx->sel_tmp.p, t1, keys, keys2, idx, idx2, (size_t)n_units, 0, 32, ctx->stream));
+    hipLaunchKernelGGL(k_probe_order, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, idx2, n, a.mode, (uint32_t *)ctx->loc_list.p);
+    RC_CHECK_HIP(ctx, hipGetLastError());
+    return RC_OK;
+}
+
 // ---- K1: probe kernel ----------------------------------------------------------------------
 // counts[a] = GetCount(k-mer starting at arena byte a) for every a whose k-window lies inside one
 // read (reads are NUL-terminated inside the arena, so "inside one read" == "no NUL in the
@@ -470,6 +565,112 @@ __global__ __launch_bounds__(RC_PROBE_THREADS) void k_probe(rc_table_view T, con
         }
         __builtin_nontemporal_store(cnt, &counts[g]);  // streamed once: keep it out of the caches the table lives in
     }
+}
+
+// K1 over a list of reads (locality order): the workgroup's reads are copied into a local arena in
+// LDS -- each at the byte alignment it has in memory, NULs in between -- packed and probed as in
+// k_probe; a count goes to the position of its k-mer in the caller's arena.
+#define RC_PLIST_MAX_READS 64
+__global__ __launch_bounds__(RC_PROBE_THREADS) void k_probe_list(rc_table_view T, const uint8_t *__restrict__ seq, size_t nbytes,
+                                                                 const uint32_t *__restrict__ off, const uint32_t *__restrict__ list,
+                                                                 uint32_t n, uint32_t reads_per_block, int k, int32_t *__restrict__ counts)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t s_raw[(RC_PROBE_TILE + 64) / 4];
+    __shared__ uint32_t s_code[RC_PROBE_TILE / 16 + 4];
+    __shared__ uint16_t s_inv[RC_PROBE_TILE / 16 + 4];
+    __shared__ uint16_t s_nul[RC_PROBE_TILE / 16 + 4];
+    __shared__ uint32_t s_lpos[RC_PLIST_MAX_READS + 1], s_gpos[RC_PLIST_MAX_READS], s_len1[RC_PLIST_MAX_READS];
+    const int t = threadIdx.x;
+    const uint32_t i0 = blockIdx.x * reads_per_block;
+    const uint32_t nr = n - i0 < reads_per_block ? n - i0 : reads_per_block;
+    for (int c = t; c < (RC_PROBE_TILE + 64) / 4; c += RC_PROBE_THREADS) s_raw[c] = 0;
+    if ((uint32_t)t < nr) {
+        const uint32_t r = list[i0 + t], g0 = off[r];
+        s_gpos[t] = g0;
+        s_len1[t] = off[r + 1] - g0;  // bases + the NUL
+    }
+    __syncthreads();
+    if (t == 0) {  // local start of each read: same alignment modulo 4 as in memory, a NUL in front
+        uint32_t lp = 4;
+        for (uint32_t j = 0; j < nr; ++j) {
+            lp = ((lp + 3u) & ~3u) + (s_gpos[j] & 3u);
+            s_lpos[j] = lp;
+            lp += s_len1[j];
+        }
+        s_lpos[nr] = lp;
+    }
+    __syncthreads();
+    // copy: one 64-lane group per read, aligned dwords, bytes outside the read masked to NUL
+    for (uint32_t j = (uint32_t)t >> 6; j < nr; j += RC_PROBE_THREADS / 64) {
+        const uint32_t g0 = s_gpos[j], lp = s_lpos[j], g1 = g0 + s_len1[j] - 1;  // [g0, g1): the bases
+        const uint32_t w0 = g0 >> 2, w1 = (g1 + 3) >> 2;
+        for (uint32_t w = w0 + ((uint32_t)t & 63u); w < w1; w += 64u) {
+            uint32_t v;
+            if ((size_t)4 * w + 4 <= nbytes) {
+                v = *reinterpret_cast<const uint32_t *>(seq + (size_t)4 * w);
+            } else {
+                v = 0;
+                for (size_t q = 0; (size_t)4 * w + q < nbytes; ++q) v |= (uint32_t)seq[(size_t)4 * w + q] << (8 * q);
+            }
+            const uint32_t lo = 4 * w < g0 ? g0 - 4 * w : 0, hi = 4 * w + 4 > g1 ? 4 * w + 4 - g1 : 0;  // bytes to drop at either end
+            uint32_t m = 0xFFFFFFFFu;
+            if (lo) m &= 0xFFFFFFFFu << (8 * lo);
+            if (hi) m &= 0xFFFFFFFFu >> (8 * hi);
+            s_raw[(lp >> 2) + (w - w0)] = v & m;
+        }
+    }
+    __syncthreads();
+    const uint32_t total = s_lpos[nr];
+    for (int chunk = t; chunk < RC_PROBE_TILE / 16 + 2; chunk += RC_PROBE_THREADS) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(s_raw + 4 * chunk);
+        uint32_t code, inv, nul;
+        rc_pack16(v, code, inv, nul);
+        s_code[chunk] = code;
+        s_inv[chunk ^ 1] = (uint16_t)inv;
+        s_nul[chunk ^ 1] = (uint16_t)nul;
+    }
+    if (t < 2) s_code[RC_PROBE_TILE / 16 + 2 + t] = 0xFFFFFFFFu;
+    __syncthreads();
+    const uint32_t *m_inv = reinterpret_cast<const uint32_t *>(s_inv);
+    const uint32_t *m_nul = reinterpret_cast<const uint32_t *>(s_nul);
+#pragma unroll 2
+    for (uint32_t a = 4 + (uint32_t)t; a + (uint32_t)k <= total; a += RC_PROBE_THREADS) {
+        const int mw = a >> 5, ms = a & 31;
+        const uint64_t nulw = (((uint64_t)m_nul[mw] << 32) | m_nul[mw + 1]) << ms;
+        if (nulw >> (64 - k)) continue;  // window crosses a read boundary (or padding)
+        const uint64_t invw = (((uint64_t)m_inv[mw] << 32) | m_inv[mw + 1]) << ms;
+        int cnt = 0;
+        if (!(invw >> (64 - k))) {
+            const int cw = a >> 4, cs = 2 * (a & 15);
+            uint64_t x = ((uint64_t)s_code[cw] << 32) | s_code[cw + 1];
+            if (cs) x = (x << cs) | ((uint64_t)s_code[cw + 2] >> (32 - cs));
+            cnt = rc_table_lookup(T, rc_canonical(x >> (64 - 2 * k), k));
+        }
+        // the read this position belongs to: last j with lpos[j] <= a
+        uint32_t lo = 0, hi = nr;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (s_lpos[mid] <= a)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        __builtin_nontemporal_store(cnt, &counts[s_gpos[lo] + (a - s_lpos[lo])]);
+    }
+}
+
+int rc_launch_probe_list(rc_ctx *ctx, const rc_device_batch_args &a, size_t nbytes, int32_t *d_counts)
+{
+    if (a.n == 0) return RC_OK;
+    uint32_t rpb = (uint32_t)((RC_PROBE_TILE - 8) / (a.max_len + 8));  // a read takes its bases, the NUL and up to 6 bytes of alignment
+    if (rpb > RC_PLIST_MAX_READS) rpb = RC_PLIST_MAX_READS;
+    if (rpb < 1) rpb = 1;
+    rc_timer_begin(ctx);
+    hipLaunchKernelGGL(k_probe_list, dim3((a.n + rpb - 1) / rpb), dim3(RC_PROBE_THREADS), 0, ctx->stream, rc_view(ctx), a.seq, nbytes, a.off,
+                       (const uint32_t *)ctx->loc_list.p, a.n, rpb, ctx->k, d_counts);
+    rc_timer_end(ctx, RC_T_PROBE);
+    RC_CHECK_HIP(ctx, hipGetLastError());
+    return RC_OK;
 }
 
 int rc_launch_probe(rc_ctx *ctx, const uint8_t *d_seq, size_t nbytes, int32_t *d_counts)

@@ -497,3 +497,28 @@ def test_quality_bits_give_the_same_results_as_quality_bytes(gpu_ctx_factory, or
     else:
         got = ctx.correct_batch(d["mode"], a, qa, off)
     assert np.array_equal(got[0], want[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["se_k23", "pe_k23", "il_k23", "pe_var", "varlen", "edge", "k31_mc8", "long600_k31"])
+def test_locality_order_does_not_change_results(oracle, name, monkeypatch):
+    """Large batches are processed in min-hash order (overlapping reads next to each other, rc_table.hip):
+    a pure reordering -- forced here on the small parity sets, ragged, paired and interleaved ones included,
+    it must leave every result and every corrected base where the caller's order has them."""
+    d = datasets.make(name)
+    want = datasets.run_oracle(oracle, d)
+    monkeypatch.setenv("RC_LOCALITY", "force")
+    ctx = rcorrector_amd.Context(k=d["k"], max_fix_per_k=d["mfk"], device=0)
+    ctx.table_build(d["keys"], d["counts"])
+    ctx.set_run_params(d["rate"], b"H")
+    a, off = oracle.pack_reads(d["seqs1"])
+    qa, _ = oracle.pack_reads(d["quals1"])
+    if d["mode"] == 1:
+        a2, off2 = oracle.pack_reads(d["seqs2"])
+        qa2, _ = oracle.pack_reads(d["quals2"])
+        got = ctx.correct_batch(1, a, qa, off, a2, qa2, off2) + (a, a2)
+    else:
+        got = ctx.correct_batch(d["mode"], a, qa, off) + (a,)
+    for w, g, what in zip(want, got, ["ret", "l", "m", "h", "seq1", "seq2"]):
+        assert np.array_equal(w, g), "%s differs on %s in locality order" % (what, name)
+    ctx.close()
