@@ -141,6 +141,7 @@ rc_ctx *rc_create(const rc_config *cfg, char *errbuf, size_t errbuf_len)
     ctx->env_k2_wave_per_read = getenv("RC_K2_WAVE_PER_READ") != nullptr;  // dev: force the wave-per-read threshold kernel
     ctx->env_no_classify = getenv("RC_NO_CLASSIFY") != nullptr;            // dev: every read goes through k_correct
     ctx->env_timing = getenv("RC_TIMING") != nullptr;
+    ctx->env_no_fuse = getenv("RC_NO_FUSE") != nullptr;
     if (const char *e = getenv("RC_LOCALITY")) ctx->locality_mode = !strcmp(e, "force") ? 1 : (!strcmp(e, "off") ? -1 : 0);  // tests / A-B
     if (const char *e = getenv("RC_K3_GRID_WAVES")) ctx->env_k3_grid_waves = atoi(e);
     return ctx;
@@ -859,6 +860,7 @@ static int correct_device_impl(rc_ctx *ctx, const rc_device_batch *b, uint32_t q
     }
     RC_CHECK_HIP(ctx, hipSetDevice(ctx->device));
     int rc;
+    bool fused = false;  // probe and threshold kernels ran as one
     if ((rc = rc_dbuf_reserve(ctx, &ctx->counts, (size_t)b->nbytes * 4 + 256))) return rc;
     if ((rc = rc_dbuf_reserve(ctx, &ctx->strong, (size_t)b->n_reads * 4 + 256))) return rc;
     if ((rc = rc_dbuf_reserve(ctx, &ctx->info, (size_t)b->n_reads * 4 + 256))) return rc;
@@ -881,16 +883,18 @@ static int correct_device_impl(rc_ctx *ctx, const rc_device_batch *b, uint32_t q
     if (ctx->locality_mode >= 0 && (ctx->locality_mode > 0 || (a.n >= (1u << 18) && ctx->table_bytes > ((size_t)128 << 20))) &&
         a.max_len + 8 <= 4000) {
         if ((rc = rc_launch_locality_order(ctx, a, (size_t)b->nbytes))) return rc;
-        if ((rc = rc_launch_probe_list(ctx, a, (size_t)b->nbytes, (int32_t *)ctx->counts.p))) return rc;
+        // probe + threshold + classification in one kernel where the reads fit it
+        if ((rc = rc_launch_probe_threshold_list(ctx, a, (size_t)b->nbytes, &fused))) return rc;
+        if (!fused && (rc = rc_launch_probe_list(ctx, a, (size_t)b->nbytes, (int32_t *)ctx->counts.p))) return rc;
     } else if ((rc = rc_launch_probe(ctx, b->d_seq, (size_t)b->nbytes, (int32_t *)ctx->counts.p)))
         return rc;
     // thresholds: mates need each other's before either can be corrected, so paired / interleaved
     // batches always run the threshold kernel first; single-end batches do too when every read fits
     // the four-reads-per-wave kernel (cheaper there than inside k_correct), else k_correct computes them
-    ctx->thr_ready = false;
-    ctx->cls_ready = false;
+    ctx->thr_ready = fused;
+    if (!fused) ctx->cls_ready = false;
     const bool quarter_ok = a.max_len <= 320 && a.max_len - ctx->k + 1 <= 256 && !ctx->env_k2_wave_per_read;
-    if (a.mode != 0 || quarter_ok) {
+    if (!fused && (a.mode != 0 || quarter_ok)) {
         if ((rc = rc_launch_threshold(ctx, a, true))) return rc;
         ctx->thr_ready = true;
     }

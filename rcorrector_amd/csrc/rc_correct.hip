@@ -552,6 +552,112 @@ __global__ __launch_bounds__(64) void k_threshold(rc_kernel_args A)
 
 #include "rc_quarter.h"
 
+// ---- K1 + K2 fused, for batches probed in locality order ------------------------------------------
+// The list-driven probe kernel (rc_table.hip: k_probe_list) has its workgroup's reads and their
+// counts in LDS anyway; running the quarter-wave threshold / classification on them right there
+// saves K2's pass over the counts (4 bytes per base, written and read back through HBM) and the
+// write itself for every read the classification finishes.  Reads up to 160 bases / 128 k-mers.
+__global__ __launch_bounds__(RC_PROBE_THREADS) void k_probe_threshold_list(rc_kernel_args A, size_t nbytes, const uint32_t *__restrict__ list,
+                                                                           uint32_t reads_per_block, int32_t *__restrict__ counts)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t s_raw[(RC_PROBE_TILE + 64) / 4];
+    __shared__ uint32_t s_code[RC_PROBE_TILE / 16 + 4];
+    __shared__ uint16_t s_inv[RC_PROBE_TILE / 16 + 4];
+    __shared__ uint16_t s_nul[RC_PROBE_TILE / 16 + 4];
+    __shared__ uint32_t s_lpos[RC_PLIST_MAX_READS + 1], s_gpos[RC_PLIST_MAX_READS], s_len1[RC_PLIST_MAX_READS], s_rid[RC_PLIST_MAX_READS];
+    __shared__ int32_t s_cnt[RC_PROBE_TILE + 64];
+    __shared__ uint8_t s_cls[RC_PLIST_MAX_READS];
+    const int t = threadIdx.x, k = A.P.k;
+    const uint8_t *seq = A.seq;
+    const uint32_t i0 = blockIdx.x * reads_per_block;
+    const uint32_t nr = A.n - i0 < reads_per_block ? A.n - i0 : reads_per_block;
+    for (int c = t; c < (RC_PROBE_TILE + 64) / 4; c += RC_PROBE_THREADS) s_raw[c] = 0;
+    if ((uint32_t)t < nr) {
+        const uint32_t r = list[i0 + t], g0 = A.off[r];
+        s_rid[t] = r;
+        s_gpos[t] = g0;
+        s_len1[t] = A.off[r + 1] - g0;  // bases + the NUL
+    }
+    __syncthreads();
+    if (t == 0) {  // local start of each read: same alignment modulo 4 as in memory, a NUL in front
+        uint32_t lp = 4;
+        for (uint32_t j = 0; j < nr; ++j) {
+            lp = ((lp + 3u) & ~3u) + (s_gpos[j] & 3u);
+            s_lpos[j] = lp;
+            lp += s_len1[j];
+        }
+        s_lpos[nr] = lp;
+    }
+    __syncthreads();
+    for (uint32_t j = (uint32_t)t >> 6; j < nr; j += RC_PROBE_THREADS / 64) {  // copy, aligned dwords, outside bytes masked to NUL
+        const uint32_t g0 = s_gpos[j], lp = s_lpos[j], g1 = g0 + s_len1[j] - 1;
+        const uint32_t w0 = g0 >> 2, w1 = (g1 + 3) >> 2;
+        for (uint32_t w = w0 + ((uint32_t)t & 63u); w < w1; w += 64u) {
+            uint32_t v;
+            if ((size_t)4 * w + 4 <= nbytes) {
+                v = *reinterpret_cast<const uint32_t *>(seq + (size_t)4 * w);
+            } else {
+                v = 0;
+                for (size_t q = 0; (size_t)4 * w + q < nbytes; ++q) v |= (uint32_t)seq[(size_t)4 * w + q] << (8 * q);
+            }
+            const uint32_t lo = 4 * w < g0 ? g0 - 4 * w : 0, hi = 4 * w + 4 > g1 ? 4 * w + 4 - g1 : 0;
+            uint32_t m = 0xFFFFFFFFu;
+            if (lo) m &= 0xFFFFFFFFu << (8 * lo);
+            if (hi) m &= 0xFFFFFFFFu >> (8 * hi);
+            s_raw[(lp >> 2) + (w - w0)] = v & m;
+        }
+    }
+    __syncthreads();
+    const uint32_t total = s_lpos[nr];
+    for (int chunk = t; chunk < RC_PROBE_TILE / 16 + 2; chunk += RC_PROBE_THREADS) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(s_raw + 4 * chunk);
+        uint32_t code, inv, nul;
+        rc_pack16(v, code, inv, nul);
+        s_code[chunk] = code;
+        s_inv[chunk ^ 1] = (uint16_t)inv;
+        s_nul[chunk ^ 1] = (uint16_t)nul;
+    }
+    if (t < 2) s_code[RC_PROBE_TILE / 16 + 2 + t] = 0xFFFFFFFFu;
+    __syncthreads();
+    const uint32_t *m_inv = reinterpret_cast<const uint32_t *>(s_inv);
+    const uint32_t *m_nul = reinterpret_cast<const uint32_t *>(s_nul);
+#pragma unroll 2
+    for (uint32_t a = 4 + (uint32_t)t; a + (uint32_t)k <= total; a += RC_PROBE_THREADS) {  // probe: counts stay in LDS
+        const int mw = a >> 5, ms = a & 31;
+        const uint64_t nulw = (((uint64_t)m_nul[mw] << 32) | m_nul[mw + 1]) << ms;
+        if (nulw >> (64 - k)) continue;
+        const uint64_t invw = (((uint64_t)m_inv[mw] << 32) | m_inv[mw + 1]) << ms;
+        int cnt = 0;
+        if (!(invw >> (64 - k))) {
+            const int cw = a >> 4, cs = 2 * (a & 15);
+            uint64_t x = ((uint64_t)s_code[cw] << 32) | s_code[cw + 1];
+            if (cs) x = (x << cs) | ((uint64_t)s_code[cw + 2] >> (32 - cs));
+            cnt = rc_table_lookup(A.T, rc_canonical(x >> (64 - 2 * k), k));
+        }
+        s_cnt[a] = cnt;
+    }
+    __syncthreads();
+    // thresholds + classes: 16 reads per pass (one per 16-lane row; the list keeps mates adjacent)
+    const uint8_t *raw8 = reinterpret_cast<const uint8_t *>(s_raw);
+    for (uint32_t j0 = 0; j0 < nr; j0 += RC_PROBE_THREADS / 16) {
+        const uint32_t j = j0 + ((uint32_t)t >> 4);
+        const bool live = j < nr;
+        const uint32_t lp = live ? s_lpos[j] : 0;
+        const int len = live ? (int)s_len1[j] - 1 : 0;
+        const int cls = rcq_threshold_row<8, 10>(
+            A, live ? s_rid[j] : 0, live, len, [&](int p) { return (uint32_t)raw8[lp + p]; }, [&](int g) { return s_cnt[lp + g]; });
+        if (live && (t & 15) == 0) s_cls[j] = (uint8_t)cls;
+    }
+    __syncthreads();
+    // the counts k_correct will read: those of the reads that still need it
+    for (uint32_t j = (uint32_t)t >> 6; j < nr; j += RC_PROBE_THREADS / 64) {
+        if (A.cls && !s_cls[j]) continue;
+        const int kcnt = (int)s_len1[j] - 1 - k + 1;
+        const uint32_t lp = s_lpos[j], g0 = s_gpos[j];
+        for (int g = t & 63; g < kcnt; g += 64) counts[g0 + g] = s_cnt[lp + g];
+    }
+}
+
 #ifndef RC_HEADS
 #define RC_HEADS 8    // work-queue heads (one per XCD)
 #endif
@@ -817,6 +923,33 @@ int rc_launch_threshold(rc_ctx *ctx, const rc_device_batch_args &a, bool classif
     }
     rc_timer_end(ctx, RC_T_THRESH);
     RC_CHECK_HIP(ctx, hipGetLastError());
+    return RC_OK;
+}
+
+// K1 + K2 in one kernel over the locality list (ctx->loc_list); *done = false if the batch does not fit it
+int rc_launch_probe_threshold_list(rc_ctx *ctx, const rc_device_batch_args &a, size_t nbytes, bool *done)
+{
+    *done = false;
+    ctx->cls_ready = false;
+    if (a.n == 0 || a.max_len > 160 || a.max_len - ctx->k + 1 > 128 || ctx->env_k2_wave_per_read || ctx->env_no_fuse) return RC_OK;
+    rc_kernel_args A;
+    int rc = fill_args(ctx, a, A);
+    if (rc) return rc;
+    if (a.ret && ctx->trace_cap == 0 && !ctx->env_no_classify) {
+        if ((rc = rc_dbuf_reserve(ctx, &ctx->cls, (size_t)a.n + 256))) return rc;
+        A.cls = (uint8_t *)ctx->cls.p;
+        ctx->cls_ready = true;
+    }
+    uint32_t rpb = (uint32_t)((RC_PROBE_TILE - 8) / (a.max_len + 8));  // a read takes its bases, the NUL and up to 6 bytes of alignment
+    if (rpb > RC_PLIST_MAX_READS) rpb = RC_PLIST_MAX_READS;
+    rpb &= ~1u;  // mates stay together
+    if (rpb < 2) return RC_OK;
+    rc_timer_begin(ctx);
+    hipLaunchKernelGGL(k_probe_threshold_list, dim3((a.n + rpb - 1) / rpb), dim3(RC_PROBE_THREADS), 0, ctx->stream, A, nbytes,
+                       (const uint32_t *)ctx->loc_list.p, rpb, (int32_t *)ctx->counts.p);
+    rc_timer_end(ctx, RC_T_PROBE);
+    RC_CHECK_HIP(ctx, hipGetLastError());
+    *done = true;
     return RC_OK;
 }
 

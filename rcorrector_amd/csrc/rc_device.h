@@ -58,6 +58,32 @@ __device__ __forceinline__ int rc_table_lookup(const rc_table_view &T, uint64_t 
     }
 }
 
+// ---- pieces of the probe kernels (K1) shared by rc_table.hip and rc_correct.hip ----------------------
+#define RC_PROBE_TILE 4096
+#define RC_PROBE_THREADS 256
+
+__device__ __forceinline__ void rc_pack16(const uint4 v, uint32_t &code, uint32_t &inv, uint32_t &nul)
+{
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    code = 0;
+    inv = 0;
+    nul = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const uint32_t c = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+        uint32_t b = 3, bad = 1;
+        if (c == 'A') { b = 0; bad = 0; }
+        if (c == 'C') { b = 1; bad = 0; }
+        if (c == 'G') { b = 2; bad = 0; }
+        if (c == 'T') { b = 3; bad = 0; }
+        code |= b << (30 - 2 * j);
+        inv |= bad << (15 - j);
+        nul |= (c == 0 ? 1u : 0u) << (15 - j);
+    }
+}
+
+#define RC_PLIST_MAX_READS 64  // reads per workgroup of the list-driven probe kernels
+
 // the live entry stored in slot s of bucket b, if any: its canonical code and count.  A key that was
 // Put more than once occupies several slots; the one a probe reaches first (the latest Put,
 // Store.h:55) is the table's entry, the others are dead.

@@ -103,6 +103,7 @@ struct rc_ctx {
     rc_dbuf worklist; // uint32 per read: the reads with cls == 1, ascending
     rc_dbuf sel_tmp;  // rocPRIM scratch of the compaction
     rc_dbuf loc_a, loc_list;  // locality order of a batch (rc_launch_locality_order)
+    bool env_no_fuse = false;  // RC_NO_FUSE=1 (dev): separate probe and threshold kernels in locality order too
     int locality_mode = 0;  // 0: large batches over large tables, 1: always (RC_LOCALITY=force), -1: never (RC_LOCALITY=off)
     bool cls_ready = false;  // cls / worklist describe this batch
     // getenv() results, read once at rc_create
@@ -158,6 +159,7 @@ struct rc_device_batch_args {
 };
 int rc_launch_threshold(rc_ctx *ctx, const rc_device_batch_args &a, bool classify);
 int rc_launch_correct(rc_ctx *ctx, const rc_device_batch_args &a);
+int rc_launch_probe_threshold_list(rc_ctx *ctx, const rc_device_batch_args &a, size_t nbytes, bool *done);
 int rc_launch_summary(rc_ctx *ctx, const int32_t *d_ret, uint32_t n);
 
 // layout of rc_ctx::work (bytes): the RC_HEADS queue heads of k_correct, 128 B apart, then the

@@ -115,33 +115,17 @@ __device__ __forceinline__ uint32_t row_bits(uint64_t ballot, int row)
 
 }  // namespace rcq
 
-// GetStrongTrustedThreshold for every read (what k_threshold computes through rc_front_end()),
-// four reads per wave.  256-thread workgroups = 16 reads.
-template <int E_CNT, int E_BASE>
-__global__ __launch_bounds__(256) void k_threshold_q(rc_kernel_args A)
+// GetStrongTrustedThreshold + classification of the read held by this lane's 16-lane row (four reads
+// per wave; rows 2j and 2j+1 of a wave hold the two mates of a pair).  base_at(p) = letter of base p,
+// count_at(g) = K1's count of k-mer g; the caller decides where they come from (HBM for
+// k_threshold_q, the workgroup's LDS for the fused probe kernel).  Writes strong / info / cls and, for
+// reads it can finish, ret / l / m / h of read r; returns the class (1 = k_correct has work to do).
+template <int E_CNT, int E_BASE, class FB, class FC>
+__device__ __forceinline__ int rcq_threshold_row(const rc_kernel_args &A, uint32_t r, bool live, int len, FB base_at, FC count_at)
 {
     using namespace rcq;
     const int lane = threadIdx.x & 63, row = lane >> 4, l = lane & 15;
     const int k = A.P.k;
-    // rows 2j and 2j+1 of a wave hold the two mates of a pair (paired: reads u and n/2 + u;
-    // interleaved: reads 2u and 2u+1), so the pair threshold is one lane exchange away
-    const uint32_t wv = (uint32_t)blockIdx.x * 4u + (threadIdx.x >> 6);
-    uint32_t r;
-    bool live;
-    if (A.mode == 1) {
-        const uint32_t half = A.n >> 1, u = wv * 2u + (uint32_t)(row >> 1);
-        live = u < half;
-        r = (row & 1) ? half + u : u;
-    } else {
-        r = wv * 4u + (uint32_t)row;
-        live = r < A.n;
-    }
-    uint32_t o = 0;
-    int len = 0;
-    if (live) {
-        o = A.off[r];
-        len = (int)(A.off[r + 1] - o) - 1;
-    }
     const int kcnt = len >= k ? len - k + 1 : 0;
 
     // bases (as letter codes) and K1's counts, element g in register g/16 of lane g%16
@@ -149,12 +133,12 @@ __global__ __launch_bounds__(256) void k_threshold_q(rc_kernel_args A)
 #pragma unroll
     for (int e = 0; e < E_BASE; ++e) {
         const int p = e * 16 + l;
-        code[e] = p < len ? rc_base_code(A.seq[o + p]) : 7;
+        code[e] = p < len ? rc_base_code(base_at(p)) : 7;
     }
 #pragma unroll
     for (int e = 0; e < E_CNT; ++e) {
         const int g = e * 16 + l;
-        x[e] = g < kcnt ? A.counts[o + g] : 0;
+        x[e] = g < kcnt ? count_at(g) : 0;
     }
 
     // letter masks of the row's read as 32-bit words (bit p%32 of word p/32 = base p is the letter)
@@ -314,4 +298,33 @@ __global__ __launch_bounds__(256) void k_threshold_q(rc_kernel_args A)
         A.info[r] = screened ? 4 : ((found ? 1 : 0) | ((found && prev == 2) ? 2 : 0));
         if (A.cls) A.cls[r] = (uint8_t)cls;
     }
+    return cls;
+}
+
+// the threshold kernel over a batch in HBM: 256-thread workgroups = 16 reads
+template <int E_CNT, int E_BASE>
+__global__ __launch_bounds__(256) void k_threshold_q(rc_kernel_args A)
+{
+    const int row = (threadIdx.x & 63) >> 4;
+    // rows 2j and 2j+1 of a wave hold the two mates of a pair (paired: reads u and n/2 + u;
+    // interleaved: reads 2u and 2u+1), so the pair threshold is one lane exchange away
+    const uint32_t wv = (uint32_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+    uint32_t r;
+    bool live;
+    if (A.mode == 1) {
+        const uint32_t half = A.n >> 1, u = wv * 2u + (uint32_t)(row >> 1);
+        live = u < half;
+        r = (row & 1) ? half + u : u;
+    } else {
+        r = wv * 4u + (uint32_t)row;
+        live = r < A.n;
+    }
+    uint32_t o = 0;
+    int len = 0;
+    if (live) {
+        o = A.off[r];
+        len = (int)(A.off[r + 1] - o) - 1;
+    }
+    rcq_threshold_row<E_CNT, E_BASE>(
+        A, r, live, len, [&](int p) { return (uint32_t)A.seq[o + p]; }, [&](int g) { return A.counts[o + g]; });
 }

@@ -491,29 +491,6 @@ int rc_launch_locality_order(rc_ctx *ctx, const rc_device_batch_args &a, size_t 
 // One 256-thread workgroup owns a 4 KiB tile of the arena: it stages the tile (+32 B halo) into
 // LDS as 2-bit codes plus two bit masks (non-ACGT, NUL), then every lane extracts its windows
 // with funnel shifts, canonicalises with bit-reverse and probes one 64-byte bucket.
-#define RC_PROBE_TILE 4096
-#define RC_PROBE_THREADS 256
-
-__device__ __forceinline__ void rc_pack16(const uint4 v, uint32_t &code, uint32_t &inv, uint32_t &nul)
-{
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-    code = 0;
-    inv = 0;
-    nul = 0;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const uint32_t c = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-        uint32_t b = 3, bad = 1;
-        if (c == 'A') { b = 0; bad = 0; }
-        if (c == 'C') { b = 1; bad = 0; }
-        if (c == 'G') { b = 2; bad = 0; }
-        if (c == 'T') { b = 3; bad = 0; }
-        code |= b << (30 - 2 * j);
-        inv |= bad << (15 - j);
-        nul |= (c == 0 ? 1u : 0u) << (15 - j);
-    }
-}
-
 __global__ __launch_bounds__(RC_PROBE_THREADS) void k_probe(rc_table_view T, const uint8_t *__restrict__ seq,
                                                             size_t nbytes, int k, int32_t *__restrict__ counts)
 {
@@ -570,7 +547,6 @@ __global__ __launch_bounds__(RC_PROBE_THREADS) void k_probe(rc_table_view T, con
 // K1 over a list of reads (locality order): the workgroup's reads are copied into a local arena in
 // LDS -- each at the byte alignment it has in memory, NULs in between -- packed and probed as in
 // k_probe; a count goes to the position of its k-mer in the caller's arena.
-#define RC_PLIST_MAX_READS 64
 __global__ __launch_bounds__(RC_PROBE_THREADS) void k_probe_list(rc_table_view T, const uint8_t *__restrict__ seq, size_t nbytes,
                                                                  const uint32_t *__restrict__ off, const uint32_t *__restrict__ list,
                                                                  uint32_t n, uint32_t reads_per_block, int k, int32_t *__restrict__ counts)
