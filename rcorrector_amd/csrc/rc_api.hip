@@ -899,8 +899,9 @@ static int correct_device_impl(rc_ctx *ctx, const rc_device_batch *b, uint32_t q
         ctx->thr_ready = true;
     }
     if (ctx->cls_ready) {  // the reads the threshold kernel could not finish, as k_correct's work list
-        if ((rc = rc_dbuf_reserve(ctx, &ctx->worklist, (size_t)a.n * 4 + 256))) return rc;
-        if ((rc = rc_launch_compact(ctx, (const uint8_t *)ctx->cls.p, a.n, (uint32_t *)ctx->worklist.p,
+        ctx->work_stride = ((size_t)a.n + 63) & ~(size_t)63;
+        if ((rc = rc_dbuf_reserve(ctx, &ctx->worklist, ctx->work_stride * RC_WORK_CLASSES * 4 + 256))) return rc;
+        if ((rc = rc_launch_compact(ctx, (const uint8_t *)ctx->cls.p, a.n, (uint32_t *)ctx->worklist.p, ctx->work_stride,
                                     (uint32_t *)((char *)ctx->work.p + RC_WORK_NWORK_OFF))))
             return rc;
     }

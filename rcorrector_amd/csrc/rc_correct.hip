@@ -436,6 +436,7 @@ struct rc_kernel_args {
     int cap;        // LDS capacity of the runtime-layout kernels (k_threshold)
     int cap_class;  // capacity class of k_correct (192 / 320 / 1024)
     unsigned long long *phase_cycles;  // [8], PROF builds only
+    uint32_t work_stride;              // entries between the sections of worklist (rc_internal.h)
     int fused_front_end;               // 1: k_correct computes the read's own threshold (single-end, no threshold kernel ran)
     int32_t *trace;                    // TRACE builds only: n x (2 + trace_cap * RC_TRACE_WORDS) words
     int trace_cap;
@@ -699,27 +700,45 @@ __global__ __launch_bounds__(64, rc_k3_waves(CAP)) void k_correct(rc_kernel_args
     // apart).  A wave starts on the slice of its XCD (workgroup b runs on XCD b % 8 -- an affinity
     // for speed, nothing depends on it), takes RC_DEQUEUE entries per atomic, and moves on to the
     // next slice when one is exhausted, so no slice is left behind whatever the placement.
-    const uint32_t n_work = A.n_work ? (uint32_t)__builtin_amdgcn_readfirstlane((int)*A.n_work) : A.n;
+    // The list has RC_WORK_CLASSES sections, taken one after the other (the reads the threshold kernel
+    // expects to search longest come first: a launch ends when its last read does, and a read that
+    // runs for tens of thousands of gather rounds had better not be the last one started).  Without
+    // a list (no classification ran) there is one section, the reads themselves.
+    const int n_sections = A.n_work ? RC_WORK_CLASSES : 1;
+    int section = 0;
+    uint32_t n_work = A.n_work ? (uint32_t)__builtin_amdgcn_readfirstlane((int)A.n_work[0]) : A.n;
+    const uint32_t *list = A.worklist;
+    uint32_t *heads = A.work;
     uint32_t chunk_lo = 0, chunk_hi = 0, chunk_base = 0;
     uint32_t *meta = reinterpret_cast<uint32_t *>(lds + L.o_meta);
     int head = (int)(blockIdx.x % RC_HEADS), heads_done = 0;
     for (;;) {
         if (chunk_lo >= chunk_hi) {
             bool got = false;
-            while (heads_done < RC_HEADS) {
-                const uint32_t lo = (uint32_t)(((uint64_t)n_work * (uint32_t)head) / RC_HEADS);
-                const uint32_t hi = (uint32_t)(((uint64_t)n_work * (uint32_t)(head + 1)) / RC_HEADS);
-                uint32_t r0 = 0;
-                if (w.lane == 0) r0 = atomicAdd(A.work + head * 32, (uint32_t)RC_DEQUEUE);
-                r0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)r0);
-                if (r0 < hi - lo) {
-                    chunk_lo = lo + r0;
-                    chunk_hi = hi - chunk_lo > (uint32_t)RC_DEQUEUE ? chunk_lo + RC_DEQUEUE : hi;
-                    got = true;
-                    break;
+            for (;;) {
+                while (heads_done < RC_HEADS) {
+                    const uint32_t lo = (uint32_t)(((uint64_t)n_work * (uint32_t)head) / RC_HEADS);
+                    const uint32_t hi = (uint32_t)(((uint64_t)n_work * (uint32_t)(head + 1)) / RC_HEADS);
+                    uint32_t r0 = hi - lo;
+                    if (hi > lo) {  // (an empty slice costs no atomic)
+                        if (w.lane == 0) r0 = atomicAdd(heads + head * 32, (uint32_t)RC_DEQUEUE);
+                        r0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)r0);
+                    }
+                    if (r0 < hi - lo) {
+                        chunk_lo = lo + r0;
+                        chunk_hi = hi - chunk_lo > (uint32_t)RC_DEQUEUE ? chunk_lo + RC_DEQUEUE : hi;
+                        got = true;
+                        break;
+                    }
+                    head = head + 1 == RC_HEADS ? 0 : head + 1;
+                    ++heads_done;
                 }
-                head = head + 1 == RC_HEADS ? 0 : head + 1;
-                ++heads_done;
+                if (got || ++section >= n_sections) break;
+                n_work = (uint32_t)__builtin_amdgcn_readfirstlane((int)A.n_work[section]);
+                list = A.worklist + (size_t)section * A.work_stride;
+                heads = A.work + section * (RC_HEADS * 32);
+                head = (int)(blockIdx.x % RC_HEADS);
+                heads_done = 0;
             }
             if (!got) {
                 if (PROF && w.lane == 0) atomicMin(A.phase_cycles + 9, (unsigned long long)wall_clock64());
@@ -730,7 +749,7 @@ __global__ __launch_bounds__(64, rc_k3_waves(CAP)) void k_correct(rc_kernel_args
             chunk_base = chunk_lo;
             if ((uint32_t)w.lane < chunk_hi - chunk_lo) {
                 uint32_t ri = chunk_lo + (uint32_t)w.lane;
-                if (A.worklist) ri = A.worklist[ri];
+                if (list) ri = list[ri];
                 uint32_t *mw = meta + w.lane * RC_META_WORDS;
                 mw[0] = ri;
                 mw[1] = A.off[ri];
@@ -868,6 +887,7 @@ static int fill_args(rc_ctx *ctx, const rc_device_batch_args &a, rc_kernel_args 
     A.info = (int32_t *)ctx->info.p;
     A.cls = nullptr;
     A.worklist = nullptr;
+    A.work_stride = 0;
     A.n_work = nullptr;
     A.ret = a.ret;
     A.l = a.l;
@@ -973,6 +993,7 @@ int rc_launch_correct(rc_ctx *ctx, const rc_device_batch_args &a)
     A.phase_cycles = (unsigned long long *)((char *)ctx->work.p + RC_WORK_PHASE_OFF);
     if (ctx->cls_ready) {
         A.worklist = (const uint32_t *)ctx->worklist.p;
+        A.work_stride = (uint32_t)ctx->work_stride;
         A.n_work = (const uint32_t *)((char *)ctx->work.p + RC_WORK_NWORK_OFF);
     }
     if (ctx->trace_cap > 0) {
@@ -995,10 +1016,14 @@ int rc_launch_correct(rc_ctx *ctx, const rc_device_batch_args &a)
     rc_timer_end(ctx, RC_T_CORRECT);
     if (ctx->phase_prof && A.cap_class == 192) {
         unsigned long long pc[24];
-        uint32_t nwork = a.n;
+        uint32_t nwork = a.n, nsec[RC_WORK_CLASSES] = {0};
         RC_CHECK_HIP(ctx, hipMemcpyAsync(pc, A.phase_cycles, sizeof pc, hipMemcpyDeviceToHost, ctx->stream));
-        if (A.n_work) RC_CHECK_HIP(ctx, hipMemcpyAsync(&nwork, A.n_work, 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (A.n_work) RC_CHECK_HIP(ctx, hipMemcpyAsync(nsec, A.n_work, sizeof nsec, hipMemcpyDeviceToHost, ctx->stream));
         RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (A.n_work) {
+            nwork = 0;
+            for (int i = 0; i < RC_WORK_CLASSES; ++i) nwork += nsec[i];
+        }
         static const char *names[8] = {"dequeue+load", "polya", "islands/segments", "search", "lower-thresholds", "post-filters", "apply+kmerinfo", "store"};
         unsigned long long tot = 0;
         for (int i = 0; i < 8; ++i) tot += pc[i];
@@ -1011,7 +1036,8 @@ int rc_launch_correct(rc_ctx *ctx, const rc_device_batch_args &a)
         // wall_clock64 ticks at 100 MHz: when the queue ran dry and when the last wave ended
         fprintf(stderr, "\n[rc phase prof] work list %u of %u reads; queue empty at %.2f ms, last wave done at %.2f ms; gather rounds: %.2f per listed read, worst read %llu\n",
                 nwork, a.n, (double)(pc[9] - pc[8]) / 1e5, (double)(pc[10] - pc[8]) / 1e5, (double)pc[11] / (nwork ? nwork : 1), pc[12]);
-        fprintf(stderr, "[rc phase prof] bucket reads: %.1f per listed read\n", (double)pc[13] / (nwork ? nwork : 1));
+        fprintf(stderr, "[rc phase prof] bucket reads: %.1f per listed read; work-list sections (first to last): %u / %u / %u / %u reads\n",
+                (double)pc[13] / (nwork ? nwork : 1), nsec[0], nsec[1], nsec[2], nsec[3]);
         static const char *sn[8] = {"node entry+pop", "refill (gather round)", "keep-run", "single node", "gap windows", "jump", "terminal", "-"};
         fprintf(stderr, "[rc phase prof] inside the search, cycles/read:");
         for (int i = 0; i < 7; ++i) fprintf(stderr, " %s=%.0f", sn[i], (double)pc[16 + i] / a.n);

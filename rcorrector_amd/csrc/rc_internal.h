@@ -100,12 +100,13 @@ struct rc_ctx {
     rc_dbuf info;     // int32 per read
     bool thr_ready = false;  // strong / info hold this batch's thresholds (the threshold kernel ran)
     rc_dbuf cls;      // uint8 per read: 1 = still needs k_correct (written by the threshold kernel)
-    rc_dbuf worklist; // uint32 per read: the reads with cls == 1, ascending
+    rc_dbuf worklist; // RC_WORK_CLASSES sections of work_stride uint32 each: the reads with cls == 4, 3, 2, 1, ascending within a section
     rc_dbuf sel_tmp;  // rocPRIM scratch of the compaction
     rc_dbuf loc_a, loc_list;  // locality order of a batch (rc_launch_locality_order)
     bool env_no_fuse = false;  // RC_NO_FUSE=1 (dev): separate probe and threshold kernels in locality order too
     int locality_mode = 0;  // 0: large batches over large tables, 1: always (RC_LOCALITY=force), -1: never (RC_LOCALITY=off)
     bool cls_ready = false;  // cls / worklist describe this batch
+    size_t work_stride = 0;  // uint32 entries between the sections of worklist
     // getenv() results, read once at rc_create
     bool env_k2_wave_per_read = false, env_no_classify = false, env_timing = false;
     int env_k3_grid_waves = 0;  // dev: persistent k_correct waves per SIMD actually launched (0 = as compiled)
@@ -143,7 +144,7 @@ int rc_launch_last_base_variants(rc_ctx *ctx, const uint64_t *d_codes, size_t n,
 int rc_launch_digest(rc_ctx *ctx, unsigned long long *d_out);
 int rc_launch_locality_order(rc_ctx *ctx, const struct rc_device_batch_args &a, size_t nbytes);
 int rc_launch_probe_list(rc_ctx *ctx, const struct rc_device_batch_args &a, size_t nbytes, int32_t *d_counts);
-int rc_launch_compact(rc_ctx *ctx, const uint8_t *d_flags, uint32_t n, uint32_t *d_list, uint32_t *d_count);
+int rc_launch_compact(rc_ctx *ctx, const uint8_t *d_cls, uint32_t n, uint32_t *d_list, size_t stride, uint32_t *d_count);
 
 // rc_correct.hip
 struct rc_device_batch_args {
@@ -162,9 +163,13 @@ int rc_launch_correct(rc_ctx *ctx, const rc_device_batch_args &a);
 int rc_launch_probe_threshold_list(rc_ctx *ctx, const rc_device_batch_args &a, size_t nbytes, bool *done);
 int rc_launch_summary(rc_ctx *ctx, const int32_t *d_ret, uint32_t n);
 
-// layout of rc_ctx::work (bytes): the RC_HEADS queue heads of k_correct, 128 B apart, then the
-// length of the work list, then the phase counters of PROF builds
-#define RC_WORK_BYTES 2048
-#define RC_WORK_NWORK_OFF 1024
-#define RC_WORK_PHASE_OFF 1152
-#define RC_WORK_SUMMARY_OFF 1536  // 2 x uint64: reads, corrected bases (never reset)
+// k_correct's work list comes in RC_WORK_CLASSES sections, taken in order: the reads expected to be
+// the most expensive first, so that the last waves of a launch are not left alone with them
+// (cls value of a read = 1 + its section counted from the back; cls 0 = finished by the threshold kernel)
+#define RC_WORK_CLASSES 4
+// layout of rc_ctx::work (bytes): RC_WORK_CLASSES x RC_HEADS queue heads of k_correct, 128 B apart,
+// then the lengths of the work-list sections, then the phase counters of PROF builds
+#define RC_WORK_BYTES 5120
+#define RC_WORK_NWORK_OFF 4096
+#define RC_WORK_PHASE_OFF 4224
+#define RC_WORK_SUMMARY_OFF 4608  // 2 x uint64: reads, corrected bases (never reset)

@@ -377,15 +377,23 @@ int rc_launch_selftest_bound(rc_ctx *ctx, const int32_t *d_c, size_t n, double e
     return RC_OK;
 }
 
-// d_list = the indices i in [0, n) with d_flags[i] != 0, ascending; *d_count = how many
-int rc_launch_compact(rc_ctx *ctx, const uint8_t *d_flags, uint32_t n, uint32_t *d_list, uint32_t *d_count)
+// section c (0 .. RC_WORK_CLASSES-1) of d_list, at d_list + c * stride = the indices i in [0, n) with
+// d_cls[i] == RC_WORK_CLASSES - c, ascending; d_count[c] = how many
+struct rc_cls_is {
+    uint8_t v;
+    __host__ __device__ bool operator()(uint8_t c) const { return c == v; }
+};
+int rc_launch_compact(rc_ctx *ctx, const uint8_t *d_cls, uint32_t n, uint32_t *d_list, size_t stride, uint32_t *d_count)
 {
-    size_t tmp = 0;
     rocprim::counting_iterator<uint32_t> ids(0);
-    RC_CHECK_HIP(ctx, rocprim::select(nullptr, tmp, ids, d_flags, d_list, d_count, (size_t)n, ctx->stream));
-    int rc = rc_dbuf_reserve(ctx, &ctx->sel_tmp, tmp);
-    if (rc) return rc;
-    RC_CHECK_HIP(ctx, rocprim::select(ctx->sel_tmp.p, tmp, ids, d_flags, d_list, d_count, (size_t)n, ctx->stream));
+    for (int c = 0; c < RC_WORK_CLASSES; ++c) {
+        auto flags = rocprim::make_transform_iterator(d_cls, rc_cls_is{(uint8_t)(RC_WORK_CLASSES - c)});
+        size_t tmp = 0;
+        RC_CHECK_HIP(ctx, rocprim::select(nullptr, tmp, ids, flags, d_list + c * stride, d_count + c, (size_t)n, ctx->stream));
+        int rc = rc_dbuf_reserve(ctx, &ctx->sel_tmp, tmp);
+        if (rc) return rc;
+        RC_CHECK_HIP(ctx, rocprim::select(ctx->sel_tmp.p, tmp, ids, flags, d_list + c * stride, d_count + c, (size_t)n, ctx->stream));
+    }
     return RC_OK;
 }
 
