@@ -558,21 +558,32 @@ __global__ __launch_bounds__(64) void k_threshold(rc_kernel_args A)
 // counts in LDS anyway; running the quarter-wave threshold / classification on them right there
 // saves K2's pass over the counts (4 bytes per base, written and read back through HBM) and the
 // write itself for every read the classification finishes.  Reads up to 160 bases / 128 k-mers.
-__global__ __launch_bounds__(RC_PROBE_THREADS) void k_probe_threshold_list(rc_kernel_args A, size_t nbytes, const uint32_t *__restrict__ list,
+// RC_FUSED_TILE = bytes of the workgroup's local arena, WAVES = resident waves per SIMD the register
+// allocation is held to: 2816 B = 16 reads of up to 160 bases, one full pass of the 16-row threshold
+// code, 17 KB of LDS; 4096 B = 32 reads of up to 119 bases, two passes, 24 KB.  Six waves (80 VGPRs)
+// for both: the small arena would allow eight by LDS, but at 64 VGPRs the compiler no longer keeps the
+// eight 16-byte loads of two probes in flight -- measured on 25 M x 150 bp against a 1.26 GB table:
+// 44.1 / 42.3 / 46.2 / 47.7 ms at 5 / 6 / 7 / 8 waves (a 545 MB table, mostly cache hits, prefers
+// eight: 65.5 -> 62.1 ms).
+#ifndef RC_FUSED_SMALL_WAVES
+#define RC_FUSED_SMALL_WAVES 6
+#endif
+template <int RC_FUSED_TILE, int WAVES>
+__global__ __launch_bounds__(RC_PROBE_THREADS) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_probe_threshold_list(rc_kernel_args A, size_t nbytes, const uint32_t *__restrict__ list,
                                                                            uint32_t reads_per_block, int32_t *__restrict__ counts)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t s_raw[(RC_PROBE_TILE + 64) / 4];
-    __shared__ uint32_t s_code[RC_PROBE_TILE / 16 + 4];
-    __shared__ uint16_t s_inv[RC_PROBE_TILE / 16 + 4];
-    __shared__ uint16_t s_nul[RC_PROBE_TILE / 16 + 4];
+    __shared__ __attribute__((aligned(16))) uint32_t s_raw[(RC_FUSED_TILE + 64) / 4];
+    __shared__ uint32_t s_code[RC_FUSED_TILE / 16 + 4];
+    __shared__ uint16_t s_inv[RC_FUSED_TILE / 16 + 4];
+    __shared__ uint16_t s_nul[RC_FUSED_TILE / 16 + 4];
     __shared__ uint32_t s_lpos[RC_PLIST_MAX_READS + 1], s_gpos[RC_PLIST_MAX_READS], s_len1[RC_PLIST_MAX_READS], s_rid[RC_PLIST_MAX_READS];
-    __shared__ int32_t s_cnt[RC_PROBE_TILE + 64];
+    __shared__ __attribute__((aligned(16))) int32_t s_cnt[RC_FUSED_TILE + 64];
     __shared__ uint8_t s_cls[RC_PLIST_MAX_READS];
     const int t = threadIdx.x, k = A.P.k;
     const uint8_t *seq = A.seq;
     const uint32_t i0 = blockIdx.x * reads_per_block;
     const uint32_t nr = A.n - i0 < reads_per_block ? A.n - i0 : reads_per_block;
-    for (int c = t; c < (RC_PROBE_TILE + 64) / 4; c += RC_PROBE_THREADS) s_raw[c] = 0;
+    for (int c = t; c < (RC_FUSED_TILE + 64) / 4; c += RC_PROBE_THREADS) s_raw[c] = 0;
     if ((uint32_t)t < nr) {
         const uint32_t r = list[i0 + t], g0 = A.off[r];
         s_rid[t] = r;
@@ -610,7 +621,7 @@ __global__ __launch_bounds__(RC_PROBE_THREADS) void k_probe_threshold_list(rc_ke
     }
     __syncthreads();
     const uint32_t total = s_lpos[nr];
-    for (int chunk = t; chunk < RC_PROBE_TILE / 16 + 2; chunk += RC_PROBE_THREADS) {
+    for (int chunk = t; chunk < RC_FUSED_TILE / 16 + 2; chunk += RC_PROBE_THREADS) {
         const uint4 v = *reinterpret_cast<const uint4 *>(s_raw + 4 * chunk);
         uint32_t code, inv, nul;
         rc_pack16(v, code, inv, nul);
@@ -618,7 +629,7 @@ __global__ __launch_bounds__(RC_PROBE_THREADS) void k_probe_threshold_list(rc_ke
         s_inv[chunk ^ 1] = (uint16_t)inv;
         s_nul[chunk ^ 1] = (uint16_t)nul;
     }
-    if (t < 2) s_code[RC_PROBE_TILE / 16 + 2 + t] = 0xFFFFFFFFu;
+    if (t < 2) s_code[RC_FUSED_TILE / 16 + 2 + t] = 0xFFFFFFFFu;
     __syncthreads();
     const uint32_t *m_inv = reinterpret_cast<const uint32_t *>(s_inv);
     const uint32_t *m_nul = reinterpret_cast<const uint32_t *>(s_nul);
@@ -650,12 +661,17 @@ __global__ __launch_bounds__(RC_PROBE_THREADS) void k_probe_threshold_list(rc_ke
         if (live && (t & 15) == 0) s_cls[j] = (uint8_t)cls;
     }
     __syncthreads();
-    // the counts k_correct will read: those of the reads that still need it
+    // the counts k_correct will read: those of the reads that still need it, four per lane (a read
+    // starts at the same offset modulo 4 here and in the arena; the up to three words in front of its
+    // first count and behind its last one belong to NULs and to the last k-1 positions of a read,
+    // which hold no count -- k >= 4, rc_launch_probe_threshold_list)
     for (uint32_t j = (uint32_t)t >> 6; j < nr; j += RC_PROBE_THREADS / 64) {
         if (A.cls && !s_cls[j]) continue;
         const int kcnt = (int)s_len1[j] - 1 - k + 1;
-        const uint32_t lp = s_lpos[j], g0 = s_gpos[j];
-        for (int g = t & 63; g < kcnt; g += 64) counts[g0 + g] = s_cnt[lp + g];
+        const uint32_t lp = s_lpos[j], g0 = s_gpos[j], head = lp & 3u;
+        const int4 *src = reinterpret_cast<const int4 *>(s_cnt + (lp - head));
+        int4 *dst = reinterpret_cast<int4 *>(counts + (size_t)(g0 - head));
+        for (int q = t & 63; 4 * q < kcnt + (int)head; q += 64) dst[q] = src[q];
     }
 }
 
@@ -951,7 +967,7 @@ int rc_launch_probe_threshold_list(rc_ctx *ctx, const rc_device_batch_args &a, s
 {
     *done = false;
     ctx->cls_ready = false;
-    if (a.n == 0 || a.max_len > 160 || a.max_len - ctx->k + 1 > 128 || ctx->env_k2_wave_per_read || ctx->env_no_fuse) return RC_OK;
+    if (a.n == 0 || a.max_len > 160 || a.max_len - ctx->k + 1 > 128 || ctx->k < 4 || ctx->env_k2_wave_per_read || ctx->env_no_fuse) return RC_OK;
     rc_kernel_args A;
     int rc = fill_args(ctx, a, A);
     if (rc) return rc;
@@ -960,13 +976,24 @@ int rc_launch_probe_threshold_list(rc_ctx *ctx, const rc_device_batch_args &a, s
         A.cls = (uint8_t *)ctx->cls.p;
         ctx->cls_ready = true;
     }
-    uint32_t rpb = (uint32_t)((RC_PROBE_TILE - 8) / (a.max_len + 8));  // a read takes its bases, the NUL and up to 6 bytes of alignment
-    if (rpb > RC_PLIST_MAX_READS) rpb = RC_PLIST_MAX_READS;
-    rpb &= ~1u;  // mates stay together
-    if (rpb < 2) return RC_OK;
+    // reads per workgroup: a read takes its bases, the NUL and up to 6 bytes of alignment; whole passes
+    // of the 16-row threshold code (mates stay together); the small arena unless the large one holds
+    // twice the reads
+    auto fit = [&](int tile) {
+        uint32_t r = (uint32_t)((tile - 8) / (a.max_len + 8));
+        if (r > RC_PLIST_MAX_READS) r = RC_PLIST_MAX_READS;
+        return r & ~15u;
+    };
+    const bool large = fit(2816) < 32 && fit(4096) >= 32;
+    const uint32_t rpb = large ? fit(4096) : fit(2816);
+    if (rpb == 0) return RC_OK;  // (not reached: 16 reads of 160 bases fit)
     rc_timer_begin(ctx);
-    hipLaunchKernelGGL(k_probe_threshold_list, dim3((a.n + rpb - 1) / rpb), dim3(RC_PROBE_THREADS), 0, ctx->stream, A, nbytes,
-                       (const uint32_t *)ctx->loc_list.p, rpb, (int32_t *)ctx->counts.p);
+    if (large)
+        hipLaunchKernelGGL((k_probe_threshold_list<4096, 6>), dim3((a.n + rpb - 1) / rpb), dim3(RC_PROBE_THREADS), 0, ctx->stream, A, nbytes,
+                           (const uint32_t *)ctx->loc_list.p, rpb, (int32_t *)ctx->counts.p);
+    else
+        hipLaunchKernelGGL((k_probe_threshold_list<2816, RC_FUSED_SMALL_WAVES>), dim3((a.n + rpb - 1) / rpb), dim3(RC_PROBE_THREADS), 0, ctx->stream, A, nbytes,
+                           (const uint32_t *)ctx->loc_list.p, rpb, (int32_t *)ctx->counts.p);
     rc_timer_end(ctx, RC_T_PROBE);
     RC_CHECK_HIP(ctx, hipGetLastError());
     *done = true;
