@@ -81,6 +81,7 @@ rc_table_view rc_view(const rc_ctx *ctx)
     v.nb_home = ctx->nb_home;
     v.nbuckets_alloc = ctx->nb_alloc;
     v.layout = ctx->layout;
+    v.ext = ctx->ext;
     v.k = ctx->k;
     return v;
 }
@@ -136,7 +137,10 @@ rc_ctx *rc_create(const rc_config *cfg, char *errbuf, size_t errbuf_len)
     ctx->work.bytes = RC_WORK_BYTES;
     (void)hipMemset(ctx->work.p, 0, RC_WORK_BYTES);
     if (const char *e = getenv("RC_PHASE_PROF")) ctx->phase_prof = ctx->phase_prof_print = atoi(e) != 0;
-    if (const char *e = getenv("RC_TABLE_LOAD")) ctx->table_load = ctx->table_load_packed = atof(e);  // tuning knob
+    if (const char *e = getenv("RC_TABLE_LOAD")) {
+        ctx->table_load = ctx->table_load_packed = atof(e);
+        ctx->table_load_set = true;
+    }  // tuning knob
     if (const char *e = getenv("RC_TABLE_LAYOUT")) ctx->layout_pref = strcmp(e, "wide") != 0;         // dev: A/B the slot layouts
     ctx->env_k2_wave_per_read = getenv("RC_K2_WAVE_PER_READ") != nullptr;  // dev: force the wave-per-read threshold kernel
     ctx->env_no_classify = getenv("RC_NO_CLASSIFY") != nullptr;            // dev: every read goes through k_correct
@@ -486,6 +490,7 @@ int rc_table_share(rc_ctx *dst, const rc_ctx *src)
     dst->buckets_borrowed = true;
     dst->nb_home = src->nb_home;
     dst->layout = src->layout;
+    dst->ext = src->ext;
     dst->nb_alloc = src->nb_alloc;
     dst->n_entries = src->n_entries;
     dst->table_bytes = src->table_bytes;
@@ -515,6 +520,7 @@ int rc_table_replicate(rc_ctx *dst, const rc_ctx *src)
     RC_CHECK_HIP(dst, hipMemcpyPeer(dst->d_buckets, dst->device, src->d_buckets, src->device, src->table_bytes));
     dst->nb_home = src->nb_home;
     dst->layout = src->layout;
+    dst->ext = src->ext;
     dst->nb_alloc = src->nb_alloc;
     dst->n_entries = src->n_entries;
     dst->table_bytes = src->table_bytes;

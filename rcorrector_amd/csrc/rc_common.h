@@ -37,6 +37,9 @@
 //   word = count (27 bits) | displacement bucket - home (4 bits, 0..14; 15 = empty slot) | bit 31: the
 //   continue flag, kept in the bucket's last slot.  A third less memory per k-mer: more of the table within the reach
 //   of the TLB and the Infinity Cache.  Chosen per table when k, the counts and the placement allow.
+//   Where nb_home < 2^(2k-32) (k >= 28 for tables of ordinary size) the remainder takes `ext` more
+//   bits, the next ones of the same product, at the top of the count field: word = count (27-ext
+//   bits) | remainder bits 32..32+ext (ext bits) | displacement | flag, for counts below 2^(27-ext).
 #define RC_BUCKET_DWORDS 16
 #define RC_BUCKET_BYTES 64
 #define RC_WIDE_SLOTS 5
@@ -51,7 +54,9 @@ struct rc_table_view {
     uint32_t nbuckets_alloc;  // home buckets + slack (no wrap-around)
     int layout;               // 0 wide, 1 packed
     int k;
+    int ext;                  // PACKED: remainder bits beyond 32, kept above the count (0 .. RC_PACKED_MAX_EXT)
 };
+#define RC_PACKED_MAX_EXT 8   // counts keep at least 19 bits
 
 RC_HD int rc_layout_slots(int layout) { return layout ? RC_PACKED_SLOTS : RC_WIDE_SLOTS; }
 
@@ -179,12 +184,14 @@ RC_HD uint32_t rc_mulhi32(uint32_t a, uint32_t b)
 #endif
 }
 // home bucket and remainder of a canonical code: P = (mixed << (64 - 2k)) * nb_home as a 96-bit
-// number, home = P >> 64, rem = bits 32..63 of P.  Codes that share a home differ by at least
-// 2^(64-2k) * nb_home in P, so by at least one unit of rem when nb_home >= 2^(2k-32).
-RC_HD void rc_packed_addr(uint64_t canon, int k, uint32_t nb_home, uint32_t *home, uint32_t *rem)
+// number, home = P >> 64, rem = bits 32..63 of P, xrem = the `ext` bits below those.  Codes that
+// share a home differ by at least 2^(64-2k) * nb_home in P, so by at least one unit of (rem, xrem)
+// when nb_home * 2^ext >= 2^(2k-32).
+RC_HD void rc_packed_addr(uint64_t canon, int k, uint32_t nb_home, int ext, uint32_t *home, uint32_t *rem, uint32_t *xrem)
 {
     const int kb = 2 * k;
     const uint64_t m = rc_mix2k(canon, k);
+    *xrem = 0;
     if (kb <= 32) {
         const uint32_t a = (uint32_t)m << (32 - kb);
         *home = rc_mulhi32(a, nb_home);
@@ -198,19 +205,20 @@ RC_HD void rc_packed_addr(uint64_t canon, int k, uint32_t nb_home, uint32_t *hom
     const uint32_t sum = tl + u;
     *home = th + (sum < tl ? 1u : 0u);
     *rem = sum;
+    if (ext) *xrem = (b * nb_home) >> (32 - ext);
 }
-// the inverse: the canonical code stored as (home, rem).  With m = mixed code, m * nb_home =
-// home * 2^2k + f and rem = the top 32 bits of the 2k-bit fraction f, so m = ceil(N / nb_home) for
-// N = home * 2^2k + (rem aligned to the top of 2k bits) -- a 96-bit by 32-bit long division.
-RC_HD uint64_t rc_packed_key(uint32_t home, uint32_t rem, int k, uint32_t nb_home)
+// the inverse: the canonical code stored as (home, rem, xrem).  With m = mixed code, m * nb_home =
+// home * 2^2k + f and (rem, xrem) = the top 32 + ext bits of the 2k-bit fraction f, so m = ceil(N /
+// nb_home) for N = home * 2^2k + ((rem, xrem) aligned to the top of 2k bits) -- a 96-bit by 32-bit
+// long division.
+RC_HD uint64_t rc_packed_key(uint32_t home, uint32_t rem, uint32_t xrem, int ext, int k, uint32_t nb_home)
 {
     const int kb = 2 * k;
     uint64_t hi, lo;  // N = hi * 2^64 + lo
     if (kb >= 32) {
-        const uint64_t v = ((uint64_t)home << 32) | rem;
-        const int sh = kb - 32;
-        hi = sh ? (v >> (64 - sh)) : 0;
-        lo = v << sh;
+        const uint64_t frac = (((uint64_t)rem << ext) | xrem) << (kb - 32 - ext);  // below 2^2k
+        hi = kb == 64 ? home : ((uint64_t)home >> (64 - kb));
+        lo = (kb == 64 ? 0 : ((uint64_t)home << kb)) | frac;
     } else {
         hi = 0;
         lo = ((uint64_t)home << kb) | (rem >> (32 - kb));

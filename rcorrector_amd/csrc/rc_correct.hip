@@ -568,7 +568,7 @@ __global__ __launch_bounds__(64) void k_threshold(rc_kernel_args A)
 #ifndef RC_FUSED_SMALL_WAVES
 #define RC_FUSED_SMALL_WAVES 6
 #endif
-template <int RC_FUSED_TILE, int WAVES>
+template <int RC_FUSED_TILE, int WAVES, bool EXT>
 __global__ __launch_bounds__(RC_PROBE_THREADS) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_probe_threshold_list(rc_kernel_args A, size_t nbytes, const uint32_t *__restrict__ list,
                                                                            uint32_t reads_per_block, int32_t *__restrict__ counts)
 {
@@ -644,7 +644,7 @@ __global__ __launch_bounds__(RC_PROBE_THREADS) __attribute__((amdgpu_waves_per_e
             const int cw = a >> 4, cs = 2 * (a & 15);
             uint64_t x = ((uint64_t)s_code[cw] << 32) | s_code[cw + 1];
             if (cs) x = (x << cs) | ((uint64_t)s_code[cw + 2] >> (32 - cs));
-            cnt = rc_table_lookup(A.T, rc_canonical(x >> (64 - 2 * k), k));
+            cnt = rc_table_lookup<EXT>(A.T, rc_canonical(x >> (64 - 2 * k), k));
         }
         s_cnt[a] = cnt;
     }
@@ -988,12 +988,17 @@ int rc_launch_probe_threshold_list(rc_ctx *ctx, const rc_device_batch_args &a, s
     const uint32_t rpb = large ? fit(4096) : fit(2816);
     if (rpb == 0) return RC_OK;  // (not reached: 16 reads of 160 bases fit)
     rc_timer_begin(ctx);
-    if (large)
-        hipLaunchKernelGGL((k_probe_threshold_list<4096, 6>), dim3((a.n + rpb - 1) / rpb), dim3(RC_PROBE_THREADS), 0, ctx->stream, A, nbytes,
-                           (const uint32_t *)ctx->loc_list.p, rpb, (int32_t *)ctx->counts.p);
+    const dim3 grid((a.n + rpb - 1) / rpb), block(RC_PROBE_THREADS);
+    const uint32_t *list = (const uint32_t *)ctx->loc_list.p;
+    int32_t *counts = (int32_t *)ctx->counts.p;
+    if (large && ctx->ext)
+        hipLaunchKernelGGL((k_probe_threshold_list<4096, 6, true>), grid, block, 0, ctx->stream, A, nbytes, list, rpb, counts);
+    else if (large)
+        hipLaunchKernelGGL((k_probe_threshold_list<4096, 6, false>), grid, block, 0, ctx->stream, A, nbytes, list, rpb, counts);
+    else if (ctx->ext)
+        hipLaunchKernelGGL((k_probe_threshold_list<2816, RC_FUSED_SMALL_WAVES, true>), grid, block, 0, ctx->stream, A, nbytes, list, rpb, counts);
     else
-        hipLaunchKernelGGL((k_probe_threshold_list<2816, RC_FUSED_SMALL_WAVES>), dim3((a.n + rpb - 1) / rpb), dim3(RC_PROBE_THREADS), 0, ctx->stream, A, nbytes,
-                           (const uint32_t *)ctx->loc_list.p, rpb, (int32_t *)ctx->counts.p);
+        hipLaunchKernelGGL((k_probe_threshold_list<2816, RC_FUSED_SMALL_WAVES, false>), grid, block, 0, ctx->stream, A, nbytes, list, rpb, counts);
     rc_timer_end(ctx, RC_T_PROBE);
     RC_CHECK_HIP(ctx, hipGetLastError());
     *done = true;

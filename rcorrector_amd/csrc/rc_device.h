@@ -6,14 +6,21 @@
 // of the same sector; the slots are picked out of registers.  Of two equal keys the first in
 // probe order wins (the build places the later Put first).  T.layout is wave-uniform.
 // n_req (optional): incremented once per bucket read (profiling builds of k_correct)
+// EXT = false: the caller knows that T.ext == 0 (the probe kernels, bound by VALU issue, are compiled
+// both ways: the masks become constants and the extra multiply of rc_packed_addr disappears)
+template <bool EXT = true>
 __device__ __forceinline__ int rc_table_lookup(const rc_table_view &T, uint64_t canon, uint32_t *n_req = nullptr)
 {
     // The slots are compared as 64-bit words, from the last slot to the first, so that the first slot in
     // probe order is assigned last and wins without a test (two instructions per slot: the probe
     // kernels are bound by VALU issue).
-    if (T.layout) {  // PACKED: 8 x {rem, count | disp << 27}, continue flag in the last slot's bit 31
-        uint32_t b, rem;
-        rc_packed_addr(canon, T.k, T.nb_home, &b, &rem);
+    if (T.layout) {  // PACKED: 8 x {rem, count | xrem | disp << 27}, continue flag in the last slot's bit 31
+        uint32_t b, rem, xrem;
+        const int ext = EXT ? T.ext : 0;
+        rc_packed_addr(canon, T.k, T.nb_home, ext, &b, &rem, &xrem);
+        const uint32_t cmask = RC_PACKED_COUNT_MASK >> ext;  // (uniform)
+        const uint64_t mask = ((uint64_t)(0x7FFFFFFFu & ~cmask) << 32) | 0xFFFFFFFFull;
+        const uint32_t xhi = xrem << (27 - ext);
         for (uint32_t disp = 0;; ++disp, ++b) {
             const uint4 *p = reinterpret_cast<const uint4 *>(T.buckets + (size_t)b * RC_BUCKET_DWORDS);
             uint64_t d[RC_PACKED_SLOTS];
@@ -25,11 +32,11 @@ __device__ __forceinline__ int rc_table_lookup(const rc_table_view &T, uint64_t 
                 d[2 * q + 1] = ((uint64_t)v.w << 32) | v.z;
             }
             // an empty slot carries displacement 15, which no entry has: rem and displacement decide
-            const uint64_t want = ((uint64_t)(disp << 27) << 32) | rem;
+            const uint64_t want = ((uint64_t)((disp << 27) | xhi) << 32) | rem;
             int r = 0;
 #pragma unroll
             for (int s2 = RC_PACKED_SLOTS - 1; s2 >= 0; --s2)
-                r = (d[s2] & 0x78000000FFFFFFFFull) == want ? (int)((uint32_t)(d[s2] >> 32) & RC_PACKED_COUNT_MASK) : r;
+                r = (d[s2] & mask) == want ? (int)((uint32_t)(d[s2] >> 32) & cmask) : r;
             if (r != 0 || !(d[RC_PACKED_SLOTS - 1] >> 63) || disp == RC_PACKED_MAX_DISP) return r;
         }
     }
@@ -92,20 +99,21 @@ __device__ __forceinline__ bool rc_table_slot_entry(const rc_table_view &T, size
     const uint32_t *w = T.buckets + b * RC_BUCKET_DWORDS;
     uint64_t kk;
     int32_t cc;
+    const uint32_t cmask = RC_PACKED_COUNT_MASK >> T.ext;
     if (T.layout) {
         const uint32_t word = w[2 * s + 1];
-        cc = (int32_t)(word & RC_PACKED_COUNT_MASK);
+        cc = (int32_t)(word & cmask);
         if (cc == 0) return false;
-        kk = rc_packed_key((uint32_t)(b - ((word >> 27) & 15u)), w[2 * s], T.k, T.nb_home);
+        kk = rc_packed_key((uint32_t)(b - ((word >> 27) & 15u)), w[2 * s], (word & RC_PACKED_COUNT_MASK) >> (27 - T.ext), T.ext, T.k, T.nb_home);
     } else {
         cc = (int32_t)w[3 * s + 2];
         if (cc == 0) return false;
         kk = ((uint64_t)w[3 * s + 1] << 32) | w[3 * s];
     }
     // walk the probe sequence from the key's home: live iff this slot is the first match
-    uint32_t hb, rem = 0;
+    uint32_t hb, rem = 0, xrem = 0;
     if (T.layout)
-        rc_packed_addr(kk, T.k, T.nb_home, &hb, &rem);
+        rc_packed_addr(kk, T.k, T.nb_home, T.ext, &hb, &rem, &xrem);
     else
         hb = rc_home(kk, T.nb_home);
     const int S = rc_layout_slots(T.layout);
@@ -115,7 +123,8 @@ __device__ __forceinline__ bool rc_table_slot_entry(const rc_table_view &T, size
             bool match;
             if (T.layout) {
                 const uint32_t word = q[2 * i + 1];
-                match = (word & RC_PACKED_COUNT_MASK) != 0 && q[2 * i] == rem && ((word >> 27) & 15u) == (uint32_t)(bb - hb);
+                match = (word & cmask) != 0 && q[2 * i] == rem && ((word >> 27) & 15u) == (uint32_t)(bb - hb) &&
+                        (word & RC_PACKED_COUNT_MASK) >> (27 - T.ext) == xrem;
             } else {
                 match = q[3 * i + 2] != 0 && q[3 * i] == (uint32_t)kk && q[3 * i + 1] == (uint32_t)(kk >> 32);
             }

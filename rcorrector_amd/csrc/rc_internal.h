@@ -77,8 +77,10 @@ struct rc_ctx {
     bool buckets_borrowed = false;  // rc_table_share: another context owns d_buckets
     uint32_t nb_home = 0;
     double table_load = 0.50;  // target slot load factor of the next build (WIDE layout)
+    bool table_load_set = false;  // RC_TABLE_LOAD given: no size-dependent choice
     double table_load_packed = 0.50;  // ... (PACKED layout)
     int layout = 0;       // slot layout of the table (rc_common.h): 0 WIDE, 1 PACKED
+    int ext = 0;          // PACKED: remainder bits kept above the count (rc_table_view::ext)
     int layout_pref = 1;  // 0: always WIDE (RC_TABLE_LAYOUT=wide)
     uint32_t nb_alloc = 0;
     size_t n_entries = 0;   // accepted entries (duplicates included)

@@ -26,14 +26,14 @@
 
 // ---- K0: build -----------------------------------------------------------------------------
 __global__ void k_home_and_index(const uint64_t *__restrict__ canon, uint32_t *__restrict__ home,
-                                 uint32_t *__restrict__ idx, size_t n, uint32_t nb_home, int layout, int k)
+                                 uint32_t *__restrict__ idx, size_t n, uint32_t nb_home, int layout, int k, int ext)
 {
     size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     size_t i = n - 1 - j;  // reversed input order (see header)
-    uint32_t h, rem;
+    uint32_t h, rem, xrem;
     if (layout)
-        rc_packed_addr(canon[i], k, nb_home, &h, &rem);
+        rc_packed_addr(canon[i], k, nb_home, ext, &h, &rem, &xrem);
     else
         h = rc_home(canon[i], nb_home);
     home[j] = h;
@@ -47,23 +47,23 @@ __global__ void k_slot_seed(const uint32_t *__restrict__ home_sorted, long long 
     q[j] = (long long)slots * home_sorted[j] - (long long)j;
 }
 
-// what rules the PACKED layout out for a given input: a count of 2^27 or more, or a key pushed
+// what rules the PACKED layout out for a given input: a count of 2^(27-ext) or more, or a key pushed
 // more than 14 buckets past its home.  flags[0] |= 1 / 2.
 __global__ void k_packed_feasible(const uint32_t *__restrict__ home_sorted, const long long *__restrict__ qmax,
-                                  const int32_t *__restrict__ counts, size_t n, unsigned *__restrict__ flags)
+                                  const int32_t *__restrict__ counts, size_t n, int ext, unsigned *__restrict__ flags)
 {
     size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     const long long p = qmax[j] + (long long)j;
     unsigned f = 0;
-    if ((uint32_t)counts[j] > RC_PACKED_COUNT_MASK) f |= 1u;  // (counts are indexed by input, any order does)
+    if ((uint32_t)counts[j] > (RC_PACKED_COUNT_MASK >> ext)) f |= 1u;  // (counts are indexed by input, any order does)
     if ((uint32_t)(p / RC_PACKED_SLOTS) - home_sorted[j] > RC_PACKED_MAX_DISP) f |= 2u;
     if (f) atomicOr(flags, f);
 }
 
 __global__ void k_scatter(const uint32_t *__restrict__ home_sorted, const uint32_t *__restrict__ idx_sorted,
                           const long long *__restrict__ qmax, const uint64_t *__restrict__ canon,
-                          const int32_t *__restrict__ counts, uint32_t *__restrict__ buckets, size_t n, uint32_t nb_home, int layout, int k)
+                          const int32_t *__restrict__ counts, uint32_t *__restrict__ buckets, size_t n, uint32_t nb_home, int layout, int k, int ext)
 {
     size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
@@ -73,14 +73,14 @@ __global__ void k_scatter(const uint32_t *__restrict__ home_sorted, const uint32
     const uint32_t i = idx_sorted[j];
     const uint64_t key = canon[i];
     if (layout) {
-        uint32_t h, rem;
-        rc_packed_addr(key, k, nb_home, &h, &rem);
+        uint32_t h, rem, xrem;
+        rc_packed_addr(key, k, nb_home, ext, &h, &rem, &xrem);
         uint32_t *w = buckets + (size_t)b * RC_BUCKET_DWORDS + s * 2;
         w[0] = rem;
         // the last slot's bit 31 is the bucket's continue flag, set (atomically: another thread may own
         // that slot) by whoever lands in slot 0 of the next bucket with an earlier home
         atomicAnd(w + 1, 0x80000000u);  // (the slot starts as RC_PACKED_EMPTY_WORD; the flag bit may already be set)
-        atomicOr(w + 1, ((uint32_t)counts[i] & RC_PACKED_COUNT_MASK) | ((b - h) << 27));
+        atomicOr(w + 1, ((uint32_t)counts[i] & (RC_PACKED_COUNT_MASK >> ext)) | (xrem << (27 - ext)) | ((b - h) << 27));
         if (s == 0 && h < b) atomicOr(buckets + (size_t)(b - 1) * RC_BUCKET_DWORDS + (RC_BUCKET_DWORDS - 1), 0x80000000u);
     } else {
         uint32_t *w = buckets + (size_t)b * RC_BUCKET_DWORDS + s * 3;
@@ -92,7 +92,7 @@ __global__ void k_scatter(const uint32_t *__restrict__ home_sorted, const uint32
 }
 
 // one attempt at one layout; *ok = false (PACKED only) if a count or a displacement does not fit
-static int build_attempt(rc_ctx *ctx, const uint64_t *d_canon, const int32_t *d_counts, size_t n, int layout, uint32_t nb_home, bool *ok)
+static int build_attempt(rc_ctx *ctx, const uint64_t *d_canon, const int32_t *d_counts, size_t n, int layout, int ext, uint32_t nb_home, bool *ok)
 {
     *ok = true;
     const int S = rc_layout_slots(layout);
@@ -114,7 +114,7 @@ static int build_attempt(rc_ctx *ctx, const uint64_t *d_canon, const int32_t *d_
         uint32_t *home = b_home.as<uint32_t>(), *home_s = b_home_s.as<uint32_t>();
         uint32_t *idx = b_idx.as<uint32_t>(), *idx_s = b_idx_s.as<uint32_t>();
         long long *q = b_q.as<long long>(), *qm = b_qm.as<long long>();
-        hipLaunchKernelGGL(k_home_and_index, dim3(G), dim3(B), 0, ctx->stream, d_canon, home, idx, n, nb_home, layout, ctx->k);
+        hipLaunchKernelGGL(k_home_and_index, dim3(G), dim3(B), 0, ctx->stream, d_canon, home, idx, n, nb_home, layout, ctx->k, ext);
         RC_CHECK_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp_sort, home, home_s, idx, idx_s, n, 0, bits > 0 ? bits : 1, ctx->stream));
         RC_CHECK_HIP(ctx, rocprim::inclusive_scan(nullptr, tmp_scan, q, qm, n, rocprim::maximum<long long>(), ctx->stream));
         RC_CHECK_HIP(ctx, b_tmp.alloc(tmp_sort > tmp_scan ? tmp_sort : tmp_scan));
@@ -125,7 +125,7 @@ static int build_attempt(rc_ctx *ctx, const uint64_t *d_canon, const int32_t *d_
         unsigned flags = 0;
         if (layout) {
             RC_CHECK_HIP(ctx, hipMemsetAsync(b_flags.p, 0, 8, ctx->stream));
-            hipLaunchKernelGGL(k_packed_feasible, dim3(G), dim3(B), 0, ctx->stream, home_s, qm, d_counts, n, b_flags.as<unsigned>());
+            hipLaunchKernelGGL(k_packed_feasible, dim3(G), dim3(B), 0, ctx->stream, home_s, qm, d_counts, n, ext, b_flags.as<unsigned>());
             RC_CHECK_HIP(ctx, hipMemcpyAsync(&flags, b_flags.p, 4, hipMemcpyDeviceToHost, ctx->stream));
         }
         RC_CHECK_HIP(ctx, hipMemcpyAsync(&q_last, qm + (n - 1), 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -144,6 +144,7 @@ static int build_attempt(rc_ctx *ctx, const uint64_t *d_canon, const int32_t *d_
     }
     ctx->nb_home = nb_home;
     ctx->layout = layout;
+    ctx->ext = layout ? ext : 0;
     ctx->nb_alloc = (uint32_t)nb_alloc;
     ctx->table_bytes = (size_t)nb_alloc * RC_BUCKET_BYTES;
     RC_CHECK_HIP(ctx, hipMalloc((void **)&ctx->d_buckets, ctx->table_bytes));  // (hipDeviceMallocContiguous: no effect on the TLB cliff, measured)
@@ -153,7 +154,7 @@ static int build_attempt(rc_ctx *ctx, const uint64_t *d_canon, const int32_t *d_
         RC_CHECK_HIP(ctx, hipMemsetAsync(ctx->d_buckets, 0, ctx->table_bytes, ctx->stream));
     if (n > 0) {
         hipLaunchKernelGGL(k_scatter, dim3(G), dim3(B), 0, ctx->stream, b_home_s.as<uint32_t>(), b_idx_s.as<uint32_t>(),
-                           b_qm.as<long long>(), d_canon, d_counts, ctx->d_buckets, n, nb_home, layout, ctx->k);
+                           b_qm.as<long long>(), d_canon, d_counts, ctx->d_buckets, n, nb_home, layout, ctx->k, ext);
         RC_CHECK_HIP(ctx, hipGetLastError());
     }
     RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -178,24 +179,31 @@ int rc_build_table_from_device_pairs(rc_ctx *ctx, const uint64_t *d_canon, const
         uint64_t want = (uint64_t)((double)n / (slots * load)) + 1;
         return want < 64 ? 64 : want;
     };
-    const uint64_t wide = buckets_for(RC_WIDE_SLOTS, ctx->table_load, 0.50);
-    // PACKED needs nb_home >= 2^(2k-32) for (home, rem) to identify a code; it is used when that
-    // floor does not make the table larger than the WIDE one would be (small tables and k >= 28 stay WIDE)
-    uint64_t packed = buckets_for(RC_PACKED_SLOTS, ctx->table_load_packed, 0.50);
+    // PACKED needs nb_home * 2^ext >= 2^(2k-32) for (home, rem, xrem) to identify a code: ext = the
+    // smallest such number of extra remainder bits (0 for k <= 28 at ordinary table sizes); it is
+    // used when the counts leave room for them (k_packed_feasible), WIDE otherwise
+    const uint64_t packed = buckets_for(RC_PACKED_SLOTS, ctx->table_load_packed, 0.50);
     const int kb = 2 * ctx->k;
-    if (kb > 32 && packed < (1ull << (kb - 32))) packed = 1ull << (kb - 32);
-    if (ctx->layout_pref != 0 && packed <= wide && packed < (1ull << 32) - 8) {
+    int ext = 0;
+    while (kb > 32 && kb - 32 - ext > 0 && (packed << ext) < (1ull << (kb - 32))) ++ext;
+    if (ctx->layout_pref != 0 && ext <= RC_PACKED_MAX_EXT && packed < (1ull << 32) - 8) {
         bool ok = false;
-        int rc = build_attempt(ctx, d_canon, d_counts, n, 1, (uint32_t)packed, &ok);
+        int rc = build_attempt(ctx, d_canon, d_counts, n, 1, ext, (uint32_t)packed, &ok);
         if (rc) return rc;
-        if (ok) return RC_OK;  // else: a count >= 2^27 or a chain longer than 15 buckets -- WIDE takes anything
+        if (ok) return RC_OK;  // else: a count >= 2^(27-ext) or a chain longer than 15 buckets -- WIDE takes anything
     }
+    // WIDE: past the reach of the TLB (a table of 4.9 GB: two L1-TLB misses in three requests) a
+    // denser table is worth its longer probe chains -- 201 M entries, 25 M x 150 bp reads at 5 % errors:
+    // k_correct 2412 / 2257 / 2024 / 1841 / 1874 / 2551 ms at load 0.5 / 0.6 / 0.65 / 0.7 / 0.75 / 0.8
+    double wide_load = ctx->table_load;
+    if (!ctx->table_load_set && (double)n / (RC_WIDE_SLOTS * 0.50) * RC_BUCKET_BYTES > 3.0 * 1073741824.0) wide_load = 0.70;
+    const uint64_t wide = buckets_for(RC_WIDE_SLOTS, wide_load, 0.50);
     if (wide >= (1ull << 32) - 8) {
         rc_set_error(ctx, "table build: bucket count overflow");
         return RC_ERR_ARG;
     }
     bool ok = false;
-    return build_attempt(ctx, d_canon, d_counts, n, 0, (uint32_t)wide, &ok);
+    return build_attempt(ctx, d_canon, d_counts, n, 0, 0, (uint32_t)wide, &ok);
 }
 
 // forward (or canonical) reference codes -> canonical, in place
@@ -499,6 +507,7 @@ int rc_launch_locality_order(rc_ctx *ctx, const rc_device_batch_args &a, size_t 
 // One 256-thread workgroup owns a 4 KiB tile of the arena: it stages the tile (+32 B halo) into
 // LDS as 2-bit codes plus two bit masks (non-ACGT, NUL), then every lane extracts its windows
 // with funnel shifts, canonicalises with bit-reverse and probes one 64-byte bucket.
+template <bool EXT>
 __global__ __launch_bounds__(RC_PROBE_THREADS) void k_probe(rc_table_view T, const uint8_t *__restrict__ seq,
                                                             size_t nbytes, int k, int32_t *__restrict__ counts)
 {
@@ -546,7 +555,7 @@ __global__ __launch_bounds__(RC_PROBE_THREADS) void k_probe(rc_table_view T, con
             uint64_t x = ((uint64_t)s_code[cw] << 32) | s_code[cw + 1];
             if (cs) x = (x << cs) | ((uint64_t)s_code[cw + 2] >> (32 - cs));
             const uint64_t code = x >> (64 - 2 * k);
-            cnt = rc_table_lookup(T, rc_canonical(code, k));
+            cnt = rc_table_lookup<EXT>(T, rc_canonical(code, k));
         }
         __builtin_nontemporal_store(cnt, &counts[g]);  // streamed once: keep it out of the caches the table lives in
     }
@@ -555,6 +564,7 @@ __global__ __launch_bounds__(RC_PROBE_THREADS) void k_probe(rc_table_view T, con
 // K1 over a list of reads (locality order): the workgroup's reads are copied into a local arena in
 // LDS -- each at the byte alignment it has in memory, NULs in between -- packed and probed as in
 // k_probe; a count goes to the position of its k-mer in the caller's arena.
+template <bool EXT>
 __global__ __launch_bounds__(RC_PROBE_THREADS) void k_probe_list(rc_table_view T, const uint8_t *__restrict__ seq, size_t nbytes,
                                                                  const uint32_t *__restrict__ off, const uint32_t *__restrict__ list,
                                                                  uint32_t n, uint32_t reads_per_block, int k, int32_t *__restrict__ counts)
@@ -628,7 +638,7 @@ __global__ __launch_bounds__(RC_PROBE_THREADS) void k_probe_list(rc_table_view T
             const int cw = a >> 4, cs = 2 * (a & 15);
             uint64_t x = ((uint64_t)s_code[cw] << 32) | s_code[cw + 1];
             if (cs) x = (x << cs) | ((uint64_t)s_code[cw + 2] >> (32 - cs));
-            cnt = rc_table_lookup(T, rc_canonical(x >> (64 - 2 * k), k));
+            cnt = rc_table_lookup<EXT>(T, rc_canonical(x >> (64 - 2 * k), k));
         }
         // the read this position belongs to: last j with lpos[j] <= a
         uint32_t lo = 0, hi = nr;
@@ -650,8 +660,12 @@ int rc_launch_probe_list(rc_ctx *ctx, const rc_device_batch_args &a, size_t nbyt
     if (rpb > RC_PLIST_MAX_READS) rpb = RC_PLIST_MAX_READS;
     if (rpb < 1) rpb = 1;
     rc_timer_begin(ctx);
-    hipLaunchKernelGGL(k_probe_list, dim3((a.n + rpb - 1) / rpb), dim3(RC_PROBE_THREADS), 0, ctx->stream, rc_view(ctx), a.seq, nbytes, a.off,
-                       (const uint32_t *)ctx->loc_list.p, a.n, rpb, ctx->k, d_counts);
+    if (ctx->ext)
+        hipLaunchKernelGGL(k_probe_list<true>, dim3((a.n + rpb - 1) / rpb), dim3(RC_PROBE_THREADS), 0, ctx->stream, rc_view(ctx), a.seq, nbytes, a.off,
+                           (const uint32_t *)ctx->loc_list.p, a.n, rpb, ctx->k, d_counts);
+    else
+        hipLaunchKernelGGL(k_probe_list<false>, dim3((a.n + rpb - 1) / rpb), dim3(RC_PROBE_THREADS), 0, ctx->stream, rc_view(ctx), a.seq, nbytes, a.off,
+                           (const uint32_t *)ctx->loc_list.p, a.n, rpb, ctx->k, d_counts);
     rc_timer_end(ctx, RC_T_PROBE);
     RC_CHECK_HIP(ctx, hipGetLastError());
     return RC_OK;
@@ -666,7 +680,10 @@ int rc_launch_probe(rc_ctx *ctx, const uint8_t *d_seq, size_t nbytes, int32_t *d
     }
     const unsigned G = (unsigned)((nbytes + RC_PROBE_TILE - 1) / RC_PROBE_TILE);
     rc_timer_begin(ctx);
-    hipLaunchKernelGGL(k_probe, dim3(G), dim3(RC_PROBE_THREADS), 0, ctx->stream, rc_view(ctx), d_seq, nbytes, ctx->k, d_counts);
+    if (ctx->ext)
+        hipLaunchKernelGGL(k_probe<true>, dim3(G), dim3(RC_PROBE_THREADS), 0, ctx->stream, rc_view(ctx), d_seq, nbytes, ctx->k, d_counts);
+    else
+        hipLaunchKernelGGL(k_probe<false>, dim3(G), dim3(RC_PROBE_THREADS), 0, ctx->stream, rc_view(ctx), d_seq, nbytes, ctx->k, d_counts);
     rc_timer_end(ctx, RC_T_PROBE);
     RC_CHECK_HIP(ctx, hipGetLastError());
     return RC_OK;

@@ -421,24 +421,32 @@ def test_correct_batch_refuses_wrong_dtype(gpu_ctx_factory, oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("k", [11, 16, 17, 23, 25])
-def test_table_packed_and_wide_layouts_hold_the_same_table(k, monkeypatch):
+@pytest.mark.parametrize("k,n", [(11, 300000), (16, 300000), (17, 300000), (23, 300000), (25, 300000), (28, 300000),
+                                 (31, 300000), (31, 17000000), (32, 300000)])
+def test_table_packed_and_wide_layouts_hold_the_same_table(k, n, monkeypatch):
     """The two slot layouts (rc_common.h) of the k-mer table answer every lookup alike, export the same
-    (code, count) set and have the same content digest; PACKED is chosen when k, the counts and the
-    placement allow it, WIDE takes over when a count needs more than 27 bits."""
+    (code, count) set and have the same content digest.  PACKED is chosen when k, the counts and the
+    placement allow it: its remainder takes `ext` = 2k - 32 - log2(buckets) extra bits out of the count
+    field when the table is small for its k (up to 8: k = 31 needs 17 M entries), and
+    WIDE takes over when a count needs more than the 27 - ext bits left."""
     rng = np.random.Generator(np.random.PCG64(100 + k))
-    n = 300000
-    mask = np.uint64((1 << (2 * k)) - 1)
-    fwd = rng.integers(0, 1 << 62, size=n, dtype=np.uint64) & mask
+    mask = np.uint64((1 << (2 * k)) - 1) if k < 32 else np.uint64(0xFFFFFFFFFFFFFFFF)
+    fwd = rng.integers(0, 1 << 63, size=n, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=n, dtype=np.uint64)
+    fwd &= mask
     can = np.unique(np.minimum(fwd, _revcomp_codes(fwd, k)))
-    counts = rng.integers(2, 1 << 20, size=len(can)).astype(np.int32)
-    counts[2000:2007] = [2, (1 << 27) - 1, 3, 100, 2, 65535, 1 << 26]
+    buckets = int(len(can) + 1000) // 4 + 1           # the build's choice: entries / (8 slots * load 0.5)
+    ext = 0
+    while 2 * k > 32 and (buckets << ext) < (1 << (2 * k - 32)):
+        ext += 1
+    limit = 1 << (27 - min(ext, 8))
+    counts = rng.integers(2, min(1 << 20, limit) - 1, size=len(can)).astype(np.int32)
+    counts[2000:2007] = [2, limit - 1, 3, 100, 2, min(65535, limit - 2), limit >> 1]
     # duplicates: the later Put wins (Store.h:55)
     codes = np.concatenate([can, can[:1000]])
     cnts = np.concatenate([counts, counts[:1000] + 1])
     want = counts.copy()
     want[:1000] += 1
-    probes = np.concatenate([can, rng.integers(0, 1 << 62, size=50000, dtype=np.uint64) & mask])
+    probes = np.concatenate([can[:2000000], rng.integers(0, 1 << 62, size=50000, dtype=np.uint64) & mask])
     res = {}
     for layout in ("packed", "wide"):
         monkeypatch.setenv("RC_TABLE_LAYOUT", layout)
@@ -449,20 +457,21 @@ def test_table_packed_and_wide_layouts_hold_the_same_table(k, monkeypatch):
         res[layout] = (ctx.table_layout(), ctx.lookup(probes), ec[o], en[o], ctx.table_digest(), ctx.table_stats()["bytes"])
         ctx.close()
     assert res["wide"][0] == 0
-    min_buckets = 1 << max(0, 2 * k - 32)
-    if min_buckets <= len(codes) / (5 * 0.5):
+    if ext <= 8:
         assert res["packed"][0] == 1 and res["packed"][5] < res["wide"][5]
+    else:
+        assert res["packed"][0] == 0
     for a, b in zip(res["packed"][1:5], res["wide"][1:5]):
         assert np.array_equal(a, b)
-    assert np.array_equal(res["wide"][1][:len(can)], want)
+    assert np.array_equal(res["wide"][1][:min(len(can), 2000000)], want[:2000000])
     assert np.array_equal(res["wide"][2], can) and np.array_equal(res["wide"][3], want)
-    # one count that does not fit 27 bits: the build falls back to WIDE by itself
+    # one count that does not fit the count field: the build falls back to WIDE by itself
     monkeypatch.setenv("RC_TABLE_LAYOUT", "packed")
     ctx = rcorrector_amd.Context(k=k, device=0)
     cnts2 = cnts.copy()
-    cnts2[len(can) // 2] = 1 << 27
+    cnts2[len(can) // 2] = limit
     ctx.table_build(codes, cnts2)
-    assert ctx.table_layout() == 0 and ctx.lookup(can[len(can) // 2:len(can) // 2 + 1])[0] == 1 << 27
+    assert ctx.table_layout() == 0 and ctx.lookup(can[len(can) // 2:len(can) // 2 + 1])[0] == limit
     ctx.close()
 
 

@@ -1,0 +1,16 @@
+"""PACKED table addressing (rcorrector_amd/csrc/rc_common.h) checked on the host: the 2k-bit bijection
+and its inverse, and (home, remainder, extra remainder bits) <-> canonical code for every k, several
+table sizes and the number of extra bits the build would choose for them."""
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_packed_addressing_round_trips(tmp_path):
+    exe = str(tmp_path / "packed_math")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "rcorrector_amd", "csrc"),
+                    os.path.join(ROOT, "tests", "hostmath", "packed_math.cpp"), "-o", exe], check=True)
+    p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+    out = p.stdout.decode()
+    assert p.returncode == 0 and out.startswith("ok "), out
