@@ -182,7 +182,12 @@ int rc_build_table_from_device_pairs(rc_ctx *ctx, const uint64_t *d_canon, const
     // PACKED needs nb_home * 2^ext >= 2^(2k-32) for (home, rem, xrem) to identify a code: ext = the
     // smallest such number of extra remainder bits (0 for k <= 28 at ordinary table sizes); it is
     // used when the counts leave room for them (k_packed_feasible), WIDE otherwise
-    const uint64_t packed = buckets_for(RC_PACKED_SLOTS, ctx->table_load_packed, 0.50);
+    // (load: 0.5 gives the shortest probe chains -- configs 1-2: 0.5 / 0.6 / 0.7 / 0.8 = 126 / 133 / 143 / 172 ms
+    // per step -- until the table leaves the reach of the TLB, 2.7-3.2 GB depending on the box: 201 M
+    // entries at 0.5 / 0.6 / 0.65 / 0.7 = 3.2 / 2.7 / 2.5 / 2.3 GB: k_correct 1537 / 1189 / 1227 / 1280 ms)
+    double packed_load = ctx->table_load_packed;
+    if (!ctx->table_load_set && (double)n / (RC_PACKED_SLOTS * 0.50) * RC_BUCKET_BYTES > 2.5 * 1073741824.0) packed_load = 0.60;
+    const uint64_t packed = buckets_for(RC_PACKED_SLOTS, packed_load, 0.50);
     const int kb = 2 * ctx->k;
     int ext = 0;
     while (kb > 32 && kb - 32 - ext > 0 && (packed << ext) < (1ull << (kb - 32))) ++ext;
