@@ -182,11 +182,16 @@ int rc_build_table_from_device_pairs(rc_ctx *ctx, const uint64_t *d_canon, const
     // PACKED needs nb_home * 2^ext >= 2^(2k-32) for (home, rem, xrem) to identify a code: ext = the
     // smallest such number of extra remainder bits (0 for k <= 28 at ordinary table sizes); it is
     // used when the counts leave room for them (k_packed_feasible), WIDE otherwise
-    // (load: 0.5 gives the shortest probe chains -- configs 1-2: 0.5 / 0.6 / 0.7 / 0.8 = 126 / 133 / 143 / 172 ms
-    // per step -- until the table leaves the reach of the TLB, 2.7-3.2 GB depending on the box: 201 M
-    // entries at 0.5 / 0.6 / 0.65 / 0.7 = 3.2 / 2.7 / 2.5 / 2.3 GB: k_correct 1537 / 1189 / 1227 / 1280 ms)
+    // load by size: the emptier the table, the fewer probes run on into a second bucket (configs 1-3 at
+    // 0.4 / 0.45 / 0.5: 282 / 281 / 275, 201 / 201 / 197 and 212 / 210 / 206 M reads/s; 0.6 / 0.7 / 0.8:
+    // config 2 at 187 / 174 / 145) -- until the table leaves the reach of the TLB, 2.7-3.2 GB depending on
+    // the box: 201 M entries at 0.5 / 0.6 / 0.65 / 0.7 = 3.2 / 2.7 / 2.5 / 2.3 GB: k_correct 1537 / 1189 / 1227 /
+    // 1280 ms.  So: 0.4 up to 2 GiB, 0.5 up to 2.5 GiB, 0.6 beyond.
     double packed_load = ctx->table_load_packed;
-    if (!ctx->table_load_set && (double)n / (RC_PACKED_SLOTS * 0.50) * RC_BUCKET_BYTES > 2.5 * 1073741824.0) packed_load = 0.60;
+    if (!ctx->table_load_set) {
+        const double gib = (double)n * 8.0 / 1073741824.0;  // slot bytes of the entries
+        packed_load = gib / 0.40 <= 2.0 ? 0.40 : (gib / 0.50 <= 2.5 ? 0.50 : 0.60);
+    }
     const uint64_t packed = buckets_for(RC_PACKED_SLOTS, packed_load, 0.50);
     const int kb = 2 * ctx->k;
     int ext = 0;

@@ -434,7 +434,7 @@ def test_table_packed_and_wide_layouts_hold_the_same_table(k, n, monkeypatch):
     fwd = rng.integers(0, 1 << 63, size=n, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=n, dtype=np.uint64)
     fwd &= mask
     can = np.unique(np.minimum(fwd, _revcomp_codes(fwd, k)))
-    buckets = int(len(can) + 1000) // 4 + 1           # the build's choice: entries / (8 slots * load 0.5)
+    buckets = int((len(can) + 1000) / (8 * 0.4)) + 1   # the build's choice for a small table: entries / (8 slots * load 0.4)
     ext = 0
     while 2 * k > 32 and (buckets << ext) < (1 << (2 * k - 32)):
         ext += 1
