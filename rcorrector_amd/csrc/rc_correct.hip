@@ -89,6 +89,12 @@ struct DevWaveT {
     }
     __device__ __forceinline__ void phase(int id)
     {
+        // At the boundaries between the phases of a read the lane number becomes a new value to the
+        // compiler, so that nothing derived from it (lane * 24, ~lane, 1 << lane, an LDS address ...) is
+        // computed once before the per-read loop and kept alive -- i.e. spilled to scratch -- across the
+        // search: each phase recomputes its few from the one register that holds the lane.  (Not inside
+        // the search, ids 8 and up: there the hoisting is wanted.)
+        if (id < 8) asm volatile("" : "+v"(lane));
         if (PROF) {
             unsigned long long t = __builtin_readcyclecounter();
             acc[cur_phase] += t - t_last;
