@@ -864,6 +864,10 @@ static int correct_device_impl(rc_ctx *ctx, const rc_device_batch *b, uint32_t q
         rc_set_error(ctx, "correct_device: arena of %llu bytes exceeds the 4 GiB batch limit", (unsigned long long)b->nbytes);
         return RC_ERR_ARG;
     }
+    if (!ctx->d_buckets) {  // (before anything is launched: every probe kernel dereferences the table)
+        rc_set_error(ctx, "correct: no k-mer table loaded");
+        return RC_ERR_STATE;
+    }
     RC_CHECK_HIP(ctx, hipSetDevice(ctx->device));
     int rc;
     bool fused = false;  // probe and threshold kernels ran as one

@@ -666,6 +666,10 @@ __global__ __launch_bounds__(RC_PROBE_THREADS) void k_probe_list(rc_table_view T
 int rc_launch_probe_list(rc_ctx *ctx, const rc_device_batch_args &a, size_t nbytes, int32_t *d_counts)
 {
     if (a.n == 0) return RC_OK;
+    if (!ctx->d_buckets) {
+        rc_set_error(ctx, "probe: no k-mer table loaded");
+        return RC_ERR_STATE;
+    }
     uint32_t rpb = (uint32_t)((RC_PROBE_TILE - 8) / (a.max_len + 8));  // a read takes its bases, the NUL and up to 6 bytes of alignment
     if (rpb > RC_PLIST_MAX_READS) rpb = RC_PLIST_MAX_READS;
     if (rpb < 1) rpb = 1;
