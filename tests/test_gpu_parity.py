@@ -149,6 +149,21 @@ def test_errors_are_loud(gpu_ctx_factory):
         rcorrector_amd.Context(k=33)
 
 
+@pytest.mark.parametrize("env", [{}, {"RC_LOCALITY": "force"}, {"RC_LOCALITY": "force", "RC_NO_FUSE": "1"}, {"RC_LOCALITY": "off"}])
+def test_no_table_is_an_error_on_every_probe_path(env, monkeypatch):
+    """A context without a table refuses to correct before anything is launched, whichever probe kernel
+    the batch would have taken (the list-driven ones dereference the table without a check of their own)."""
+    import rcorrector_amd
+    for kk, v in env.items():
+        monkeypatch.setenv(kk, v)
+    ctx = rcorrector_amd.Context(k=23, device=0)
+    ctx.set_run_params(0.01, b"H")
+    a, off = rcorrector_amd.pack_reads([b"ACGT" * 10, b"TTGCA" * 9])
+    with pytest.raises(rcorrector_amd.RcorrectorError, match="no k-mer table"):
+        ctx.correct_batch(0, a, a.copy(), off)
+    ctx.close()
+
+
 def test_count_reads_device_matches_exact_counts(gpu_ctx_factory, oracle):
     """stages 0-2 replacement: k-mer counting on the GPU == exact canonical counts >= 2 (what
     `jellyfish count -C` + `dump -L 2` yields), incl. reads with N and ragged lengths."""
