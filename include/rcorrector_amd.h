@@ -96,8 +96,9 @@ int rc_table_export(rc_ctx *ctx, uint64_t *codes, int32_t *counts, size_t cap, s
 int rc_table_digest(rc_ctx *ctx, uint64_t *digest);
 /* slot layout the last build chose: 0 = WIDE (5 x 12-byte {code, count} slots per 64-byte bucket, any k
  * and count), 1 = PACKED (8 x 8-byte {remainder, count} slots: the code is implied by the bucket it
- * hashes to; taken when the counts fit the count field -- 27 bits, less up to 8 where a large k over a
- * small table needs more remainder bits -- and the placement allows: a third less HBM per k-mer).
+ * hashes to; the count field has 27 bits, less up to 8 where a large k over a small table needs more
+ * remainder bits, larger counts live in a side array of the same allocation; taken when at most 4000
+ * counts overflow and the placement allows: a third less HBM per k-mer).
  * Same answers either way (rc_table_digest is layout independent).  < 0: no table. */
 int rc_table_layout(const rc_ctx *ctx);
 /* bytes of HBM held by the table, number of buckets, number of stored entries */

@@ -74,6 +74,13 @@ int rc_dbuf_reserve(rc_ctx *ctx, rc_dbuf *b, size_t bytes)
     return RC_OK;
 }
 
+void rc_table_release(rc_ctx *ctx)
+{
+    if (ctx->d_buckets && !ctx->buckets_borrowed) (void)hipFree(reinterpret_cast<char *>(ctx->d_buckets) - RC_TABLE_PREFIX_BYTES);
+    ctx->d_buckets = nullptr;
+    ctx->buckets_borrowed = false;
+}
+
 rc_table_view rc_view(const rc_ctx *ctx)
 {
     rc_table_view v;
@@ -182,7 +189,7 @@ void rc_destroy(rc_ctx *c)
     if (ctx->s_d2h) (void)hipStreamDestroy(ctx->s_d2h);
     if (ctx->cnt_keys) (void)hipFree(ctx->cnt_keys);
     if (ctx->cnt_vals) (void)hipFree(ctx->cnt_vals);
-    if (ctx->d_buckets && !ctx->buckets_borrowed) (void)hipFree(ctx->d_buckets);
+    rc_table_release(ctx);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -482,10 +489,8 @@ int rc_table_share(rc_ctx *dst, const rc_ctx *src)
         rc_set_error(dst, "table_share: the source context has no table");
         return RC_ERR_STATE;
     }
-    if (dst->d_buckets && !dst->buckets_borrowed) {
-        RC_CHECK_HIP(dst, hipSetDevice(dst->device));
-        (void)hipFree(dst->d_buckets);
-    }
+    RC_CHECK_HIP(dst, hipSetDevice(dst->device));
+    rc_table_release(dst);
     dst->d_buckets = src->d_buckets;
     dst->buckets_borrowed = true;
     dst->nb_home = src->nb_home;
@@ -511,13 +516,14 @@ int rc_table_replicate(rc_ctx *dst, const rc_ctx *src)
     RC_CHECK_HIP(dst, hipSetDevice(src->device));
     RC_CHECK_HIP(dst, hipStreamSynchronize(src->stream));
     RC_CHECK_HIP(dst, hipSetDevice(dst->device));
-    if (dst->d_buckets && !dst->buckets_borrowed) (void)hipFree(dst->d_buckets);
-    dst->d_buckets = nullptr;
-    dst->buckets_borrowed = false;
+    rc_table_release(dst);
     static_cast<rc_ctx_full *>(dst)->dump.valid = false;
-    RC_CHECK_HIP(dst, hipMalloc((void **)&dst->d_buckets, src->table_bytes));
-    // the bucket array is the table: one copy over the direct xGMI link between the two GPUs
-    RC_CHECK_HIP(dst, hipMemcpyPeer(dst->d_buckets, dst->device, src->d_buckets, src->device, src->table_bytes));
+    char *base = nullptr;
+    RC_CHECK_HIP(dst, hipMalloc((void **)&base, src->table_bytes + RC_TABLE_PREFIX_BYTES));
+    dst->d_buckets = reinterpret_cast<uint32_t *>(base + RC_TABLE_PREFIX_BYTES);
+    // the bucket array (and its prefix) is the table: one copy over the direct xGMI link between the two GPUs
+    RC_CHECK_HIP(dst, hipMemcpyPeer(base, dst->device, reinterpret_cast<const char *>(src->d_buckets) - RC_TABLE_PREFIX_BYTES, src->device,
+                                    src->table_bytes + RC_TABLE_PREFIX_BYTES));
     dst->nb_home = src->nb_home;
     dst->layout = src->layout;
     dst->ext = src->ext;

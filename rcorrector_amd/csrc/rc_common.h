@@ -57,6 +57,14 @@ struct rc_table_view {
     int ext;                  // PACKED: remainder bits beyond 32, kept above the count (0 .. RC_PACKED_MAX_EXT)
 };
 #define RC_PACKED_MAX_EXT 8   // counts keep at least 19 bits
+// A count that does not fit the count field is stored as "all ones" and kept in full in a small
+// array IN FRONT of the bucket array (same allocation, so a table is still one pointer): the
+// RC_TABLE_PREFIX_BYTES before `buckets` hold up to RC_PACKED_OVF_MAX entries {code_lo, code_hi,
+// count, 0}, ascending by code, from the start of the prefix, and their number in the dword 64 bytes
+// before `buckets`.  (rRNA k-mers of a deep data set, with k >= 28: the alternative is the WIDE layout
+// for the whole table, i.e. a table outside the reach of the TLB.)
+#define RC_TABLE_PREFIX_BYTES 65536
+#define RC_PACKED_OVF_MAX 4000
 
 RC_HD int rc_layout_slots(int layout) { return layout ? RC_PACKED_SLOTS : RC_WIDE_SLOTS; }
 

@@ -6,6 +6,28 @@
 // of the same sector; the slots are picked out of registers.  Of two equal keys the first in
 // probe order wins (the build places the later Put first).  T.layout is wave-uniform.
 // n_req (optional): incremented once per bucket read (profiling builds of k_correct)
+// the full count of a k-mer whose slot holds the "all ones" count (rc_common.h): binary search in the
+// table's prefix.  Rare by construction (at most RC_PACKED_OVF_MAX k-mers of a table).
+__device__ inline int rc_packed_overflow_count(const rc_table_view &T, uint64_t canon)
+{
+    const uint32_t n = T.buckets[-16];
+    const uint4 *E = reinterpret_cast<const uint4 *>(T.buckets) - RC_TABLE_PREFIX_BYTES / 16;
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        const uint4 e = E[mid];
+        if ((((uint64_t)e.y << 32) | e.x) < canon)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    if (lo < n) {
+        const uint4 e = E[lo];
+        if ((((uint64_t)e.y << 32) | e.x) == canon) return (int)e.z;
+    }
+    return 0;  // (not reached for a slot that carries the mark)
+}
+
 // EXT = false: the caller knows that T.ext == 0 (the probe kernels, bound by VALU issue, are compiled
 // both ways: the masks become constants and the extra multiply of rc_packed_addr disappears)
 template <bool EXT = true>
@@ -37,7 +59,10 @@ __device__ __forceinline__ int rc_table_lookup(const rc_table_view &T, uint64_t 
 #pragma unroll
             for (int s2 = RC_PACKED_SLOTS - 1; s2 >= 0; --s2)
                 r = (d[s2] & mask) == want ? (int)((uint32_t)(d[s2] >> 32) & cmask) : r;
-            if (r != 0 || !(d[RC_PACKED_SLOTS - 1] >> 63) || disp == RC_PACKED_MAX_DISP) return r;
+            if (r != 0 || !(d[RC_PACKED_SLOTS - 1] >> 63) || disp == RC_PACKED_MAX_DISP) {
+                if (r == (int)cmask) r = rc_packed_overflow_count(T, canon);
+                return r;
+            }
         }
     }
     uint32_t b = rc_home(canon, T.nb_home);
@@ -105,6 +130,7 @@ __device__ __forceinline__ bool rc_table_slot_entry(const rc_table_view &T, size
         cc = (int32_t)(word & cmask);
         if (cc == 0) return false;
         kk = rc_packed_key((uint32_t)(b - ((word >> 27) & 15u)), w[2 * s], (word & RC_PACKED_COUNT_MASK) >> (27 - T.ext), T.ext, T.k, T.nb_home);
+        if (cc == (int32_t)cmask) cc = rc_packed_overflow_count(T, kk);
     } else {
         cc = (int32_t)w[3 * s + 2];
         if (cc == 0) return false;

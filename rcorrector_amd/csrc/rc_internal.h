@@ -126,6 +126,8 @@ struct rc_ctx {
 void rc_set_error(rc_ctx *ctx, const char *fmt, ...);
 int rc_dbuf_reserve(rc_ctx *ctx, rc_dbuf *b, size_t bytes);
 rc_table_view rc_view(const rc_ctx *ctx);
+// frees the table this context owns (the allocation starts RC_TABLE_PREFIX_BYTES before d_buckets)
+void rc_table_release(rc_ctx *ctx);
 void rc_timer_begin(rc_ctx *ctx);
 void rc_timer_end(rc_ctx *ctx, int which);
 

@@ -19,6 +19,8 @@
 #include <cstring>
 #include <vector>
 
+#include <algorithm>
+#include <vector>
 #include <rocprim/rocprim.hpp>
 
 #include "rc_internal.h"
@@ -47,18 +49,29 @@ __global__ void k_slot_seed(const uint32_t *__restrict__ home_sorted, long long 
     q[j] = (long long)slots * home_sorted[j] - (long long)j;
 }
 
-// what rules the PACKED layout out for a given input: a count of 2^(27-ext) or more, or a key pushed
-// more than 14 buckets past its home.  flags[0] |= 1 / 2.
+// what rules the PACKED layout out for a given input: a key pushed more than 14 buckets past its home
+// (flags[0] |= 2), or more counts that do not fit the count field than the table's prefix holds
+// (flags[1] = how many there are: rc_common.h, RC_PACKED_OVF_MAX).
 __global__ void k_packed_feasible(const uint32_t *__restrict__ home_sorted, const long long *__restrict__ qmax,
                                   const int32_t *__restrict__ counts, size_t n, int ext, unsigned *__restrict__ flags)
 {
     size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     const long long p = qmax[j] + (long long)j;
-    unsigned f = 0;
-    if ((uint32_t)counts[j] > (RC_PACKED_COUNT_MASK >> ext)) f |= 1u;  // (counts are indexed by input, any order does)
-    if ((uint32_t)(p / RC_PACKED_SLOTS) - home_sorted[j] > RC_PACKED_MAX_DISP) f |= 2u;
-    if (f) atomicOr(flags, f);
+    if ((uint32_t)counts[j] >= (RC_PACKED_COUNT_MASK >> ext)) atomicAdd(flags + 1, 1u);  // (counts are indexed by input, any order does)
+    if ((uint32_t)(p / RC_PACKED_SLOTS) - home_sorted[j] > RC_PACKED_MAX_DISP) atomicOr(flags, 2u);
+}
+
+// the entries whose count does not fit: {code, count, input index} in any order (the host sorts the few)
+__global__ void k_collect_overflow(const uint64_t *__restrict__ canon, const int32_t *__restrict__ counts, size_t n, uint32_t cmask,
+                                   unsigned *__restrict__ n_out, uint4 *__restrict__ out, uint32_t *__restrict__ out_idx)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || (uint32_t)counts[i] < cmask) return;
+    const unsigned o = atomicAdd(n_out, 1u);
+    if (o >= RC_PACKED_OVF_MAX) return;
+    out[o] = make_uint4((uint32_t)canon[i], (uint32_t)(canon[i] >> 32), (uint32_t)counts[i], 0u);
+    out_idx[o] = (uint32_t)i;
 }
 
 __global__ void k_scatter(const uint32_t *__restrict__ home_sorted, const uint32_t *__restrict__ idx_sorted,
@@ -80,7 +93,8 @@ __global__ void k_scatter(const uint32_t *__restrict__ home_sorted, const uint32
         // the last slot's bit 31 is the bucket's continue flag, set (atomically: another thread may own
         // that slot) by whoever lands in slot 0 of the next bucket with an earlier home
         atomicAnd(w + 1, 0x80000000u);  // (the slot starts as RC_PACKED_EMPTY_WORD; the flag bit may already be set)
-        atomicOr(w + 1, ((uint32_t)counts[i] & (RC_PACKED_COUNT_MASK >> ext)) | (xrem << (27 - ext)) | ((b - h) << 27));
+        const uint32_t cmask = RC_PACKED_COUNT_MASK >> ext, cnt = (uint32_t)counts[i] < cmask ? (uint32_t)counts[i] : cmask;  // all ones: see the prefix
+        atomicOr(w + 1, cnt | (xrem << (27 - ext)) | ((b - h) << 27));
         if (s == 0 && h < b) atomicOr(buckets + (size_t)(b - 1) * RC_BUCKET_DWORDS + (RC_BUCKET_DWORDS - 1), 0x80000000u);
     } else {
         uint32_t *w = buckets + (size_t)b * RC_BUCKET_DWORDS + s * 3;
@@ -99,6 +113,7 @@ static int build_attempt(rc_ctx *ctx, const uint64_t *d_canon, const int32_t *d_
     int bits = 0;
     while ((1ull << bits) < (uint64_t)nb_home) ++bits;
     long long p_last = -1;
+    unsigned n_overflow = 0;  // PACKED: counts that go to the table's prefix
     rc_dev_tmp b_home, b_home_s, b_idx, b_idx_s, b_q, b_qm, b_tmp, b_flags;
     const unsigned B = 256;
     const unsigned G = (unsigned)((n + B - 1) / B);
@@ -122,18 +137,19 @@ static int build_attempt(rc_ctx *ctx, const uint64_t *d_canon, const int32_t *d_
         hipLaunchKernelGGL(k_slot_seed, dim3(G), dim3(B), 0, ctx->stream, home_s, q, n, S);
         RC_CHECK_HIP(ctx, rocprim::inclusive_scan(b_tmp.p, tmp_scan, q, qm, n, rocprim::maximum<long long>(), ctx->stream));
         long long q_last = 0;
-        unsigned flags = 0;
+        unsigned flags[2] = {0, 0};
         if (layout) {
             RC_CHECK_HIP(ctx, hipMemsetAsync(b_flags.p, 0, 8, ctx->stream));
             hipLaunchKernelGGL(k_packed_feasible, dim3(G), dim3(B), 0, ctx->stream, home_s, qm, d_counts, n, ext, b_flags.as<unsigned>());
-            RC_CHECK_HIP(ctx, hipMemcpyAsync(&flags, b_flags.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+            RC_CHECK_HIP(ctx, hipMemcpyAsync(flags, b_flags.p, 8, hipMemcpyDeviceToHost, ctx->stream));
         }
         RC_CHECK_HIP(ctx, hipMemcpyAsync(&q_last, qm + (n - 1), 8, hipMemcpyDeviceToHost, ctx->stream));
         RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (flags) {
+        if (flags[0] || flags[1] > RC_PACKED_OVF_MAX) {
             *ok = false;
             return RC_OK;
         }
+        n_overflow = flags[1];
         p_last = q_last + (long long)(n - 1);
     }
     uint64_t need = (uint64_t)(p_last / S) + 2;  // +1 empty bucket after the last used
@@ -147,7 +163,39 @@ static int build_attempt(rc_ctx *ctx, const uint64_t *d_canon, const int32_t *d_
     ctx->ext = layout ? ext : 0;
     ctx->nb_alloc = (uint32_t)nb_alloc;
     ctx->table_bytes = (size_t)nb_alloc * RC_BUCKET_BYTES;
-    RC_CHECK_HIP(ctx, hipMalloc((void **)&ctx->d_buckets, ctx->table_bytes));  // (hipDeviceMallocContiguous: no effect on the TLB cliff, measured)
+    {   // the bucket array, RC_TABLE_PREFIX_BYTES (zero unless counts overflow, below) in front of it
+        char *base = nullptr;
+        RC_CHECK_HIP(ctx, hipMalloc((void **)&base, ctx->table_bytes + RC_TABLE_PREFIX_BYTES));  // (hipDeviceMallocContiguous: no effect on the TLB cliff, measured)
+        ctx->d_buckets = reinterpret_cast<uint32_t *>(base + RC_TABLE_PREFIX_BYTES);
+        RC_CHECK_HIP(ctx, hipMemsetAsync(base, 0, RC_TABLE_PREFIX_BYTES, ctx->stream));
+    }
+    if (layout && n_overflow) {
+        rc_dev_tmp b_o, b_oi, b_on;
+        RC_CHECK_HIP(ctx, b_o.alloc(RC_PACKED_OVF_MAX * sizeof(uint4)));
+        RC_CHECK_HIP(ctx, b_oi.alloc(RC_PACKED_OVF_MAX * 4));
+        RC_CHECK_HIP(ctx, b_on.alloc(4));
+        RC_CHECK_HIP(ctx, hipMemsetAsync(b_on.p, 0, 4, ctx->stream));
+        hipLaunchKernelGGL(k_collect_overflow, dim3(G), dim3(B), 0, ctx->stream, d_canon, d_counts, n, RC_PACKED_COUNT_MASK >> ext, b_on.as<unsigned>(),
+                           b_o.as<uint4>(), b_oi.as<uint32_t>());
+        std::vector<uint4> e(n_overflow);
+        std::vector<uint32_t> ei(n_overflow);
+        RC_CHECK_HIP(ctx, hipMemcpyAsync(e.data(), b_o.p, n_overflow * sizeof(uint4), hipMemcpyDeviceToHost, ctx->stream));
+        RC_CHECK_HIP(ctx, hipMemcpyAsync(ei.data(), b_oi.p, n_overflow * 4, hipMemcpyDeviceToHost, ctx->stream));
+        RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        // ascending by code; of two Puts of one code the later one is the table's entry (Store.h:55)
+        std::vector<uint32_t> o(n_overflow);
+        for (uint32_t i = 0; i < n_overflow; ++i) o[i] = i;
+        auto code = [&](uint32_t i) { return ((uint64_t)e[i].y << 32) | e[i].x; };
+        std::sort(o.begin(), o.end(), [&](uint32_t a, uint32_t b) { return code(a) != code(b) ? code(a) < code(b) : ei[a] < ei[b]; });
+        std::vector<uint4> sorted;
+        for (uint32_t j = 0; j < n_overflow; ++j)
+            if (j + 1 == n_overflow || code(o[j + 1]) != code(o[j])) sorted.push_back(e[o[j]]);
+        const uint32_t ns = (uint32_t)sorted.size();
+        char *base = reinterpret_cast<char *>(ctx->d_buckets) - RC_TABLE_PREFIX_BYTES;
+        RC_CHECK_HIP(ctx, hipMemcpyAsync(base, sorted.data(), ns * sizeof(uint4), hipMemcpyHostToDevice, ctx->stream));
+        RC_CHECK_HIP(ctx, hipMemcpyAsync(reinterpret_cast<char *>(ctx->d_buckets) - 64, &ns, 4, hipMemcpyHostToDevice, ctx->stream));
+        RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (the vectors go out of scope)
+    }
     if (layout)
         RC_CHECK_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)ctx->d_buckets, (int)RC_PACKED_EMPTY_WORD, ctx->table_bytes / 4, ctx->stream));
     else
@@ -168,9 +216,7 @@ int rc_build_table_from_device_pairs(rc_ctx *ctx, const uint64_t *d_canon, const
         rc_set_error(ctx, "table build: %zu entries exceed the 2^31 limit", n);
         return RC_ERR_ARG;
     }
-    if (ctx->d_buckets && !ctx->buckets_borrowed) (void)hipFree(ctx->d_buckets);
-    ctx->d_buckets = nullptr;
-    ctx->buckets_borrowed = false;
+    rc_table_release(ctx);
     // home buckets: n / (slots * load).  Random 64-byte gathers on MI355X are request-rate bound
     // (~55 G/s, tools/microbench_gather.hip) and fall off a cliff once the table outgrows the TLB
     // reach (~2 GiB), so a dense table wins: fewer bytes => more MALL/L2 hits per probe.

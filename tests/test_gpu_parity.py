@@ -443,7 +443,8 @@ def test_table_packed_and_wide_layouts_hold_the_same_table(k, n, monkeypatch):
     (code, count) set and have the same content digest.  PACKED is chosen when k, the counts and the
     placement allow it: its remainder takes `ext` = 2k - 32 - log2(buckets) extra bits out of the count
     field when the table is small for its k (up to 8: k = 31 needs 17 M entries), and
-    WIDE takes over when a count needs more than the 27 - ext bits left."""
+    counts that need more than the 27 - ext bits left go to a side array in front of the buckets; WIDE
+    takes over when there are too many of those, or when a key would sit too far from its home."""
     rng = np.random.Generator(np.random.PCG64(100 + k))
     mask = np.uint64((1 << (2 * k)) - 1) if k < 32 else np.uint64(0xFFFFFFFFFFFFFFFF)
     fwd = rng.integers(0, 1 << 63, size=n, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=n, dtype=np.uint64)
@@ -480,13 +481,36 @@ def test_table_packed_and_wide_layouts_hold_the_same_table(k, n, monkeypatch):
         assert np.array_equal(a, b)
     assert np.array_equal(res["wide"][1][:min(len(can), 2000000)], want[:2000000])
     assert np.array_equal(res["wide"][2], can) and np.array_equal(res["wide"][3], want)
-    # one count that does not fit the count field: the build falls back to WIDE by itself
+    # counts that do not fit the count field go to the table's prefix (rc_common.h) and the table stays
+    # PACKED -- also where a key was Put twice (the later Put is the table's entry, Store.h:55) ...
     monkeypatch.setenv("RC_TABLE_LAYOUT", "packed")
+    if ext <= 8:
+        ctx = rcorrector_amd.Context(k=k, device=0)
+        cnts2 = cnts.copy()
+        big = [limit - 1, limit, 3 * limit + 7, (1 << 31) - 1]
+        mid = len(can) // 2
+        for j, v in enumerate(big):
+            cnts2[mid + j] = v
+        cnts2[5], cnts2[len(can) + 5] = 2 * limit, 2 * limit + 1     # both Puts overflow
+        cnts2[6], cnts2[len(can) + 6] = 2 * limit, 77                # only the shadowed one does
+        cnts2[7], cnts2[len(can) + 7] = 78, 2 * limit + 9            # only the live one does
+        ctx.table_build(codes, cnts2)
+        assert ctx.table_layout() == 1
+        got = ctx.lookup(np.concatenate([can[mid:mid + 4], can[5:8], can[100:110]]))
+        assert got.tolist() == big + [2 * limit + 1, 77, 2 * limit + 9] + (counts[100:110] + 1).tolist()
+        ec, en = ctx.table_export()
+        o = np.argsort(ec)
+        w2 = want.copy()
+        w2[mid:mid + 4] = big
+        w2[5:8] = [2 * limit + 1, 77, 2 * limit + 9]
+        assert np.array_equal(ec[o], can) and np.array_equal(en[o], w2)
+        ctx.close()
+    # ... up to 4000 of them; beyond that the build falls back to WIDE by itself
     ctx = rcorrector_amd.Context(k=k, device=0)
-    cnts2 = cnts.copy()
-    cnts2[len(can) // 2] = limit
-    ctx.table_build(codes, cnts2)
-    assert ctx.table_layout() == 0 and ctx.lookup(can[len(can) // 2:len(can) // 2 + 1])[0] == limit
+    cnts3 = cnts.copy()
+    cnts3[20000:24100] = limit + 5
+    ctx.table_build(codes, cnts3)
+    assert ctx.table_layout() == 0 and ctx.lookup(can[20000:20001])[0] == limit + 5
     ctx.close()
 
 
