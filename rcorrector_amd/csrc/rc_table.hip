@@ -227,7 +227,7 @@ int rc_build_table_from_device_pairs(rc_ctx *ctx, const uint64_t *d_canon, const
     };
     // PACKED needs nb_home * 2^ext >= 2^(2k-32) for (home, rem, xrem) to identify a code: ext = the
     // smallest such number of extra remainder bits (0 for k <= 28 at ordinary table sizes); it is
-    // used when the counts leave room for them (k_packed_feasible), WIDE otherwise
+    // used when at most RC_PACKED_MAX_EXT are needed and the placement allows (k_packed_feasible), WIDE otherwise
     // load by size: the emptier the table, the fewer probes run on into a second bucket (configs 1-3 at
     // 0.4 / 0.45 / 0.5: 282 / 281 / 275, 201 / 201 / 197 and 212 / 210 / 206 M reads/s; 0.6 / 0.7 / 0.8:
     // config 2 at 187 / 174 / 145) -- until the table leaves the reach of the TLB, 2.7-3.2 GB depending on
@@ -246,7 +246,7 @@ int rc_build_table_from_device_pairs(rc_ctx *ctx, const uint64_t *d_canon, const
         bool ok = false;
         int rc = build_attempt(ctx, d_canon, d_counts, n, 1, ext, (uint32_t)packed, &ok);
         if (rc) return rc;
-        if (ok) return RC_OK;  // else: a count >= 2^(27-ext) or a chain longer than 15 buckets -- WIDE takes anything
+        if (ok) return RC_OK;  // else: too many counts beyond the count field or a chain longer than 15 buckets -- WIDE takes anything
     }
     // WIDE: past the reach of the TLB (a table of 4.9 GB: two L1-TLB misses in three requests) a
     // denser table is worth its longer probe chains -- 201 M entries, 25 M x 150 bp reads at 5 % errors:
