@@ -53,3 +53,16 @@ def test_gpu_bytes_equal_cpu_bytes():
         a, aq = _gen("cpu", **kw).generate(5000, 3000)
         b, bq = _gen("cuda:0", **kw).generate(5000, 3000)
         assert torch.equal(a, b.cpu()) and torch.equal(aq, bq.cpu())
+
+
+def test_every_bench_preset_has_a_committed_traffic_figure():
+    """roofline.traffic of a preset comes from the committed FETCH_SIZE pass (profiles/r2_traffic.json,
+    tools/final_measurements.sh): every preset must have one, and workloads that are not presets none."""
+    import types
+    import bench
+    for c in sorted(bench.PRESETS):
+        a = types.SimpleNamespace(reads=None, len=None, k=None, err=None, alpha=None, seed=None, maxcork=None, paired=None, config=c)
+        t, note = bench.fetch_size_pass(a, 1)
+        assert t is not None and t > 1e9 and "FETCH_SIZE" in note
+    a = types.SimpleNamespace(reads=1000, len=None, k=None, err=None, alpha=None, seed=None, maxcork=None, paired=None, config=2)
+    assert bench.fetch_size_pass(a, 1)[0] is None
