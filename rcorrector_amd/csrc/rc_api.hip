@@ -133,6 +133,8 @@ rc_ctx *rc_create(const rc_config *cfg, char *errbuf, size_t errbuf_len)
     ctx->P.max_fix_per_k = cfg->max_fix_per_k > 0 ? cfg->max_fix_per_k : 4;
     ctx->P.error_rate = 0.01;
     ctx->P.bad_qual = 0;
+    memset(ctx->P.bs, 0, sizeof ctx->P.bs);
+    ctx->P.flags = 0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
@@ -153,6 +155,8 @@ rc_ctx *rc_create(const rc_config *cfg, char *errbuf, size_t errbuf_len)
     ctx->env_no_classify = getenv("RC_NO_CLASSIFY") != nullptr;            // dev: every read goes through k_correct
     ctx->env_timing = getenv("RC_TIMING") != nullptr;
     ctx->env_no_fuse = getenv("RC_NO_FUSE") != nullptr;
+    ctx->env_k3_generic = getenv("RC_K3_GENERIC") != nullptr;
+    ctx->env_no_alt = getenv("RC_NO_ALT") != nullptr;  // dev / tests: no alternative chains in the search's speculation rounds
     if (const char *e = getenv("RC_LOCALITY")) ctx->locality_mode = !strcmp(e, "force") ? 1 : (!strcmp(e, "off") ? -1 : 0);  // tests / A-B
     if (const char *e = getenv("RC_K3_GRID_WAVES")) ctx->env_k3_grid_waves = atoi(e);
     return ctx;
@@ -817,6 +821,12 @@ int rc_set_run_params(rc_ctx *ctx, double error_rate, char bad_quality)
     if (!ctx) return RC_ERR_ARG;
     ctx->P.error_rate = error_rate;
     ctx->P.bad_qual = (int)(signed char)bad_quality;
+    // the first integer steps of GetBound at this rate (rc_common.h), computed here with the host's -- the
+    // reference's -- arithmetic; they travel to the correction kernel with its arguments
+    uint32_t steps[RC_BOUND_STEPS];
+    rc_bound_steps_build(error_rate, steps);
+    for (int v = 0; v < RC_BS_INLINE; ++v) ctx->P.bs[v] = steps[v];
+    ctx->P.flags = ctx->env_no_alt ? RC_PF_NO_ALT : 0;
     ctx->params_set = true;
     return RC_OK;
 }
@@ -873,6 +883,12 @@ static int correct_device_impl(rc_ctx *ctx, const rc_device_batch *b, uint32_t q
     if (!ctx->d_buckets) {  // (before anything is launched: every probe kernel dereferences the table)
         rc_set_error(ctx, "correct: no k-mer table loaded");
         return RC_ERR_STATE;
+    }
+    // mates travel together (main.cpp:441, :459-468): an odd read count in a paired or interleaved batch has a
+    // read without a mate -- refused before the locality order or the pair exchange of the threshold kernel see it
+    if (b->mode != 0 && (b->n_reads & 1u)) {
+        rc_set_error(ctx, "correct: %s mode needs an even number of reads (got %u)", b->mode == 1 ? "paired" : "interleaved", b->n_reads);
+        return RC_ERR_ARG;
     }
     RC_CHECK_HIP(ctx, hipSetDevice(ctx->device));
     int rc;
@@ -1092,7 +1108,7 @@ static int hbuf_reserve(rc_ctx *ctx, rc_hbuf *h, size_t bytes)
     return RC_OK;
 }
 
-static bool is_pinned(const void *p)
+static bool is_pinned_at(const void *p)
 {
     hipPointerAttribute_t at;
     if (hipPointerGetAttributes(&at, p) != hipSuccess) {
@@ -1100,6 +1116,17 @@ static bool is_pinned(const void *p)
         return false;
     }
     return at.type == hipMemoryTypeHost;
+}
+
+// the whole range [p, p + bytes) is page-locked: its first and last byte are (a registration or a
+// hipHostMalloc block is one contiguous range, so a buffer that starts and ends inside pinned memory and was
+// handed over as one array lies in it -- unless it straddles two separate registrations, which then both
+// cover their part)
+static bool is_pinned(const void *p, size_t bytes)
+{
+    if (!p) return false;
+    if (!is_pinned_at(p)) return false;
+    return bytes <= 1 || is_pinned_at(static_cast<const char *>(p) + bytes - 1);
 }
 
 int rc_host_alloc(rc_ctx *ctx, size_t bytes, void **out)
@@ -1177,6 +1204,14 @@ int rc_submit(rc_ctx *c, const rc_batch *b, int slot)
         rc_set_error(ctx, "submit: batch too large (split it)");
         return RC_ERR_ARG;
     }
+    if (b->mode == 2 && (n1 & 1)) {  // (before any copy is queued)
+        rc_set_error(ctx, "submit: interleaved mode needs an even number of reads (got %zu)", n1);
+        return RC_ERR_ARG;
+    }
+    if (!ctx->d_buckets) {
+        rc_set_error(ctx, "correct: no k-mer table loaded");
+        return RC_ERR_STATE;
+    }
     // offsets of the device arena (arena 1 then arena 2) and the longest read, into pinned memory
     if ((rc = hbuf_reserve(ctx, &sl.p_off, (total + 1) * 4))) return rc;
     uint32_t *off = (uint32_t *)sl.p_off.p;
@@ -1196,8 +1231,9 @@ int rc_submit(rc_ctx *c, const rc_batch *b, int slot)
     if ((rc = rc_dbuf_reserve(ctx, &sl.d_qual, qbase2 + q2 + 64))) return rc;
     if ((rc = rc_dbuf_reserve(ctx, &sl.d_off, (total + 1) * 4))) return rc;
     if ((rc = rc_dbuf_reserve(ctx, &sl.d_res, total * 16))) return rc;
-    sl.seq_pinned = is_pinned(b->seq) && is_pinned(b->qual) && (b->mode != 1 || (is_pinned(b->seq2) && is_pinned(b->qual2)));
-    sl.res_pinned = is_pinned(b->ret) && is_pinned(b->l) && is_pinned(b->m) && is_pinned(b->h);
+    sl.seq_pinned = is_pinned(b->seq, sl.bytes1) && is_pinned(b->qual, q1) &&
+                    (b->mode != 1 || (is_pinned(b->seq2, sl.bytes2) && is_pinned(b->qual2, q2)));
+    sl.res_pinned = is_pinned(b->ret, total * 4) && is_pinned(b->l, total * 4) && is_pinned(b->m, total * 4) && is_pinned(b->h, total * 4);
     const char *h_seq1 = b->seq, *h_qual1 = b->qual, *h_seq2 = b->seq2, *h_qual2 = b->qual2;
     if (!sl.seq_pinned) {  // pageable buffers: through the slot's pinned staging
         if ((rc = hbuf_reserve(ctx, &sl.p_seq, nbytes))) return rc;
@@ -1218,6 +1254,20 @@ int rc_submit(rc_ctx *c, const rc_batch *b, int slot)
     // one upload stream: bases and qualities on two streams measured 21 GB/s against 26.6 GB/s on one
     // (the link, not a DMA engine, is the bound)
     hipStream_t sq = ctx->s_h2d;
+    // from here on copies are in flight from the caller's buffers (or the slot's staging): an error must not
+    // return before they have drained, or the caller could free / the next submit could overwrite memory the
+    // DMA engines still read
+    struct drain_on_error {
+        rc_ctx *c;
+        bool armed = true;
+        ~drain_on_error()
+        {
+            if (!armed) return;
+            (void)hipStreamSynchronize(c->s_h2d);
+            (void)hipStreamSynchronize(c->stream);
+            (void)hipStreamSynchronize(c->s_d2h);
+        }
+    } guard{ctx};
     RC_CHECK_HIP(ctx, hipMemcpyAsync(d_seq, h_seq1, sl.bytes1, hipMemcpyHostToDevice, ctx->s_h2d));
     RC_CHECK_HIP(ctx, hipMemcpyAsync(d_qual, h_qual1, q1, hipMemcpyHostToDevice, sq));
     if (b->mode == 1) {
@@ -1260,6 +1310,7 @@ int rc_submit(rc_ctx *c, const rc_batch *b, int slot)
         RC_CHECK_HIP(ctx, hipMemcpyAsync(sl.p_res.p, d_res, total * 16, hipMemcpyDeviceToHost, ctx->s_d2h));
     }
     RC_CHECK_HIP(ctx, hipEventRecord(sl.e_done, ctx->s_d2h));
+    guard.armed = false;
     sl.busy = true;
     return RC_OK;
 }

@@ -303,6 +303,40 @@ RC_HD int rc_bound_i(int c, double e)
     return (int)x;
 }
 
+// ---- the integer steps of GetBound ------------------------------------------------------------
+// (int)GetBound(c) is a non-decreasing step function of the count c (every operation in it is
+// monotone and correctly rounded), and ERROR_RATE is a constant of the run: B[v] = the smallest
+// count whose bound reaches v, computed once on the host (x86 arithmetic: the reference's own) when
+// the run parameters are set.  The search asks "is the bound of this count at least t" thousands of
+// times per read and needs the bound's value only when the answer is no: one integer compare against
+// B[t] replaces the double-precision multiply / square root / add chain in the common case.
+//   B[v], v in [2, RC_BOUND_STEPS): as above, or RC_BOUND_NEVER if no count below 2^31 reaches v.
+//   B[0] = number of valid entries (0: table unusable -- the bound overflows int for large counts
+//   at this error rate, which breaks monotonicity -- every caller then evaluates GetBound itself).
+#define RC_BOUND_STEPS 1024
+#define RC_BOUND_NEVER 0x80000000u
+inline void rc_bound_steps_build(double e, uint32_t *B)  // host only
+{
+    for (int v = 0; v < RC_BOUND_STEPS; ++v) B[v] = RC_BOUND_NEVER;
+    B[0] = 0;
+    B[1] = 0;
+    const double top = rc_bound_d(2147483647, e);
+    if (!(e >= 0.0) || !(top < 2147483648.0)) return;  // NaN / negative rates, or the (int) conversion overflows: no table
+    for (int v = 2; v < RC_BOUND_STEPS; ++v) {
+        if (rc_bound_i(2147483647, e) < v) break;  // never reached (and no larger v is)
+        long long lo = 0, hi = 2147483647;  // smallest c in [lo, hi] with bound_i(c) >= v
+        while (lo < hi) {
+            const long long mid = (lo + hi) >> 1;
+            if (rc_bound_i((int)mid, e) >= v)
+                hi = mid;
+            else
+                lo = mid + 1;
+        }
+        B[v] = (uint32_t)lo;
+    }
+    B[0] = RC_BOUND_STEPS;
+}
+
 // `b < GetBound(c)` as the double comparison at ErrorCorrection.cpp:1195 (NaN compares false)
 RC_HD bool rc_less_than_bound(int b, int c, double e)
 {

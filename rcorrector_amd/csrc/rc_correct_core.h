@@ -28,12 +28,23 @@
 #pragma once
 #include "rc_common.h"
 
+#define RC_BS_INLINE 16
+// k as the wave back end knows it: a compile-time constant where the kernel was instantiated for one k
+// (W::KT > 0: masks, shifts and window lengths become immediates instead of scalar registers), else the run's
+#define RC_K(P) (W::KT > 0 ? W::KT : (P).k)
+
 struct rc_run_params {
     int k;
     int max_fix_per_k;
     double error_rate;
     int bad_qual;  // badQualityThreshold as a signed char value
+    // the first integer steps of GetBound at this error_rate (rc_common.h: rc_bound_steps_build): bs[v] = the
+    // smallest count whose bound reaches v, for v in [2, RC_BS_INLINE); bs[0] = 0 if there is no table.
+    // Part of the kernel arguments, i.e. read with scalar loads.
+    uint32_t bs[RC_BS_INLINE];
+    int flags;  // RC_PF_*
 };
+#define RC_PF_NO_ALT 1  // dev / tests: no alternative chains in the speculation rounds of the search
 
 struct rc_island {
     short from, to;
@@ -83,9 +94,18 @@ struct rc_read_state {
     // the read as 2-bit codes, 16 bases per word, first base most significant (a letter outside
     // ACGT contributes 3, as KmerCode::Append does); cap/16 + 3 words, the last two never written
     uint32_t *pk;
-    // speculation cache of the search (rc_probe4_cached): extension counts of the next RC_SPEC
-    // positions of the keep-base path, fetched in one gather round
-    int *spec_cnt;          // [RC_SPEC*4]
+    // speculation cache of the search (rc_probe4_cached): what one gather round fetched.  Entries
+    // [0, 4 n): the four extension counts of the next n <= RC_SPEC nodes of the keep-base path ("chain 0").
+    // If the round expects the keep base of the chain's last node z to fail (K1 found its k-mer absent)
+    // and z may be substituted, the other lanes fetch, for each of the three alternatives of z, the
+    // keep-base counts of the nodes that follow on that alternative's path: three "alternative chains" of
+    // spec_meta[0] entries each, from entry 4 (z + 1) on.
+    int *spec_cnt;          // [RC_SPEC_ENTRIES]
+    int *spec_meta;         // [4] entries per alternative chain (0 = none), nodes per alternative chain, z
+    // counts of the corrected read's k-mers that a search already fetched, for GetKmerInformation:
+    // [0] n (0 = empty), [1] first window, [2] position p and [3] base c of the one fix these windows
+    // were probed with, [4 .. 4 + n) the counts of windows [1] .. [1] + n - 1
+    int *memo;              // [4 + RC_MEMO_MAX]
     uint64_t *spec_code;    // [RC_SPEC]
     int *spec_inv;          // [RC_SPEC]
     int *spec_ret;          // [RC_SPEC] max(GetBound(max count),1) per cached node
@@ -95,7 +115,9 @@ struct rc_read_state {
     int len, kcnt;
 };
 
-#define RC_SPEC 16
+#define RC_SPEC 16           // nodes of chain 0
+#define RC_SPEC_ENTRIES 128  // probes per gather round: two per lane
+#define RC_MEMO_MAX 32
 
 struct rc_spec_state {
     int n;    // cached positions (0 = empty)
@@ -282,9 +304,9 @@ template <class W>
 RC_HD int rc_front_end(W &w, rc_read_state &S, const rc_run_params &P, int *info)
 {
     *info = 4;
-    if (S.len < P.k) return -1;
-    if (rc_screened(w, S, P.k)) return -1;
-    rc_polya_flags(w, S, P.k);
+    if (S.len < RC_K(P)) return -1;
+    if (rc_screened(w, S, RC_K(P))) return -1;
+    rc_polya_flags(w, S, RC_K(P));
     rc_masked_sorted(w, S);
     int found, prev;
     int strong = rc_initial_strong(w, S, &found, &prev);
@@ -351,6 +373,16 @@ RC_HD int rc_pos_threshold(const rc_cnt4 &cnt, int upper, double e)
     return upper;
 }
 
+RC_HD int rc_max4(const rc_cnt4 &cnt)
+{
+    int mx = 0;
+    mx = cnt.c0 > mx ? cnt.c0 : mx;
+    mx = cnt.c1 > mx ? cnt.c1 : mx;
+    mx = cnt.c2 > mx ? cnt.c2 : mx;
+    mx = cnt.c3 > mx ? cnt.c3 : mx;
+    return mx;
+}
+
 RC_HD rc_kmer rc_extend(rc_kmer km, int k, int dir, int b)
 {
     return dir > 0 ? rc_append(km, k, b) : rc_prepend(km, k, b);
@@ -390,6 +422,25 @@ RC_HD rc_kmer rc_extend_run(const rc_read_state &S, rc_kmer kc, int k, int dir, 
     return r;
 }
 
+// original k-mer of the read starting at base `a`, as the reference builds an anchor (Restart +
+// k Appends, ErrorCorrection.cpp:1140-1142 / :1152-1154): a window of the packed read, the
+// tracker at the last base of the window that is not ACGT.  Wave-uniform: scalar loads.
+template <class W>
+RC_HD rc_kmer rc_anchor(W &w, const rc_read_state &S, int k, int a)
+{
+    rc_kmer kc;
+    const int w0 = a >> 4, sh = 2 * (a & 15);
+    uint64_t x = ((uint64_t)(uint32_t)RC_U(S.pk[w0]) << 32) | (uint32_t)RC_U(S.pk[w0 + 1]);
+    if (sh) x = (x << sh) | ((uint64_t)(uint32_t)RC_U(S.pk[w0 + 2]) >> (32 - sh));
+    kc.code = x >> (64 - 2 * k);
+    const int mw = a >> 6, ms = a & 63;
+    uint64_t im = RC_U64(S.m_inv[mw]) >> ms;
+    if (ms) im |= RC_U64(S.m_inv[mw + 1]) << (64 - ms);
+    if (k < 64) im &= (1ull << k) - 1ull;
+    kc.inv = im ? k - 1 - (63 - rc_clz64(im)) : -1;
+    return kc;
+}
+
 // The four extension counts of search node (kc, pos).  InferPosThreshold and steps (1)/(3) of the
 // reference all look at the same four k-mers, so they are fetched once per node -- and, because a
 // node's successor along the keep-base path is known in advance (the read's own next base), the
@@ -397,10 +448,22 @@ RC_HD rc_kmer rc_extend_run(const rc_read_state &S, rc_kmer kc, int k, int dir, 
 // extends kc by the read's bases pos .. pos+j-1 and probes extension c.  Later nodes hit the cache
 // iff their k-mer state equals the speculated one; anything else (a substitution, a jump, a
 // popped frame) misses and refills from there.  Pure memoisation: results cannot change.
+//
+// What a round speculates on is a matter of efficiency only, and K1 has already told us a lot: while
+// the path is still the read itself, the keep-base count of node j is a count K1 fetched.  Where that
+// count is 0 the keep base WILL fail (every threshold is >= 1), so nodes beyond such a node z are not
+// worth fetching along the keep path; if z may be substituted (:343 / :577), what comes next are its
+// alternatives, and the lanes go to them instead: for each of the three other bases the keep-base
+// counts of the nodes behind z on that base's path ("alternative chains", rc_alt_run) -- one probe per
+// node where no node of that stretch can have substitution candidates of its own (strong-trusted or
+// poly-A positions: the usual case, the k-1 bases behind an isolated error).  A single-error segment
+// then costs one gather round instead of three, and the counts it fetched are the new k-mer counts
+// GetKmerInformation needs afterwards (rc_read_state::memo).
 template <class W>
-RC_HD int rc_probe4_cached(W &w, rc_read_state &S, rc_spec_state &Z, rc_kmer kc, int dir, int pos, int to, int k,
+RC_HD int rc_probe4_cached(W &w, rc_read_state &S, rc_spec_state &Z, const rc_run_params &P, rc_kmer kc, int dir, int pos, int to,
                            rc_cnt4 &cnt)
 {
+    const int k = RC_K(P);
     if (Z.n > 0 && Z.dir == dir) {
         const int j = (pos - Z.pos) * dir;
         if (j >= 0 && j < Z.n && RC_U64(S.spec_code[j]) == kc.code && RC_U(S.spec_inv[j]) == kc.inv) {
@@ -415,16 +478,84 @@ RC_HD int rc_probe4_cached(W &w, rc_read_state &S, rc_spec_state &Z, rc_kmer kc,
     int n = dir > 0 ? (to - pos) : (pos - to + 1);  // nodes left on this side of the segment end
     if (n > RC_SPEC) n = RC_SPEC;
     if (n < 1) n = 1;
-    w.sync();
-    w.for_lanes64(0, 4 * n, [&](int q, int) {
-        const int j = q >> 2, c = q & 3;
-        const rc_kmer kj = rc_extend_run(S, kc, k, dir, pos, j);
-        if (c == 0) {
-            S.spec_code[j] = kj.code;
-            S.spec_inv[j] = kj.inv;
+    // alternative chains?  z = first node of the keep path whose k-mer K1 found absent
+    int am = 0, ana = 0, az = 0, bz = 0;
+    const int a0 = dir > 0 ? pos - k : pos + 1;  // first base of this node's k-mer if it is a k-mer of the read
+    if (!(P.flags & RC_PF_NO_ALT) && kc.inv == -1 && a0 >= 0 && a0 + k <= S.len) {
+        const rc_kmer o = rc_anchor(w, S, k, a0);
+        if (o.code == kc.code && o.inv == -1) {
+            const uint64_t zm = w.ballot64(0, n, [&](int j) { return (dir > 0 ? S.counts[pos + j - k + 1] : S.counts[pos - j]) == 0; });
+            if (zm) {
+                const int z = rc_ctz64(zm), pz = pos + dir * z;
+                bz = RC_U(S.base[pz]);
+                const int pa = RC_U(dir > 0 ? S.polya[pz - k + 1] : S.polya[pz]);
+                const int na = dir > 0 ? to - pz - 1 : pz - to;                  // nodes behind z up to the end of the search
+                int mm = dir > 0 ? S.len - 1 - pz : pz;                          // k-mers on that side that contain base pz ...
+                if (mm > k - 1) mm = k - 1;
+                int m = na > mm ? na : mm;                                       // ... are fetched too (for the memo)
+                if (z + 1 + m > 31) m = 31 - (z + 1);                            // (rc_extend_run takes at most 31 steps)
+                if (4 * (z + 1) + 3 * m > RC_SPEC_ENTRIES) m = (RC_SPEC_ENTRIES - 4 * (z + 1)) / 3;
+                if (bz < 4 && !RC_U(S.strongb[pz]) && !(pa & 1) && na >= 0 && na <= m && m >= 1) {
+                    // no node of the stretch may have substitution candidates of its own
+                    const uint64_t open = w.ballot64(0, na, [&](int j) {
+                        const int q = pz + dir * (1 + j);
+                        return !S.strongb[q] && !((dir > 0 ? S.polya[q - k + 1] : S.polya[q]) & 1);
+                    });
+                    if (!open) {
+                        am = m;
+                        ana = na;
+                        az = z;
+                        n = z + 1;
+                    }
+                }
+            }
         }
-        S.spec_cnt[q] = w.get(rc_extend(kj, k, dir, c));
-    });
+    }
+    w.sync();
+    const int n4 = 4 * n, E = n4 + 3 * am;
+    // entry e: chain 0, node e / 4, extension e % 4 -- or alternative (e - n4) / am, its node (e - n4) % am,
+    // whose k-mer is the read's own k-mer there with base z replaced
+    auto entry = [&](int e, bool *live) -> rc_kmer {
+        rc_kmer km;
+        km.code = 0;
+        km.inv = 0;
+        *live = e < E;
+        if (e < n4) {
+            const int j = e >> 2, c = e & 3;
+            const rc_kmer kj = rc_extend_run(S, kc, k, dir, pos, j);
+            if (c == 0) {
+                S.spec_code[j] = kj.code;
+                S.spec_inv[j] = kj.inv;
+            }
+            km = rc_extend(kj, k, dir, c);
+        } else if (e < E) {
+            const int r = e - n4;
+            const int a = (r >= am ? 1 : 0) + (r >= 2 * am ? 1 : 0), j = r - a * am;
+            const int ca = a + (a >= bz ? 1 : 0);
+            // the k-mer that ends (right) / starts (left) j + 1 positions past z: az + 2 + j steps along the
+            // read from this node, with base z -- now j + 1 places inside -- replaced by ca
+            km = rc_extend_run(S, kc, k, dir, pos, az + 2 + j);
+            if (j + 1 < k) {
+                const int sh = dir > 0 ? 2 * (j + 1) : 2 * (k - 1 - (j + 1));
+                km.code ^= (uint64_t)(bz ^ ca) << sh;
+            }
+        }
+        return km;
+    };
+    // (up to two probes per lane, one after the other: both in flight at once would need the registers of
+    // two bucket reads, which the kernel does not have at 8 waves per SIMD)
+    for (int e0 = 0; e0 < E; e0 += 64) {
+        w.for_lanes64(e0, E, [&](int q, int) {
+            bool live;
+            const rc_kmer km = entry(q, &live);
+            S.spec_cnt[q] = w.get(km);
+        });
+    }
+    if (w.lane == 0) {
+        S.spec_meta[0] = am;
+        S.spec_meta[1] = ana;
+        S.spec_meta[2] = az;
+    }
     w.sync();
     Z.n = n;
     Z.pos = pos;
@@ -436,10 +567,55 @@ RC_HD int rc_probe4_cached(W &w, rc_read_state &S, rc_spec_state &Z, rc_kmer kc,
     return 0;
 }
 
-// terminal bookkeeping, ErrorCorrection.cpp:243-284 / :483-523
+// The node just entered is child `a` (0..2: the alternatives of z in A, C, G, T order) of the cached
+// node z: walk its alternative chain.  A node of the chain is known by its keep-base count x alone, and
+// that is enough where (i) x >= t: the node's threshold, min(max(GetBound(max of the four counts), 1), t),
+// cannot exceed t, so the keep base passes (:302-312 / :539-549); (ii) the position cannot offer
+// substitutions (checked when the chain was fetched), so no frame is pending and nothing else happens at
+// the node; (iii) left searches hand the node's threshold down as the next t (:546): x >= bs[t] means the
+// bound of x, hence of the largest count, reaches t, so the threshold IS t and t stays.  Takes the
+// leading nodes that qualify; the first one that does not is an ordinary node again (cache miss, refill).
+// Returns the number of nodes taken; *full = the whole chain (also when it has no nodes at all).
 template <class W>
-RC_HD void rc_search_terminal(W &w, rc_read_state &S, rc_search_ctx &C, int pos, int t, int fix_cnt,
-                              int bottleneck)
+RC_HD int rc_alt_run(W &w, rc_read_state &S, const rc_run_params &P, int a, int dir, rc_kmer &kc, int &pos, int t, int &bottleneck,
+                     bool *full)
+{
+    const int am = RC_U(S.spec_meta[0]), na = RC_U(S.spec_meta[1]), az = RC_U(S.spec_meta[2]);
+    *full = na == 0;
+    if (na == 0 || t < 1) return 0;
+    uint32_t Bt = 0;
+    if (dir < 0) {
+        if (t >= RC_BS_INLINE || !P.bs[0]) return 0;
+        Bt = P.bs[t];
+    }
+    const int eb = 4 * (az + 1) + a * am;
+    const uint64_t okm = w.ballot64(0, na, [&](int j) {
+        const int x = S.spec_cnt[eb + j];
+        return x >= t && (uint32_t)x >= Bt;
+    });
+    const uint64_t notok = ~okm;
+    int R = notok ? rc_ctz64(notok) : 64;
+    if (R > na) R = na;
+    if (R == 0) return 0;
+    w.for_lanes64(0, R, [&](int j, int) { S.path[pos + dir * j] = -1; });
+    bottleneck = rc_min(bottleneck, w.min_range(S.spec_cnt, eb, eb + R));
+    rc_kmer nk = rc_extend_run(S, kc, RC_K(P), dir, pos, R);
+    kc.code = RC_U64(nk.code);
+    kc.inv = RC_U(nk.inv);
+    pos += dir * R;
+    *full = R == na;
+    w.stat(6, 1);
+    w.stat(7, R == na ? 1 : 0);
+    w.sync();
+    return R;
+}
+
+// terminal bookkeeping, ErrorCorrection.cpp:243-284 / :483-523
+// memo_a >= 0: the path ends with the substitution of the cached node z by its alternative memo_a and that
+// alternative's whole chain -- if the path is accepted, the counts of the k-mers around z go to the memo
+template <class W>
+RC_HD void rc_search_terminal(W &w, rc_read_state &S, rc_search_ctx &C, const rc_spec_state &Z, int k, int pos, int t, int fix_cnt,
+                              int bottleneck, int memo_a)
 {
     if (bottleneck < t) ++fix_cnt;
     if (fix_cnt < C.max_fix_cnt) {
@@ -465,6 +641,29 @@ RC_HD void rc_search_terminal(W &w, rc_read_state &S, rc_search_ctx &C, int pos,
         }
         w.sync();
         for (int i = lo + w.lane; i < hi; i += W::STRIDE) S.best[i] = S.path[i];
+        if (memo_a >= 0) {
+            const int am = RC_U(S.spec_meta[0]), az = RC_U(S.spec_meta[2]);
+            const int pz = Z.pos + C.dir * az, bz = RC_U(S.base[pz]);
+            const int ca = memo_a + (memo_a >= bz ? 1 : 0);
+            const int eb = 4 * (az + 1) + memo_a * am;
+            // windows in ascending order: right search: z's own k-mer starts at pz - k + 1, entry j of the chain at
+            // pz - k + 2 + j; left search: z's own at pz, entry j at pz - 1 - j
+            const int lo_w = C.dir > 0 ? pz - k + 1 : pz - am;
+            w.for_lanes64(0, am + 1, [&](int i, int) {
+                int c;
+                if (C.dir > 0)
+                    c = i == 0 ? S.spec_cnt[4 * az + ca] : S.spec_cnt[eb + i - 1];
+                else
+                    c = i == am ? S.spec_cnt[4 * az + ca] : S.spec_cnt[eb + am - 1 - i];
+                S.memo[4 + i] = c;
+            });
+            if (w.lane == 0) {
+                S.memo[0] = am + 1;
+                S.memo[1] = lo_w;
+                S.memo[2] = pz;
+                S.memo[3] = ca;
+            }
+        }
         w.sync();
         C.max_fix_cnt = fix_cnt;
         C.best_bottleneck = bottleneck;
@@ -492,9 +691,11 @@ template <class W>
 RC_HD int rc_keep_run(W &w, rc_read_state &S, const rc_run_params &P, const rc_spec_state &Z, int j0, int dir, rc_kmer &kc,
                       int &pos, int &t, int fix_cnt, int &bottleneck, int &sp)
 {
-    const int k = P.k;
+    const int k = RC_K(P);
     const int n = Z.n;
-    // per node: ret and the keep-base count
+    // per node: its threshold clamped to the t handed to the run (right searches hand t down unchanged,
+    // so this IS the node's threshold; left searches hand the node's threshold down as the next t, :546,
+    // i.e. a running minimum along the path) and the keep-base count
     w.for_lanes64(j0, n, [&](int jj, int) {
         const int c0 = S.spec_cnt[4 * jj], c1 = S.spec_cnt[4 * jj + 1], c2 = S.spec_cnt[4 * jj + 2], c3 = S.spec_cnt[4 * jj + 3];
         int mx = 0;
@@ -504,7 +705,7 @@ RC_HD int rc_keep_run(W &w, rc_read_state &S, const rc_run_params &P, const rc_s
         mx = c3 > mx ? c3 : mx;
         int ret = rc_bound_i(mx, P.error_rate);
         if (ret < 1) ret = 1;
-        S.spec_ret[jj] = ret;
+        S.spec_ret[jj] = rc_clamp_threshold(ret, t);
         const int b = S.base[Z.pos + dir * jj];
         int kc2 = -1;
         kc2 = b == 0 ? c0 : kc2;
@@ -514,18 +715,13 @@ RC_HD int rc_keep_run(W &w, rc_read_state &S, const rc_run_params &P, const rc_s
         S.spec_keep[jj] = kc2;
     });
     w.sync();
-    // thresholds: right passes t unchanged, left hands the node's threshold down as the next t (:546)
-    w.for_lanes64(j0, n, [&](int jj, int) {
-        int thr;
-        if (dir > 0) {
-            thr = rc_clamp_threshold(S.spec_ret[jj], t);
-        } else {
-            int tt = t;
-            for (int i = j0; i <= jj; ++i) tt = rc_clamp_threshold(S.spec_ret[i], tt);
-            thr = tt;
-        }
-        S.spec_thr[jj] = thr;
-    });
+    if (dir > 0) {
+        w.for_lanes64(j0, n, [&](int jj, int) { S.spec_thr[jj] = S.spec_ret[jj]; });
+    } else {
+        // clamp(ret_j, clamp(ret_j-1, ... t)) = the minimum of the clamped values so far (every ret is >= 1, and a
+        // non-positive t only lets the first node's own value through, which spec_ret already holds)
+        w.prefix_min(S.spec_ret, S.spec_thr, j0, n);
+    }
     w.sync();
     const uint64_t okm = w.ballot64(j0, n, [&](int jj) { return S.spec_keep[jj] >= S.spec_thr[jj]; });
     // leading ones of okm
@@ -577,9 +773,7 @@ RC_HD int rc_keep_run(W &w, rc_read_state &S, const rc_run_params &P, const rc_s
     }
     // the node the run stops at
     const int idx = j0 + R;
-    int bb = bottleneck;
-    for (int i = j0; i < idx; ++i) bb = rc_min(bb, RC_U(S.spec_keep[i]));
-    bottleneck = bb;
+    bottleneck = rc_min(bottleneck, w.min_range(S.spec_keep, j0, idx));
     if (dir < 0) t = RC_U(S.spec_thr[idx - 1]);
     if (idx < n) {
         kc.code = RC_U64(S.spec_code[idx]);
@@ -601,7 +795,7 @@ template <class W>
 RC_HD void rc_search(W &w, rc_read_state &S, const rc_run_params &P, rc_search_ctx &C, rc_kmer kc0,
                      int t0)
 {
-    const int k = P.k;
+    const int k = RC_K(P);
     const int dir = C.dir;
     int sp = 0;
     // current node
@@ -612,6 +806,15 @@ RC_HD void rc_search(W &w, rc_read_state &S, const rc_run_params &P, rc_search_c
     Z.n = 0;
     Z.pos = 0;
     Z.dir = dir;
+    int alt_a = -1;  // >= 0: the node being entered is this alternative of the cached node z (rc_probe4_cached)
+    // is (code, inv, p) the cached node the alternative chains hang off?  then child c of it has a chain
+    auto alt_of = [&](uint64_t code, int inv, int p, int c) -> int {
+        if (Z.n <= 0 || RC_U(S.spec_meta[0]) <= 0) return -1;
+        const int az = RC_U(S.spec_meta[2]);
+        if (p != Z.pos + dir * az || RC_U64(S.spec_code[az]) != code || RC_U(S.spec_inv[az]) != inv) return -1;
+        const int bz = RC_U(S.base[p]);
+        return c < bz ? c : c - 1;
+    };
 
     for (;;) {
         w.phase(8);
@@ -633,6 +836,7 @@ RC_HD void rc_search(W &w, rc_read_state &S, const rc_run_params &P, rc_search_c
             S.path[f.pos] = (signed char)c;
             w.sync();
             ++C.trial_cnt;
+            alt_a = alt_of(f.code, f.inv, f.pos, c);
             kc = rc_extend(fk, k, dir, c);
             pos = f.pos + dir;
             t = dir > 0 ? f.t : f.threshold;
@@ -655,18 +859,26 @@ RC_HD void rc_search(W &w, rc_read_state &S, const rc_run_params &P, rc_search_c
         }
         if (fix_cnt > C.max_fix_cnt) {
             have = false;
+            alt_a = -1;
             continue;
+        }
+        int memo_a = -1;
+        if (alt_a >= 0) {  // down the alternative's chain (no node of it changes trial_cnt or fix_cnt: the gate above holds for all)
+            bool full;
+            rc_alt_run(w, S, P, alt_a, dir, kc, pos, t, bottleneck, &full);
+            if (full) memo_a = alt_a;
+            alt_a = -1;
         }
         if (dir > 0 ? (pos >= C.to) : (pos < C.to)) {
             w.phase(14);
-            rc_search_terminal(w, S, C, pos, t, fix_cnt, bottleneck);
+            rc_search_terminal(w, S, C, Z, k, pos, t, fix_cnt, bottleneck, memo_a);
             have = false;
             continue;
         }
 
         rc_cnt4 cnt;
         w.phase(9);
-        const int j0 = rc_probe4_cached(w, S, Z, kc, dir, pos, C.to, k, cnt);
+        const int j0 = rc_probe4_cached(w, S, Z, P, kc, dir, pos, C.to, cnt);
         w.phase(10);
         // descend along "keep the base" for as many cached nodes as take that branch
         if (rc_keep_run(w, S, P, Z, j0, dir, kc, pos, t, fix_cnt, bottleneck, sp) > 0) {
@@ -753,6 +965,7 @@ RC_HD void rc_search(W &w, rc_read_state &S, const rc_run_params &P, rc_search_c
             mask &= ~(1 << c);
             S.path[pos] = (signed char)c;
             ++C.trial_cnt;
+            alt_a = alt_of(kc.code, kc.inv, pos, c);
             nkc = rc_extend(kc, k, dir, c);
             npos = pos + dir;
             nt = dir > 0 ? t : threshold;
@@ -788,7 +1001,7 @@ RC_HD void rc_search(W &w, rc_read_state &S, const rc_run_params &P, rc_search_c
                     if (i == pos)
                         cn = cnt;
                     else
-                        rc_probe4_cached(w, S, Z, tmp, dir, i, C.to, k, cn);
+                        rc_probe4_cached(w, S, Z, P, tmp, dir, i, C.to, cn);
                     thr = RC_U(rc_pos_threshold(cn, t, P.error_rate));
                     int bb = RC_U(S.base[i]);
                     tmp = rc_append(tmp, k, bb);
@@ -808,7 +1021,7 @@ RC_HD void rc_search(W &w, rc_read_state &S, const rc_run_params &P, rc_search_c
                     if (i == pos)
                         cn = cnt;
                     else
-                        rc_probe4_cached(w, S, Z, tmp, dir, i, C.to, k, cn);
+                        rc_probe4_cached(w, S, Z, P, tmp, dir, i, C.to, cn);
                     thr = RC_U(rc_pos_threshold(cn, t, P.error_rate));
                     int bb = RC_U(S.base[i]);
                     tmp = rc_prepend(tmp, k, bb);
@@ -836,25 +1049,6 @@ RC_HD void rc_search(W &w, rc_read_state &S, const rc_run_params &P, rc_search_c
     }
 }
 
-// original k-mer of the read starting at base `a`, as the reference builds an anchor (Restart +
-// k Appends, ErrorCorrection.cpp:1140-1142 / :1152-1154): a window of the packed read, the
-// tracker at the last base of the window that is not ACGT.  Wave-uniform: scalar loads.
-template <class W>
-RC_HD rc_kmer rc_anchor(W &w, const rc_read_state &S, int k, int a)
-{
-    rc_kmer kc;
-    const int w0 = a >> 4, sh = 2 * (a & 15);
-    uint64_t x = ((uint64_t)(uint32_t)RC_U(S.pk[w0]) << 32) | (uint32_t)RC_U(S.pk[w0 + 1]);
-    if (sh) x = (x << sh) | ((uint64_t)(uint32_t)RC_U(S.pk[w0 + 2]) >> (32 - sh));
-    kc.code = x >> (64 - 2 * k);
-    const int mw = a >> 6, ms = a & 63;
-    uint64_t im = RC_U64(S.m_inv[mw]) >> ms;
-    if (ms) im |= RC_U64(S.m_inv[mw + 1]) << (64 - ms);
-    if (k < 64) im &= (1ull << k) - 1ull;
-    kc.inv = im ? k - 1 - (63 - rc_clz64(im)) : -1;
-    return kc;
-}
-
 // ErrorCorrection (ErrorCorrection.cpp:682-1480).  On entry base[], counts[], polya[] are
 // loaded; strong0/info0 are this read's rc_front_end() results (from the threshold kernel) and
 // pair_t is min(strong of both mates) or -1.  Returns the reference's return value; best[]
@@ -863,8 +1057,9 @@ template <class W>
 RC_HD int rc_correct_read(W &w, rc_read_state &S, const rc_run_params &P, int pair_t, int strong0,
                           int info0)
 {
-    const int k = P.k;
+    const int k = RC_K(P);
     const int len = S.len, kcnt = S.kcnt;
+    if (w.lane == 0) S.memo[0] = 0;
     if (len < k) return -1;   // :713
     if (info0 & 4) return -1; // screens, :735-755
     w.trace_passed();         // -verbose prints "Before correction" from here on, :759-770
@@ -1036,6 +1231,9 @@ RC_HD int rc_correct_read(W &w, rc_read_state &S, const rc_run_params &P, int pa
 
         if (longest == -1) return -1;  // :1107
         if (longest == kcnt) return 0; // :1110
+#if defined(RC_EXP_STOP) && RC_EXP_STOP == 3  // dev builds (tools/exp_stops.sh): cost of the phases up to here
+        return 0;
+#endif
 
         for (i = w.lane; i < len; i += W::STRIDE) S.best[i] = -1;
         w.sync();
@@ -1137,6 +1335,9 @@ RC_HD int rc_correct_read(W &w, rc_read_state &S, const rc_run_params &P, int pa
 
     // ---- post filters (positions list in v[]) ----
     w.phase(5);
+#if defined(RC_EXP_STOP) && RC_EXP_STOP == 4
+    return total_fix;
+#endif
     int cnt = 0;  // positions with a fix on a non-N base, ascending, :1296-1303
     for (int b0 = 0; b0 < len; b0 += 64) {
         const uint64_t fm = w.ballot64(b0, len, [&](int q) { return S.base[q] != 4 && S.best[q] != -1; });
@@ -1260,7 +1461,7 @@ template <class W>
 RC_HD void rc_kmer_info(W &w, rc_read_state &S, const rc_run_params &P, int ret, int *l, int *m,
                         int *h)
 {
-    const int k = P.k;
+    const int k = RC_K(P);
     *l = *m = *h = 0;
     if (S.kcnt <= 0) return;
     // fixed positions (their base is now one of ACGT, so they leave the invalid mask)
@@ -1271,6 +1472,17 @@ RC_HD void rc_kmer_info(W &w, rc_read_state &S, const rc_run_params &P, int ret,
         S.m_x[c] = fm;
     }
     w.sync();
+    // counts a search already fetched for the windows around its one fix p -> c: good for a window whose only
+    // fix in the final result is that one (the count of a k-mer is a function of its letters)
+    int memo_n = 0, memo_lo = 0, memo_p = 0;
+    if (ret > 0) {
+        memo_n = RC_U(S.memo[0]);
+        if (memo_n > 0) {
+            memo_lo = RC_U(S.memo[1]);
+            memo_p = RC_U(S.memo[2]);
+            if (RC_U(S.best[memo_p]) != RC_U(S.memo[3])) memo_n = 0;
+        }
+    }
     int nvalid = 0;
     uint32_t lo = 0xFFFFFFFFu, hi = 0;
     for (int b0 = 0; b0 < S.kcnt; b0 += 64) {
@@ -1282,9 +1494,14 @@ RC_HD void rc_kmer_info(W &w, rc_read_state &S, const rc_run_params &P, int ret,
             uint32_t c = 0xFFFFFFFFu;
             if ((vm >> ln) & 1ull) {
                 int cc;
-                if (ret > 0 && rc_window(S.m_x, q, k) != 0)  // window holds a fix: probe the new k-mer
-                    cc = w.lookup(rc_code_at(S.pk, q, k));
-                else
+                const uint64_t fw = ret > 0 ? rc_window(S.m_x, q, k) : 0ull;
+                if (fw != 0) {  // window holds a fix: the new k-mer's count, from the memo or the table
+                    const int d = memo_p - q;
+                    if (q >= memo_lo && q < memo_lo + memo_n && d >= 0 && d < k && fw == (1ull << d))
+                        cc = S.memo[4 + q - memo_lo];
+                    else
+                        cc = w.lookup(rc_code_at(S.pk, q, k));
+                } else
                     cc = S.counts[q];
                 if (cc == 0) cc = 1;
                 c = (uint32_t)cc;

@@ -106,6 +106,8 @@ struct rc_ctx {
     rc_dbuf sel_tmp;  // rocPRIM scratch of the compaction
     rc_dbuf loc_a, loc_list;  // locality order of a batch (rc_launch_locality_order)
     bool env_no_fuse = false;  // RC_NO_FUSE=1 (dev): separate probe and threshold kernels in locality order too
+    bool env_k3_generic = false;  // RC_K3_GENERIC=1 (dev / tests): the any-k instance of k_correct even where a compiled-for-k one exists
+    bool env_no_alt = false;  // RC_NO_ALT=1 (dev / tests): rc_run_params::flags |= RC_PF_NO_ALT
     int locality_mode = 0;  // 0: large batches over large tables, 1: always (RC_LOCALITY=force), -1: never (RC_LOCALITY=off)
     bool cls_ready = false;  // cls / worklist describe this batch
     size_t work_stride = 0;  // uint32 entries between the sections of worklist

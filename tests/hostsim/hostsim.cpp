@@ -17,6 +17,7 @@ namespace {
 
 struct HostWave {
     static const int STRIDE = 1;
+    static const int KT = 0;
     int lane = 0;
     const rco_table *tab;
     int k;
@@ -50,6 +51,20 @@ struct HostWave {
     int reduce_add(int x) { return x; }
     uint32_t wave_min_u32(uint32_t x) { return x; }
     uint32_t wave_max_u32(uint32_t x) { return x; }
+    void prefix_min(const int *in, int *out, int j0, int n)
+    {
+        int m = 2147483647;
+        for (int j = j0; j < n; ++j) {
+            m = in[j] < m ? in[j] : m;
+            out[j] = m;
+        }
+    }
+    int min_range(const int *a, int lo, int hi)
+    {
+        int m = 2147483647;
+        for (int i = lo; i < hi; ++i) m = a[i] < m ? a[i] : m;
+        return m;
+    }
     int get(rc_kmer km)
     {
         ++gets;
@@ -86,7 +101,7 @@ struct Buffers {
     std::vector<rc_segment> seg;
     std::vector<uint64_t> ma, mt, mn, mi, mx, scode;
     std::vector<uint32_t> pk;
-    std::vector<int> scnt, sinv, sret, skeep, sthr, smask;
+    std::vector<int> scnt, sinv, sret, skeep, sthr, smask, smeta, memo;
     rc_read_state S;
     explicit Buffers(int cap)
     {
@@ -111,7 +126,11 @@ struct Buffers {
         scode.resize(RC_SPEC);
         pk.resize(cap / 16 + 3);
         S.pk = pk.data();
-        scnt.resize(RC_SPEC * 4);
+        scnt.resize(RC_SPEC_ENTRIES);
+        smeta.resize(4);
+        memo.resize(4 + RC_MEMO_MAX);
+        S.spec_meta = smeta.data();
+        S.memo = memo.data();
         sinv.resize(RC_SPEC);
         sret.resize(RC_SPEC);
         skeep.resize(RC_SPEC);
@@ -180,6 +199,10 @@ void hostsim_correct_batch(const rco_params *p, const rco_table *t, rco_batch *b
     P.max_fix_per_k = p->max_fix_per_k;
     P.error_rate = p->error_rate;
     P.bad_qual = (int)(signed char)p->bad_qual;
+    std::vector<uint32_t> bsteps(RC_BOUND_STEPS);
+    rc_bound_steps_build(P.error_rate, bsteps.data());
+    for (int v = 0; v < RC_BS_INLINE; ++v) P.bs[v] = bsteps[v];
+    P.flags = getenv("HOSTSIM_NO_ALT") ? RC_PF_NO_ALT : 0;
     Buffers B(RC_MAX_READ_LENGTH + 64);
     HostWave w;
     w.tab = t;
@@ -231,7 +254,7 @@ void hostsim_correct_batch(const rco_params *p, const rco_table *t, rco_batch *b
         st->probes4 = w.gets;
         st->probes1 = 0;
         st->max_stack = w.max_sp;
-        if (getenv("HOSTSIM_STATS")) fprintf(stderr, "keep_run calls=%ld sumR=%ld sum_avail=%ld refills=%ld gap_attempts=%ld gap_probes=%ld pushes=%ld pops=%ld reads=%ld\n", w.stats[0], w.stats[1], w.stats[2], w.stats[3], w.stats[4], w.stats[5], w.pushes, w.pops, (long)total);
+        if (getenv("HOSTSIM_STATS")) fprintf(stderr, "keep_run calls=%ld sumR=%ld sum_avail=%ld refills=%ld gap_attempts=%ld gap_probes=%ld pushes=%ld pops=%ld reads=%ld alt_runs=%ld alt_full=%ld gets=%ld\n", w.stats[0], w.stats[1], w.stats[2], w.stats[3], w.stats[4], w.stats[5], w.pushes, w.pops, (long)total, w.stats[6], w.stats[7], w.gets);
         st->reads = (long)total;
     }
 }
