@@ -570,3 +570,158 @@ def test_locality_order_does_not_change_results(oracle, name, monkeypatch):
     for w, g, what in zip(want, got, ["ret", "l", "m", "h", "seq1", "seq2"]):
         assert np.array_equal(w, g), "%s differs on %s in locality order" % (what, name)
     ctx.close()
+
+
+def _oracle_on_pairs(oracle, ctx, k, mfk, rate, bad_q, seq, qual, n_reads, L, pairs):
+    """The oracle on the first `pairs` pairs of a mode-1 device batch (all first mates, then all second
+    mates), with the table exported from the context.  Returns ((ret, l, m, h), arena1, arena2)."""
+    codes, counts = ctx.table_export()
+    T = oracle.Table(k, len(codes))
+    T.put_many(codes, counts)
+    P = oracle.make_params(k, mfk, rate, bad_q)
+    half = n_reads // 2
+    nb, b2 = pairs * (L + 1), half * (L + 1)
+    a1, q1 = seq[:nb].cpu().numpy().copy(), qual[:nb].cpu().numpy().copy()
+    a2, q2 = seq[b2:b2 + nb].cpu().numpy().copy(), qual[b2:b2 + nb].cpu().numpy().copy()
+    off = (np.arange(pairs + 1, dtype=np.int64) * (L + 1)).astype(np.uint32)
+    r = oracle.correct_batch(P, T, 1, a1, q1, off, a2, q2, off, threads=8)
+    return r, a1, a2
+
+
+@pytest.mark.gpu
+def test_default_dispatch_at_a_size_that_selects_the_timed_path(oracle):
+    """The kernels bench.py times -- k_unit_key -> radix sort -> k_probe_threshold_list on a PACKED table, the
+    work-list driven k_correct compiled for k = 23 -- are what rc_correct_device picks BY ITSELF for >= 2^18
+    reads over a table beyond 128 MB (no environment knob here).  400 k paired reads over a 6.6 M-base
+    transcriptome: the first 10 000 pairs against the oracle, 100 000 more through the batch-split property."""
+    import torch
+    import bench as B
+    dev = torch.device("cuda", 0)
+    n, L, k = 400_000, 150, 23
+    cnt_reads = 1_600_000
+    seq_all, qual_all = B.synth_reads_gpu(777001, cnt_reads, L, 4400, 1500, 0.8, 0.005, dev, paired=True)
+    ctx = rcorrector_amd.Context(k=k, device=0)
+    ctx.count_reads_device(seq_all, seq_all.numel(), 2)
+    st = ctx.table_stats()
+    assert st["bytes"] > (128 << 20) and ctx.table_layout() == 1, st
+    rate = ctx.estimate_error_rate(0.95)
+    ctx.set_run_params(rate, b"H")
+    # mode 1 batch of n reads: first mates [0, n/2), second mates [n/2, n) -- cut out of the generator's halves
+    half_all, half = cnt_reads // 2, n // 2
+    rows = seq_all.view(cnt_reads, L + 1)
+    qrows = qual_all.view(cnt_reads, L + 1)
+    seq = torch.cat([rows[:half], rows[half_all:half_all + half]]).reshape(-1).contiguous()
+    qual = torch.cat([qrows[:half], qrows[half_all:half_all + half]]).reshape(-1).contiguous()
+    off = (torch.arange(n + 1, device=dev, dtype=torch.int64) * (L + 1)).to(torch.int32)
+    work = seq.clone()
+    res = [torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(4)]
+    ctx.profile(True)
+    ctx.profile_reset()
+    ctx.correct_device(1, n, work.numel(), L, work, qual, off, *res)
+    ctx.sync()
+    _, launches = ctx.profile_get(0)
+    _, thr_launches = ctx.profile_get(1)
+    ctx.profile(False)
+    assert launches == 1 and thr_launches == 0, "the fused probe + threshold kernel of the locality order did not run"
+    pairs = 10_000
+    (ret, l, m, h), a1, a2 = _oracle_on_pairs(oracle, ctx, k, 4, rate, b"H", seq, qual, n, L, pairs)
+    for got, want in zip(res, (ret, l, m, h)):
+        g = got.cpu().numpy()
+        assert np.array_equal(g[:pairs], want[:pairs]) and np.array_equal(g[half:half + pairs], want[pairs:])
+    nb, b2 = pairs * (L + 1), half * (L + 1)
+    assert np.array_equal(work[:nb].cpu().numpy(), a1) and np.array_equal(work[b2:b2 + nb].cpu().numpy(), a2)
+    assert (ret > 0).sum() > 2000
+    # batch-split property: 100 k other pairs as a batch of their own (small batch: arena-order probe kernel,
+    # separate threshold kernel) give what they gave inside the large one
+    lo, m2 = 100_000, 100_000
+    s2 = torch.cat([rows[lo:lo + m2], rows[half_all + lo:half_all + lo + m2]]).reshape(-1).contiguous()
+    q2 = torch.cat([qrows[lo:lo + m2], qrows[half_all + lo:half_all + lo + m2]]).reshape(-1).contiguous()
+    o2 = (torch.arange(2 * m2 + 1, device=dev, dtype=torch.int64) * (L + 1)).to(torch.int32)
+    r2 = [torch.zeros(2 * m2, dtype=torch.int32, device=dev) for _ in range(4)]
+    ctx.correct_device(1, 2 * m2, s2.numel(), L, s2, q2, o2, *r2)
+    ctx.sync()
+    for a, b in zip(res, r2):
+        assert torch.equal(a[lo:lo + m2], b[:m2]) and torch.equal(a[half + lo:half + lo + m2], b[m2:])
+    wrows = work.view(n, L + 1)
+    srows = s2.view(2 * m2, L + 1)
+    assert torch.equal(wrows[lo:lo + m2], srows[:m2]) and torch.equal(wrows[half + lo:half + lo + m2], srows[m2:])
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_k31_maxcork8_on_a_packed_table_with_extension_bits(oracle):
+    """BASELINE configs[4]'s code path at test size: k = 31, -maxcorK 8, 5 % substitutions over a table of
+    >= 17 M entries, which the build lays out PACKED with remainder extension bits (ext > 0: the k = 31
+    instance of k_correct and the EXT probe kernels).  10 000 reads against the oracle."""
+    import torch
+    import bench as B
+    dev = torch.device("cuda", 0)
+    n, L, k = 10_000, 150, 31
+    seq, qual = B.synth_reads_gpu(777002, 200_000, L, 300, 1500, 0.8, 0.05, dev)
+    ctx = rcorrector_amd.Context(k=k, max_fix_per_k=8, device=0)
+    ctx.count_reads_device(seq, seq.numel(), 2)
+    codes, counts = ctx.table_export()
+    # pad the table with k-mers no read holds, so that it has the size (and so the layout) of a real one
+    rng = np.random.Generator(np.random.PCG64(31))
+    mask = np.uint64((1 << 62) - 1)
+    fwd = rng.integers(0, 1 << 62, size=17_500_000, dtype=np.uint64) & mask
+    pad = np.unique(np.minimum(fwd, _revcomp_codes(fwd, k)))
+    pad = pad[~np.isin(pad, codes)]
+    all_codes = np.concatenate([codes, pad])
+    all_counts = np.concatenate([counts, rng.integers(2, 200, size=len(pad)).astype(np.int32)])
+    ctx.table_build(all_codes, all_counts)
+    st = ctx.table_stats()
+    assert ctx.table_layout() == 1 and st["entries"] >= 17_000_000
+    assert st["buckets"] < (1 << (2 * k - 32)), "the table is large enough to need no extension bits: not the path under test"
+    rate = 0.01
+    ctx.set_run_params(rate, b"H")
+    nb = n * (L + 1)
+    off = (torch.arange(n + 1, device=dev, dtype=torch.int64) * (L + 1)).to(torch.int32)
+    work = seq[:nb].clone()
+    res = [torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(4)]
+    ctx.correct_device(0, n, nb, L, work, qual[:nb].contiguous(), off, *res)
+    ctx.sync()
+    T = oracle.Table(k, len(all_codes))
+    T.put_many(all_codes, all_counts)
+    P = oracle.make_params(k, 8, rate, b"H")
+    arena = seq[:nb].cpu().numpy().copy()
+    qa = qual[:nb].cpu().numpy().copy()
+    ho = (np.arange(n + 1, dtype=np.int64) * (L + 1)).astype(np.uint32)
+    want = oracle.correct_batch(P, T, 0, arena, qa, ho, threads=8)
+    for got, w in zip(res, want):
+        assert np.array_equal(got.cpu().numpy(), w)
+    assert np.array_equal(work.cpu().numpy(), arena)
+    assert (want[0] > 0).sum() > 3000 and (want[0] < 0).sum() > 100
+    ctx.close()
+
+
+KNOBS = [{"RC_TABLE_LAYOUT": "wide"}, {"RC_TABLE_LOAD": "0.85"}, {"RC_TABLE_LOAD": "0.25"}, {"RC_LOCALITY": "force"},
+         {"RC_NO_FUSE": "1", "RC_LOCALITY": "force"}, {"RC_K2_WAVE_PER_READ": "1"}, {"RC_NO_CLASSIFY": "1"},
+         {"RC_NO_ALT": "1"}, {"RC_K3_GENERIC": "1"}, {"RC_K3_GENERIC": "1", "RC_NO_ALT": "1", "RC_LOCALITY": "force"}]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("knobs", KNOBS, ids=lambda d: "+".join("%s=%s" % kv for kv in d.items()))
+@pytest.mark.parametrize("name", ["se_k23", "pe_var", "k31_mc8"])
+def test_every_alternative_code_path_gives_the_oracles_results(oracle, name, knobs, monkeypatch):
+    """tools/knob_matrix.sh as a test: the library's alternative code paths (slot layout, load factor, list-driven and
+    unfused probe kernels on small batches, wave-per-read threshold kernel, no classification, no alternative chains
+    in the search, the any-k instance of k_correct) are each a pure re-arrangement of the same computation."""
+    for kk, v in knobs.items():
+        monkeypatch.setenv(kk, v)
+    d = datasets.make(name)
+    want = datasets.run_oracle(oracle, d)
+    ctx = rcorrector_amd.Context(k=d["k"], max_fix_per_k=d["mfk"], device=0)
+    ctx.table_build(d["keys"], d["counts"])
+    ctx.set_run_params(d["rate"], b"H")
+    a, off = oracle.pack_reads(d["seqs1"])
+    qa, _ = oracle.pack_reads(d["quals1"])
+    if d["mode"] == 1:
+        a2, off2 = oracle.pack_reads(d["seqs2"])
+        qa2, _ = oracle.pack_reads(d["quals2"])
+        got = ctx.correct_batch(1, a, qa, off, a2, qa2, off2) + (a, a2)
+    else:
+        got = ctx.correct_batch(d["mode"], a, qa, off) + (a,)
+    for w, g, what in zip(want, got, ["ret", "l", "m", "h", "seq1", "seq2"]):
+        assert np.array_equal(w, g), "%s differs on %s under %s" % (what, name, knobs)
+    ctx.close()
