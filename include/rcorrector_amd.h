@@ -47,6 +47,10 @@ typedef struct {
 rc_ctx *rc_create(const rc_config *cfg, char *errbuf, size_t errbuf_len);
 void rc_destroy(rc_ctx *ctx);
 const char *rc_last_error(const rc_ctx *ctx);
+/* the NUMA node of the host the context's GPU hangs off (its PCI device's numa_node), or -1 if the system does
+ * not say: a host that feeds the GPU from page-locked buffers wants its threads and those buffers there
+ * (the reference has no counterpart: its workers are plain pthreads, main.cpp:479-483) */
+int rc_device_numa_node(const rc_ctx *ctx);
 
 /* ---- k-mer table (Store.h:17-88) ------------------------------------------------------------ */
 /* replaces the load loop main.cpp:294-308 when the caller has already parsed the dump:

@@ -10,7 +10,7 @@ CSRC = os.path.join(HERE, "csrc")
 
 # every function include/rcorrector_amd.h declares (tests check the .so exports all of them)
 ABI_SYMBOLS = [
-    "rc_create", "rc_destroy", "rc_last_error",
+    "rc_create", "rc_destroy", "rc_last_error", "rc_device_numa_node",
     "rc_table_build", "rc_table_build_device", "rc_table_load_jfdump",
     "rc_table_count_begin", "rc_table_count_add", "rc_table_count_add_device", "rc_table_count_finish",
     "rc_table_count_reads_device", "rc_table_write_jfdump", "rc_table_share", "rc_table_replicate", "rc_table_lookup", "rc_table_export", "rc_table_digest", "rc_table_layout", "rc_table_stats",

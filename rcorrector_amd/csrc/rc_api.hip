@@ -202,6 +202,23 @@ void rc_destroy(rc_ctx *c)
 
 const char *rc_last_error(const rc_ctx *ctx) { return ctx ? ctx->err : g_create_err; }
 
+int rc_device_numa_node(const rc_ctx *ctx)
+{
+    if (!ctx) return -1;
+    char bus[64];
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, ctx->device) != hipSuccess) return -1;
+    for (char *p = bus; *p; ++p)
+        if (*p >= 'A' && *p <= 'F') *p = (char)(*p - 'A' + 'a');  // sysfs spells the address in lower case
+    char path[160];
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
+    FILE *fp = fopen(path, "r");
+    if (!fp) return -1;
+    int node = -1;
+    if (fscanf(fp, "%d", &node) != 1) node = -1;
+    fclose(fp);
+    return node;
+}
+
 // ---- table ---------------------------------------------------------------------------------
 int rc_table_build_device(rc_ctx *ctx, uint64_t *d_codes, const int32_t *d_counts, size_t n)
 {

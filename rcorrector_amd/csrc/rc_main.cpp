@@ -21,6 +21,7 @@
 // -write-dump FILE keeps the k-mer table as jellyfish-dump text; without -c the k-mers are counted here.
 #include <fcntl.h>
 #include <malloc.h>
+#include <sched.h>
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -54,6 +55,7 @@ static int g_threads = 8;
 
 static double g_w_reader = 0, g_w_writer = 0, g_w_worker = 0;  // RC_TIMING: time blocked on the neighbouring stage
 static double g_t_read = 0, g_t_pack = 0, g_t_gpu = 0, g_t_format = 0, g_t_write = 0;  // RC_TIMING stage totals (thread-seconds)
+static double g_t_fill = 0, g_t_nl = 0, g_t_idx = 0;  // RC_TIMING: inside take_records (all files): pread, newline scan, line index
 
 static double now_s()
 {
@@ -66,7 +68,111 @@ static void die(const char *fmt, ...)
     va_start(ap, fmt);
     vfprintf(stderr, fmt, ap);
     va_end(ap);
-    exit(1);
+    fflush(NULL);
+    _exit(1);  // (not exit(): it would join the helper threads from whichever thread failed)
+}
+
+// Persistent helper threads for the data-parallel pieces of the host pipeline (block reads, newline scans,
+// packing, formatting): creating and joining a few dozen threads per call, dozens of calls per batch, costs more
+// than some of the pieces themselves.  run(T, fn) executes fn(0) .. fn(T-1), fn(0) on the calling thread, and
+// returns when all are done; any number of threads may call it at once (the helpers serve one queue).
+#include <atomic>
+#include <functional>
+struct Pool {
+    struct Call {
+        std::atomic<size_t> left{0};
+        std::mutex m;
+        std::condition_variable c;
+    };
+    struct Task {
+        const std::function<void(size_t)> *fn;
+        size_t idx;
+        Call *call;
+    };
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Task> q;
+    std::vector<std::thread> th;
+    bool stop = false;
+    void start(size_t n)
+    {
+        for (size_t i = th.size(); i < n; ++i)
+            th.emplace_back([this]() {
+                for (;;) {
+                    Task t;
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [&] { return stop || !q.empty(); });
+                        if (q.empty()) return;
+                        t = q.front();
+                        q.pop_front();
+                    }
+                    (*t.fn)(t.idx);
+                    if (t.call->left.fetch_sub(1) == 1) {
+                        std::lock_guard<std::mutex> lk(t.call->m);
+                        t.call->c.notify_all();
+                    }
+                }
+            });
+    }
+    void run(size_t T, const std::function<void(size_t)> &fn)
+    {
+        if (T <= 1 || th.empty()) {
+            for (size_t t = 0; t < T; ++t) fn(t);
+            return;
+        }
+        Call call;
+        call.left = T - 1;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (size_t t = 1; t < T; ++t) q.push_back(Task{&fn, t, &call});
+        }
+        cv.notify_all();
+        fn(0);
+        std::unique_lock<std::mutex> lk(call.m);
+        call.c.wait(lk, [&] { return call.left.load() == 0; });
+    }
+    ~Pool()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        cv.notify_all();
+        for (auto &x : th) x.join();
+    }
+};
+static Pool g_pool;
+
+// binds the calling thread (and the threads it creates from now on) to the CPUs of one NUMA node; memory it
+// touches first then comes from that node too.  Returns false if the node's CPU list cannot be read.
+static bool bind_to_numa_node(int node)
+{
+    char path[96];
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    FILE *fp = fopen(path, "r");
+    if (!fp) return false;
+    char buf[4096];
+    const bool ok = fgets(buf, sizeof buf, fp) != nullptr;
+    fclose(fp);
+    if (!ok) return false;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    int n_cpu = 0;
+    for (char *p = buf; *p;) {  // "0-63,128-191"
+        char *e;
+        long a = strtol(p, &e, 10);
+        if (e == p) break;
+        long b = a;
+        if (*e == '-') b = strtol(e + 1, &e, 10);
+        for (long c = a; c <= b && c < CPU_SETSIZE; ++c) {
+            CPU_SET((int)c, &set);
+            ++n_cpu;
+        }
+        p = *e == ',' ? e + 1 : e;
+        if (*e != ',') break;
+    }
+    return n_cpu > 0 && sched_setaffinity(0, sizeof set, &set) == 0;
 }
 
 template <class F>
@@ -77,9 +183,7 @@ static void parallel_for(size_t n, F fn)
         fn((size_t)0, n);
         return;
     }
-    std::vector<std::thread> th;
-    for (size_t t = 0; t < T; ++t) th.emplace_back([=, &fn]() { fn(n * t / T, n * (t + 1) / T); });
-    for (auto &x : th) x.join();
+    g_pool.run(T, [&](size_t t) { fn(n * t / T, n * (t + 1) / T); });
 }
 
 // growable byte buffer without value-initialisation (a std::vector<char> zero-fills on resize,
@@ -224,13 +328,7 @@ struct Source {
             }
             done[t] = at - lo;
         };
-        if (T == 1) {
-            rd(0);
-        } else {
-            std::vector<std::thread> th;
-            for (size_t t = 0; t < T; ++t) th.emplace_back(rd, t);
-            for (auto &x : th) x.join();
-        }
+        g_pool.run(T, rd);
         for (size_t t = 0; t < T; ++t) {
             got += done[t];
             if (done[t] < want * (t + 1) / T - want * t / T) {  // the file ended inside this slice
@@ -265,19 +363,16 @@ static void find_newlines(const char *p, size_t lo, size_t hi, std::vector<uint3
         return;
     }
     std::vector<std::vector<uint32_t>> part(T);
-    std::vector<std::thread> th;
-    for (size_t t = 0; t < T; ++t)
-        th.emplace_back([&, t]() {
-            const size_t a = lo + (hi - lo) * t / T, b = lo + (hi - lo) * (t + 1) / T;
-            part[t].reserve((b - a) / 32 + 16);
-            for (size_t at = a; at < b;) {
-                const char *q = (const char *)memchr(p + at, '\n', b - at);
-                if (!q) break;
-                part[t].push_back((uint32_t)(q - p));
-                at = (size_t)(q - p) + 1;
-            }
-        });
-    for (auto &x : th) x.join();
+    g_pool.run(T, [&](size_t t) {
+        const size_t a = lo + (hi - lo) * t / T, b = lo + (hi - lo) * (t + 1) / T;
+        part[t].reserve((b - a) / 32 + 16);
+        for (size_t at = a; at < b;) {
+            const char *q = (const char *)memchr(p + at, '\n', b - at);
+            if (!q) break;
+            part[t].push_back((uint32_t)(q - p));
+            at = (size_t)(q - p) + 1;
+        }
+    });
     size_t total = nl.size();
     for (auto &v : part) total += v.size();
     nl.reserve(total);
@@ -299,7 +394,9 @@ static void take_records(Source &s, size_t max_records, int lines_per_record, Bl
     if (have) memcpy(b.text.p, s.left.p, have);
     s.left_len = 0;
     for (;;) {
+        const double tn0 = now_s();
         find_newlines(b.text.p, scanned, have, nl);
+        g_t_nl += now_s() - tn0;
         scanned = have;
         if (nl.size() >= want_lines) break;
         if (s.eof) break;
@@ -311,7 +408,9 @@ static void take_records(Source &s, size_t max_records, int lines_per_record, Bl
         }
         want = std::min<size_t>(want, ((size_t)1 << 31) - have + 1);
         b.text.need(have + want + 64);
+        const double tf0 = now_s();
         have += s.fill(b.text.p + have, want);
+        g_t_fill += now_s() - tf0;
     }
     size_t n_lines = std::min(nl.size(), want_lines), end;
     if (nl.size() >= want_lines) {
@@ -343,11 +442,13 @@ static void take_records(Source &s, size_t max_records, int lines_per_record, Bl
     }
     s.left_len = have - end;
     if (b.records == 0) return;
+    const double ti0 = now_s();
     b.line.resize(n_lines + 1);
     b.line[0] = 0;
     parallel_for(n_lines, [&](size_t lo, size_t hi) {
         for (size_t i = lo; i < hi; ++i) b.line[i + 1] = nl[i] + 1;
     });
+    g_t_idx += now_s() - ti0;
 }
 
 struct ReadFile {
@@ -357,6 +458,7 @@ struct ReadFile {
     FILE *out = nullptr;  // only its descriptor is used, with pwrite (stdout: fwrite)
     off_t out_off = 0;
     bool wrote = false;
+    bool preallocated = false;  // the output's blocks were reserved beyond its final size (open_file)
 };
 
 // Reads.h:39-75
@@ -415,11 +517,19 @@ static void open_file(ReadFile &f, const char *path, bool paired, bool interleav
     } else {
         f.out = fopen(outp.c_str(), "w");
         if (!f.out) die("ERROR: Could not access file %s\n", outp.c_str());
+        // the output of a plain input is the input plus a few bytes per record: its blocks are reserved up front
+        // (buffered writes into preallocated space: 11.8 GB/s against 10.1 on the GPU box's host, tools/mb/iob2.cpp)
+        // and the file is cut to its real length when it is closed
+        struct stat st;
+        if (f.src.seekable && fstat(f.src.fd, &st) == 0 && st.st_size > ((off_t)64 << 20) &&
+            posix_fallocate(fileno(f.out), 0, st.st_size + st.st_size / 8) == 0)
+            f.preallocated = true;
     }
 }
 
-// the slices of a batch, in order: stdout through stdio, files by one pwrite per slice from
-// several threads (the copy into the page cache is what bounds a single writer)
+// the slices of a batch, in order.  One thread per output file: buffered writes to one file are serialised by the
+// kernel (the inode's lock), so more writers only add contention -- measured on the GPU box's host: 9.1 GB/s from
+// one thread, 8.4 from 32 (tools/mb/iob.cpp); two files written side by side get 14.5 GB/s
 static void emit_slices(ReadFile &f, const std::vector<std::vector<char>> &sl)
 {
     size_t total = 0;
@@ -432,28 +542,14 @@ static void emit_slices(ReadFile &f, const std::vector<std::vector<char>> &sl)
         return;
     }
     const int fd = fileno(f.out);
-    std::vector<off_t> at(sl.size());
-    off_t o = f.out_off;
-    for (size_t i = 0; i < sl.size(); ++i) {
-        at[i] = o;
-        o += (off_t)sl[i].size();
-    }
-    f.out_off = o;
-    auto wr = [&](size_t i) {
+    for (const auto &v : sl) {
         size_t done = 0;
-        while (done < sl[i].size()) {
-            const ssize_t n = ::pwrite(fd, sl[i].data() + done, sl[i].size() - done, at[i] + (off_t)done);
+        while (done < v.size()) {
+            const ssize_t n = ::pwrite(fd, v.data() + done, v.size() - done, f.out_off + (off_t)done);
             if (n <= 0) die("ERROR: write failed on %s\n", f.path.c_str());
             done += (size_t)n;
         }
-    };
-    if (sl.size() == 1 || total < ((size_t)4 << 20)) {
-        for (size_t i = 0; i < sl.size(); ++i) wr(i);
-    } else {
-        std::vector<std::thread> th;
-        for (size_t i = 0; i < sl.size(); ++i)
-            if (!sl[i].empty()) th.emplace_back(wr, i);
-        for (auto &x : th) x.join();
+        f.out_off += (off_t)v.size();
     }
 }
 
@@ -885,7 +981,83 @@ int main(int argc, char **argv)
         ctx[c] = rc_create(&cfg, err, sizeof err);
         if (!ctx[c]) die("rcorrector: %s\n", err);
     }
+    // One GPU: the whole host pipeline -- reader, packers, formatters, writers and their buffers -- lives on the NUMA
+    // node that GPU hangs off (every byte of a read crosses host memory a dozen times on its way through; across the
+    // socket link each crossing costs more).  Several GPUs: each GPU's worker threads bind themselves (below).
+    const bool numa_on = !(getenv("RC_NUMA") && !strcmp(getenv("RC_NUMA"), "0"));
+    if (numa_on && gpus == 1) {
+        const int node = rc_device_numa_node(ctx[0]);
+        if (node >= 0 && bind_to_numa_node(node) && g_timing) fprintf(stderr, "[rc timing] host threads bound to NUMA node %d\n", node);
+    }
+    g_pool.start((size_t)g_threads * 2);  // (the reader, the mate's reader and the workers call it side by side)
     const double t_start = now_s();
+    // While the table loads: the batch buffers of the pipeline -- text blocks, page-locked arenas, output slices --
+    // are allocated, sized from the head of the first input, touched and registered with the GPU runtime here, so
+    // that the first batches do not pay for a few GB of page faults and hipHostRegister calls one after the other
+    const size_t max_in_flight = (size_t)(nworkers + 2);
+    std::vector<std::shared_ptr<Job>> warm_jobs;
+    std::thread warm([&]() {
+        if (files.empty() || verbose || files[0].src.is_gz || !files[0].src.seekable) return;
+        const ReadFile &f = files[0];
+        const int lpr = f.fastq ? 4 : 2;
+        const char *h = f.src.left.p;
+        size_t nl = 0, last = 0, seq_len = 0, l1 = 0;
+        for (size_t i = 0; i < f.src.left_len; ++i)
+            if (h[i] == '\n') {
+                ++nl;
+                if (nl == 1) l1 = i;
+                if (nl == 2) seq_len = i - l1 - 1;
+                if (nl % (size_t)lpr == 0) last = i + 1;
+            }
+        if (last == 0 || seq_len == 0) return;
+        const double rec_bytes = (double)last / (double)(nl / (size_t)lpr);
+        struct stat st;
+        if (stat(f.path.c_str(), &st) != 0) return;
+        const double file_recs = (double)st.st_size / rec_bytes;
+        size_t recs = batch_reads;
+        if (f.interleaved) recs = batch_reads;  // (a batch of an interleaved file holds batch_reads records as well)
+        if ((double)recs > file_recs * 1.02 + 16) recs = (size_t)(file_recs * 1.02) + 16;
+        size_t njobs = (size_t)(file_recs / (double)recs) + 1;
+        if (njobs > max_in_flight) njobs = max_in_flight;
+        const size_t text_bytes = (size_t)((double)recs * rec_bytes * 1.04) + ((size_t)1 << 20);
+        const size_t arena_bytes = (size_t)((double)recs * (double)(seq_len + 1) * 1.02) + 4096;
+        const size_t S = std::max<size_t>(1, std::min<size_t>((size_t)g_threads, (recs + 8191) / 8192));
+        const size_t out_slice = (size_t)(((double)recs / (double)S + 1.0) * (rec_bytes + 48.0));
+        for (size_t jn = 0; jn < njobs; ++jn) {
+            auto j = std::make_shared<Job>();
+            const int sides = f.paired ? 2 : 1;
+            for (int sd = 0; sd < sides; ++sd) {
+                Arena &A = sd ? j->b : j->a;
+                A.blk.text.need(text_bytes);
+                A.blk.line.reserve(recs * (size_t)lpr + 8);
+                A.off.reserve(recs + 1);
+                A.seq.need(arena_bytes);   // (page-locked here: rc_host_register)
+                A.qual.need(arena_bytes);
+                std::vector<std::vector<char>> &o = sd ? j->o2 : j->o1;
+                o.resize(S);
+                for (auto &v : o) v.reserve(out_slice);
+            }
+            // touch what malloc handed out untouched (the arenas were touched by the registration)
+            g_pool.run(16, [&](size_t t) {
+                for (int sd = 0; sd < sides; ++sd) {
+                    Arena &A = sd ? j->b : j->a;
+                    const size_t lo = text_bytes * t / 16, hi = text_bytes * (t + 1) / 16;
+                    memset(A.blk.text.p + lo, 0, hi - lo);
+                    std::vector<std::vector<char>> &o = sd ? j->o2 : j->o1;
+                    for (size_t s2 = t; s2 < S; s2 += 16) {
+                        o[s2].resize(out_slice);
+                        o[s2].clear();
+                    }
+                }
+            });
+            const size_t total = (size_t)sides * recs;
+            j->ret.reserve(total);
+            j->l.reserve(total);
+            j->m.reserve(total);
+            j->h.reserve(total);
+            warm_jobs.push_back(j);
+        }
+    });
     int64_t stored = 0;
     if (dump) {  // main.cpp:294-308: ONE Store, loaded once
         if (rc_table_load_jfdump(ctx[0], dump, &stored)) die("rcorrector: %s\n", rc_last_error(ctx[0]));
@@ -970,7 +1142,8 @@ int main(int argc, char **argv)
     std::vector<std::shared_ptr<Job>> pool;  // finished jobs: their buffers are reused (no fresh page faults)
     std::deque<std::shared_ptr<Job>> q;  // one queue for all workers: whichever context is free takes the next batch
     bool closing = false, reader_done = false;
-    const size_t max_in_flight = (size_t)(nworkers + 2);
+    warm.join();
+    pool = warm_jobs;
 
     // the output records of a finished batch, formatted (and deflated for .gz outputs) in slices by
     // the worker that ran it; the writer thread only writes
@@ -1000,25 +1173,16 @@ int main(int argc, char **argv)
                 }
             }
         };
-        if (S == 1) {
-            fmt(0, 1);
-        } else {
-            std::vector<std::thread> th;
-            for (size_t s = 0; s < S; ++s) th.emplace_back([&, s]() { fmt(s, s + 1); });
-            for (auto &x : th) x.join();
-        }
+        g_pool.run(S, [&](size_t s) { fmt(s, s + 1); });
         // compression is a property of each output file (Reads::AddReadFile picks it per input name):
         // `-p a.fq.gz b.fq` writes a gzip stream for the first mates and plain text for the second
         const bool gz1 = f.out_gz && !g_stdout, gz2 = j->mode == 1 && mates[(size_t)j->file].out_gz && !g_stdout;
         if (gz1 || gz2) {  // deflate every slice into its own gzip member, in parallel
             std::vector<std::vector<char>> z1(S), z2(S);
-            std::vector<std::thread> th;
-            for (size_t s = 0; s < S; ++s)
-                th.emplace_back([&, s]() {
-                    if (gz1 && !o1[s].empty()) gzip_member(o1[s], z1[s]);
-                    if (gz2 && !o2[s].empty()) gzip_member(o2[s], z2[s]);
-                });
-            for (auto &x : th) x.join();
+            g_pool.run(S, [&](size_t s) {
+                if (gz1 && !o1[s].empty()) gzip_member(o1[s], z1[s]);
+                if (gz2 && !o2[s].empty()) gzip_member(o2[s], z2[s]);
+            });
             if (gz1) o1.swap(z1);
             if (gz2) o2.swap(z2);
         }
@@ -1028,6 +1192,10 @@ int main(int argc, char **argv)
     for (int wk = 0; wk < nworkers; ++wk) {
         workers.emplace_back([&, wk]() {
             const int g = wk % gpus, slot = wk / gpus;
+            if (numa_on && gpus > 1 && !shared_gpu) {
+                const int node = rc_device_numa_node(ctx[g]);
+                if (node >= 0) bind_to_numa_node(node);
+            }
             for (;;) {
                 std::shared_ptr<Job> j;
                 {
@@ -1172,6 +1340,7 @@ int main(int argc, char **argv)
 
     // reader
     {
+        int ramp = 0;
         for (size_t fi = 0; fi < files.size(); ++fi) {
             ReadFile &f = files[fi];
             const int lpr = f.fastq ? 4 : 2;
@@ -1191,13 +1360,18 @@ int main(int argc, char **argv)
                 j->a.lpr = lpr;
                 j->b.lpr = f.paired ? (mates[fi].fastq ? 4 : 2) : lpr;
                 const double tr0 = now_s();
+                // the first batches of a run are small, so that the stages behind the reader start early: an eighth,
+                // a quarter, a half of -batch (whole pairs; a read's result does not depend on its batch)
+                size_t want_reads = batch_reads;
+                if (ramp < 3 && batch_reads >= ((size_t)1 << 19)) want_reads = (batch_reads >> (3 - ramp)) & ~(size_t)1;
+                ++ramp;
                 if (f.paired) {  // both mates' files at once (two inflate streams run side by side for .gz pairs)
-                    std::thread mate([&]() { take_records(mates[fi].src, batch_reads, j->b.lpr, j->b.blk); });
-                    take_records(f.src, batch_reads, lpr, j->a.blk);
+                    std::thread mate([&]() { take_records(mates[fi].src, want_reads, j->b.lpr, j->b.blk); });
+                    take_records(f.src, want_reads, lpr, j->a.blk);
                     mate.join();
                     if (j->b.blk.records != j->a.blk.records) die("ERROR: The files are not paired!\n");
                 } else {
-                    take_records(f.src, batch_reads, lpr, j->a.blk);
+                    take_records(f.src, want_reads, lpr, j->a.blk);
                 }
                 if (j->a.blk.records == 0) break;
                 if (j->mode == 2 && (j->a.blk.records & 1)) die("ERROR: interleaved file %s holds an odd number of reads\n", f.path.c_str());
@@ -1237,6 +1411,8 @@ int main(int argc, char **argv)
                 one[0].swap(z);
                 emit_slices(*f, one);
             }
+            if (f->out && f->out != stdout && f->preallocated && ftruncate(fileno(f->out), f->out_off) != 0)
+                die("ERROR: could not set the length of the output of %s\n", f->path.c_str());
             if (f->out && f->out != stdout) fclose(f->out);
             f->src.close();
         }
@@ -1249,6 +1425,7 @@ int main(int argc, char **argv)
     if (g_timing)
         fprintf(stderr, "[rc timing] stage totals: read+index %.2f s (reader thread); pack %.2f s + correct_batch %.2f s + format %.2f s (sum over %d worker threads); write %.2f s (writer thread)\n",
                 g_t_read, g_t_pack, g_t_gpu, g_t_format, nworkers, g_t_write);
+    if (g_timing) fprintf(stderr, "[rc timing] inside read+index (all files, thread-seconds): pread %.2f s, newline scan %.2f s, line index %.2f s\n", g_t_fill, g_t_nl, g_t_idx);
     if (g_timing)
         fprintf(stderr, "[rc timing] blocked: reader %.2f s (no free slot), workers %.2f s (no batch), writer %.2f s (next batch not done)\n", g_w_reader, g_w_worker, g_w_writer);
     fprintf(stderr, "Processed %llu reads\n\tCorrected %llu bases.\n", (unsigned long long)total_reads, (unsigned long long)total_cor);

@@ -36,7 +36,12 @@ def main():
     n, L, k = a.reads, a.len, a.k
     seq, qual = bench.synth_reads_gpu(77000, n, L, a.n_tx, 1500, 0.8, a.err, dev, paired=a.paired)
     ctx = rcorrector_amd.Context(k=k)
-    nk = ctx.count_reads_device(seq, seq.numel(), 2)
+    ctx.count_begin()   # (an arena handed to the counter stays below 4 GiB)
+    step = 20_000_000 * (L + 1)
+    for lo in range(0, seq.numel(), step):
+        piece = seq[lo:lo + step]
+        ctx.count_add_device(piece, piece.numel())
+    nk = ctx.count_finish(2)
     codes, counts = ctx.table_export()
     o = np.argsort(codes)
     codes, counts = codes[o], counts[o]
@@ -90,9 +95,14 @@ def main():
             import shutil
             shutil.rmtree(a.dir + "/out", ignore_errors=True)   # truncating last run's multi-GB output is not part of the run
             os.sync()
+            toks = variant.split()
+            venv = dict(env)
+            while toks and "=" in toks[0] and not toks[0].startswith("-"):   # leading NAME=VALUE tokens: environment of this variant
+                kk, vv = toks.pop(0).split("=", 1)
+                venv[kk] = vv
             t0 = time.time()
-            p = subprocess.run([cli] + inputs + ["-k", str(k), "-od", a.dir + "/out"] + dump + variant.split(),
-                               cwd=a.dir, env=env, stderr=subprocess.PIPE)
+            p = subprocess.run([cli] + inputs + ["-k", str(k), "-od", a.dir + "/out"] + dump + toks,
+                               cwd=a.dir, env=venv, stderr=subprocess.PIPE)
             dt = time.time() - t0
             sys.stderr.write(p.stderr.decode())
             md5 = hashlib.md5(open(a.dir + "/out/" + first_out, "rb").read()).hexdigest()
