@@ -191,8 +191,8 @@ void rc_destroy(rc_ctx *c)
     }
     if (ctx->s_h2d) (void)hipStreamDestroy(ctx->s_h2d);
     if (ctx->s_d2h) (void)hipStreamDestroy(ctx->s_d2h);
-    if (ctx->cnt_keys) (void)hipFree(ctx->cnt_keys);
-    if (ctx->cnt_vals) (void)hipFree(ctx->cnt_vals);
+    for (auto &a : ctx->cnt_arenas)
+        if (a.p) (void)hipFree(a.p);
     rc_table_release(ctx);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -573,7 +573,7 @@ int rc_table_count_add_device(rc_ctx *ctx, const uint8_t *d_seq, size_t nbytes)
 {
     if (!ctx || (nbytes && !d_seq)) return RC_ERR_ARG;
     RC_CHECK_HIP(ctx, hipSetDevice(ctx->device));
-    return rc_count_add(ctx, d_seq, nbytes);
+    return rc_count_add(ctx, d_seq, nbytes, true);
 }
 
 int rc_table_count_add(rc_ctx *ctx, const char *seq, size_t nbytes)
@@ -581,10 +581,7 @@ int rc_table_count_add(rc_ctx *ctx, const char *seq, size_t nbytes)
     if (!ctx || (nbytes && !seq)) return RC_ERR_ARG;
     if (nbytes == 0) return RC_OK;
     RC_CHECK_HIP(ctx, hipSetDevice(ctx->device));
-    rc_dev_tmp b;
-    RC_CHECK_HIP(ctx, b.alloc(nbytes));
-    RC_CHECK_HIP(ctx, hipMemcpyAsync(b.p, seq, nbytes, hipMemcpyHostToDevice, ctx->stream));
-    return rc_count_add(ctx, b.as<uint8_t>(), nbytes);
+    return rc_count_add(ctx, reinterpret_cast<const uint8_t *>(seq), nbytes, false);
 }
 
 int rc_table_count_finish(rc_ctx *ctx, int min_count, int64_t *n_kmers)

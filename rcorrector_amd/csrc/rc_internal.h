@@ -90,10 +90,9 @@ struct rc_ctx {
     int trace_cap = 0;
     rc_dbuf trace;
 
-    // streaming k-mer counter (rc_table_count_begin/add/finish): sorted (code, count) accumulator
-    uint64_t *cnt_keys = nullptr;
-    uint32_t *cnt_vals = nullptr;
-    size_t cnt_n = 0;
+    // k-mer counter (rc_table_count_begin/add/finish): the arenas handed over so far, kept in HBM until finish
+    std::vector<rc_dbuf> cnt_arenas;
+    size_t cnt_total = 0;  // bytes
     bool cnt_active = false;
 
     // batch scratch
@@ -140,7 +139,7 @@ int rc_launch_canonicalize(rc_ctx *ctx, uint64_t *d_codes, size_t n);
 int rc_launch_lookup(rc_ctx *ctx, const uint64_t *d_codes, size_t n, int32_t *d_out);
 int rc_launch_probe(rc_ctx *ctx, const uint8_t *d_seq, size_t nbytes, int32_t *d_counts);
 int rc_count_begin(rc_ctx *ctx);
-int rc_count_add(rc_ctx *ctx, const uint8_t *d_seq, size_t nbytes);
+int rc_count_add(rc_ctx *ctx, const uint8_t *seq, size_t nbytes, bool from_device);
 int rc_count_finish(rc_ctx *ctx, int min_count, int64_t *n_kmers);
 int rc_count_reads(rc_ctx *ctx, const uint8_t *d_seq, size_t nbytes, int min_count, int64_t *n_kmers);
 int rc_launch_selftest_bound(rc_ctx *ctx, const int32_t *d_c, size_t n, double e, int32_t *d_oi, double *d_od);

@@ -749,16 +749,38 @@ int rc_launch_probe(rc_ctx *ctx, const uint8_t *d_seq, size_t nbytes, int32_t *d
     return RC_OK;
 }
 
-// ---- k-mer counting from reads (replaces jellyfish bc/count/dump for in-HBM use) -----------------
-// every valid k-mer window of the arena -> canonical code (else the all-ones sentinel, which is
-// never a canonical code), radix sort, run-length encode, keep count >= min_count, build.
-__global__ __launch_bounds__(RC_PROBE_THREADS) void k_emit_kmers(const uint8_t *__restrict__ seq, size_t nbytes, int k,
-                                                                 uint64_t *__restrict__ out)
+// ---- exact k-mer counter in bounded memory (stages 0-2 of run_rcorrector.pl:262-281 for reads that are, or
+// pass through, HBM).  `jellyfish bc` + `count --bc` exist so that the singletons of a data set -- most of its
+// distinct k-mers once reads carry errors -- never occupy the counter (run_rcorrector.pl:262-273).  Here the same
+// end is reached by cutting the KEY SPACE instead: the arenas handed over are kept in HBM (one byte per base:
+// 100 M x 150 bp are 15 GB of 288), and finish() makes P passes over them; pass p looks only at the k-mers whose
+// hash falls into slice p of P -- emit -> radix sort -> run-length encode -> keep count >= min_count -- so that no
+// more than 1/P of the k-mer occurrences is ever in flight, whatever share of them are singletons.  A histogram
+// pass sizes the slices; P follows from the memory the passes may use (RC_COUNT_MEM_MB, default 24 GiB).  The result
+// is what `jellyfish count -C` + `dump -L 2` hands to the reference: every canonical k-mer with its exact count.
+__global__ void k_u32_to_i32_clamped(const uint32_t *in, int32_t *out, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i] > 0x7fffffffu ? 0x7fffffff : (int32_t)in[i];
+}
+
+__device__ __forceinline__ uint32_t rc_count_slice(uint64_t key, uint32_t P)
+{
+    return (uint32_t)(((uint64_t)rc_hash(key ^ 0x9E3779B97F4A7C15ull) * P) >> 32);
+}
+
+// MODE 0: hist[slice] += valid k-mers of the tile; MODE 1: the canonical codes of slice `p` are appended to out
+template <int MODE>
+__global__ __launch_bounds__(RC_PROBE_THREADS) void k_count_scan(const uint8_t *__restrict__ seq, size_t nbytes, int k, uint32_t P, uint32_t p,
+                                                                 unsigned long long *__restrict__ hist, uint64_t *__restrict__ out,
+                                                                 unsigned long long *__restrict__ cursor)
 {
     __shared__ uint32_t s_code[RC_PROBE_TILE / 16 + 4];
     __shared__ uint16_t s_inv[RC_PROBE_TILE / 16 + 4];
+    __shared__ uint32_t s_hist[64];
     const size_t tile0 = (size_t)blockIdx.x * RC_PROBE_TILE;
     const int t = threadIdx.x;
+    if (MODE == 0 && t < 64) s_hist[t] = 0;
     for (int chunk = t; chunk < RC_PROBE_TILE / 16 + 2; chunk += RC_PROBE_THREADS) {
         const size_t g = tile0 + (size_t)chunk * 16;
         uint4 v = make_uint4(0, 0, 0, 0);
@@ -779,8 +801,9 @@ __global__ __launch_bounds__(RC_PROBE_THREADS) void k_emit_kmers(const uint8_t *
     const uint32_t *m_inv = reinterpret_cast<const uint32_t *>(s_inv);
     for (int a = t; a < RC_PROBE_TILE; a += RC_PROBE_THREADS) {
         const size_t g = tile0 + (size_t)a;
-        if (g >= nbytes) break;
-        uint64_t key = ~0ull;
+        bool take = false;
+        uint64_t key = 0;
+        uint32_t sl = 0;
         if (g + (size_t)k <= nbytes) {
             const int mw = a >> 5, ms = a & 31;
             const uint64_t invw = (((uint64_t)m_inv[mw] << 32) | m_inv[mw + 1]) << ms;
@@ -789,9 +812,27 @@ __global__ __launch_bounds__(RC_PROBE_THREADS) void k_emit_kmers(const uint8_t *
                 uint64_t x = ((uint64_t)s_code[cw] << 32) | s_code[cw + 1];
                 if (cs) x = (x << cs) | ((uint64_t)s_code[cw + 2] >> (32 - cs));
                 key = rc_canonical(x >> (64 - 2 * k), k);
+                sl = rc_count_slice(key, P);
+                take = MODE == 0 || sl == p;
             }
         }
-        out[g] = key;
+        if (MODE == 0) {
+            if (take) atomicAdd(&s_hist[sl & 63u], 1u);  // (P <= 64)
+        } else {
+            // one atomic per wave: the lanes that hold a key of this slice take consecutive places
+            const unsigned long long m = __ballot(take);
+            if (m) {
+                const int lane = t & 63, leader = __ffsll((long long)m) - 1;
+                unsigned long long base = 0;
+                if (lane == leader) base = atomicAdd(cursor, (unsigned long long)__popcll(m));
+                base = __shfl(base, leader, 64);
+                if (take) out[base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull))] = key;
+            }
+        }
+    }
+    if (MODE == 0) {
+        __syncthreads();
+        if (t < 64 && s_hist[t]) atomicAdd(hist + t, (unsigned long long)s_hist[t]);
     }
 }
 
@@ -799,32 +840,26 @@ __global__ void k_flag_keep(const uint64_t *__restrict__ uniq, const uint32_t *_
                             uint8_t *__restrict__ keep)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) keep[i] = (uniq[i] != ~0ull && cnt[i] >= (uint32_t)min_count) ? 1 : 0;
+    if (i < n) keep[i] = cnt[i] >= (uint32_t)min_count ? 1 : 0;
 }
 
-// ---- streaming exact k-mer counter (stages 0-2 of run_rcorrector.pl:262-281 for reads that are, or
-// pass through, HBM).  The accumulator is a sorted array of (canonical code, count); every added
-// arena is reduced to such an array (emit -> radix sort -> run-length encode) and merged into it
-// (concatenate -> sort pairs -> reduce by key).  finish keeps count >= min_count -- what
-// `jellyfish count -C` + `dump -L 2` hands to the reference -- and builds the table.
-__global__ void k_u32_to_i32_clamped(const uint32_t *in, int32_t *out, size_t n)
+static void rc_count_release(rc_ctx *ctx)
 {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = in[i] > 0x7fffffffu ? 0x7fffffff : (int32_t)in[i];
+    for (auto &a : ctx->cnt_arenas)
+        if (a.p) (void)hipFree(a.p);
+    ctx->cnt_arenas.clear();
+    ctx->cnt_total = 0;
 }
 
 int rc_count_begin(rc_ctx *ctx)
 {
-    if (ctx->cnt_keys) (void)hipFree(ctx->cnt_keys);
-    if (ctx->cnt_vals) (void)hipFree(ctx->cnt_vals);
-    ctx->cnt_keys = nullptr;
-    ctx->cnt_vals = nullptr;
-    ctx->cnt_n = 0;
+    rc_count_release(ctx);
     ctx->cnt_active = true;
     return RC_OK;
 }
 
-int rc_count_add(rc_ctx *ctx, const uint8_t *d_seq, size_t nbytes)
+// keeps a copy of the arena in HBM (from_device: d_seq is device memory, else host memory)
+int rc_count_add(rc_ctx *ctx, const uint8_t *seq, size_t nbytes, bool from_device)
 {
     if (!ctx->cnt_active) {
         rc_set_error(ctx, "count_add: call rc_table_count_begin first");
@@ -835,88 +870,25 @@ int rc_count_add(rc_ctx *ctx, const uint8_t *d_seq, size_t nbytes)
         rc_set_error(ctx, "count: an arena must be below 2^32 bytes (add it in pieces)");
         return RC_ERR_ARG;
     }
-    const int k = ctx->k;
-    rc_dev_tmp b_keys, b_keys_s, b_cnt, b_runs, b_tmp;
-    size_t t_sort = 0, t_rle = 0;
-    RC_CHECK_HIP(ctx, b_keys.alloc(nbytes * 8));
-    RC_CHECK_HIP(ctx, b_keys_s.alloc(nbytes * 8));
-    RC_CHECK_HIP(ctx, b_runs.alloc(sizeof(size_t) * 2));
-    uint64_t *keys = b_keys.as<uint64_t>(), *keys_s = b_keys_s.as<uint64_t>();
-    size_t *d_runs = b_runs.as<size_t>();
-    const unsigned G = (unsigned)((nbytes + RC_PROBE_TILE - 1) / RC_PROBE_TILE);
-    hipLaunchKernelGGL(k_emit_kmers, dim3(G), dim3(RC_PROBE_THREADS), 0, ctx->stream, d_seq, nbytes, k, keys);
-    RC_CHECK_HIP(ctx, hipGetLastError());
-    RC_CHECK_HIP(ctx, rocprim::radix_sort_keys(nullptr, t_sort, keys, keys_s, nbytes, 0, 64, ctx->stream));
-    RC_CHECK_HIP(ctx, b_tmp.alloc(t_sort));
-    RC_CHECK_HIP(ctx, rocprim::radix_sort_keys(b_tmp.p, t_sort, keys, keys_s, nbytes, 0, 64, ctx->stream));
-    uint64_t *uniq = keys;  // unique keys reuse `keys`
-    RC_CHECK_HIP(ctx, b_cnt.alloc(nbytes * 4));
-    uint32_t *cnt = b_cnt.as<uint32_t>();
-    RC_CHECK_HIP(ctx, rocprim::run_length_encode(nullptr, t_rle, keys_s, (unsigned int)nbytes, uniq, cnt, d_runs, ctx->stream));
-    RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    RC_CHECK_HIP(ctx, b_tmp.alloc(t_rle));
-    RC_CHECK_HIP(ctx, rocprim::run_length_encode(b_tmp.p, t_rle, keys_s, (unsigned int)nbytes, uniq, cnt, d_runs, ctx->stream));
-    size_t runs = 0;
-    uint64_t last_key = 0;
-    RC_CHECK_HIP(ctx, hipMemcpyAsync(&runs, d_runs, sizeof(size_t), hipMemcpyDeviceToHost, ctx->stream));
-    RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (runs) {
-        RC_CHECK_HIP(ctx, hipMemcpy(&last_key, uniq + (runs - 1), 8, hipMemcpyDeviceToHost));
-        if (last_key == ~0ull) --runs;  // the run of "no k-mer here" sentinels sorts last
+    size_t cap = (size_t)128 << 30;  // what the counter may keep in HBM
+    if (const char *e = getenv("RC_COUNT_RETAIN_MB")) cap = (size_t)atoll(e) << 20;
+    if (ctx->cnt_total + nbytes > cap) {
+        rc_set_error(ctx, "count: %zu MB of reads exceed what the k-mer counter keeps in HBM (%zu MB, RC_COUNT_RETAIN_MB): count them with "
+                          "jellyfish and pass the dump (-c)", (ctx->cnt_total + nbytes) >> 20, cap >> 20);
+        return RC_ERR_NOMEM;
     }
-    b_tmp.reset();
-    b_keys_s.reset();
-    if (runs == 0) return RC_OK;
-    // merge into the accumulator
-    const size_t total = ctx->cnt_n + runs;
-    rc_dev_tmp m_k, m_v, m_ks, m_vs, m_uk, m_uv;
-    RC_CHECK_HIP(ctx, m_k.alloc(total * 8));
-    RC_CHECK_HIP(ctx, m_v.alloc(total * 4));
-    if (ctx->cnt_n) {
-        RC_CHECK_HIP(ctx, hipMemcpyAsync(m_k.p, ctx->cnt_keys, ctx->cnt_n * 8, hipMemcpyDeviceToDevice, ctx->stream));
-        RC_CHECK_HIP(ctx, hipMemcpyAsync(m_v.p, ctx->cnt_vals, ctx->cnt_n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    rc_dbuf a;
+    RC_CHECK_HIP(ctx, hipMalloc(&a.p, nbytes + 64));
+    a.bytes = nbytes;
+    hipError_t e = hipMemcpyAsync(a.p, seq, nbytes, from_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // (the caller's buffer is its own again when this returns)
+    if (e != hipSuccess) {
+        (void)hipFree(a.p);
+        rc_set_error(ctx, "count_add: copy failed: %s", hipGetErrorString(e));
+        return RC_ERR_HIP;
     }
-    RC_CHECK_HIP(ctx, hipMemcpyAsync(m_k.as<uint64_t>() + ctx->cnt_n, uniq, runs * 8, hipMemcpyDeviceToDevice, ctx->stream));
-    RC_CHECK_HIP(ctx, hipMemcpyAsync(m_v.as<uint32_t>() + ctx->cnt_n, cnt, runs * 4, hipMemcpyDeviceToDevice, ctx->stream));
-    RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    b_keys.reset();
-    b_cnt.reset();
-    if (ctx->cnt_n == 0) {  // first arena: it IS the accumulator
-        if (ctx->cnt_keys) (void)hipFree(ctx->cnt_keys);
-        if (ctx->cnt_vals) (void)hipFree(ctx->cnt_vals);
-        ctx->cnt_keys = m_k.as<uint64_t>();
-        ctx->cnt_vals = m_v.as<uint32_t>();
-        m_k.p = nullptr;
-        m_v.p = nullptr;
-        ctx->cnt_n = runs;
-        return RC_OK;
-    }
-    size_t t_sp = 0, t_rk = 0;
-    RC_CHECK_HIP(ctx, m_ks.alloc(total * 8));
-    RC_CHECK_HIP(ctx, m_vs.alloc(total * 4));
-    RC_CHECK_HIP(ctx, rocprim::radix_sort_pairs(nullptr, t_sp, m_k.as<uint64_t>(), m_ks.as<uint64_t>(), m_v.as<uint32_t>(), m_vs.as<uint32_t>(), total, 0, 64, ctx->stream));
-    RC_CHECK_HIP(ctx, b_tmp.alloc(t_sp));
-    RC_CHECK_HIP(ctx, rocprim::radix_sort_pairs(b_tmp.p, t_sp, m_k.as<uint64_t>(), m_ks.as<uint64_t>(), m_v.as<uint32_t>(), m_vs.as<uint32_t>(), total, 0, 64, ctx->stream));
-    RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    m_k.reset();
-    m_v.reset();
-    RC_CHECK_HIP(ctx, m_uk.alloc(total * 8));
-    RC_CHECK_HIP(ctx, m_uv.alloc(total * 4));
-    RC_CHECK_HIP(ctx, rocprim::reduce_by_key(nullptr, t_rk, m_ks.as<uint64_t>(), m_vs.as<uint32_t>(), total, m_uk.as<uint64_t>(), m_uv.as<uint32_t>(), d_runs,
-                                             rocprim::plus<uint32_t>(), rocprim::equal_to<uint64_t>(), ctx->stream));
-    RC_CHECK_HIP(ctx, b_tmp.alloc(t_rk));
-    RC_CHECK_HIP(ctx, rocprim::reduce_by_key(b_tmp.p, t_rk, m_ks.as<uint64_t>(), m_vs.as<uint32_t>(), total, m_uk.as<uint64_t>(), m_uv.as<uint32_t>(), d_runs,
-                                             rocprim::plus<uint32_t>(), rocprim::equal_to<uint64_t>(), ctx->stream));
-    size_t nuniq = 0;
-    RC_CHECK_HIP(ctx, hipMemcpyAsync(&nuniq, d_runs, sizeof(size_t), hipMemcpyDeviceToHost, ctx->stream));
-    RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    (void)hipFree(ctx->cnt_keys);
-    (void)hipFree(ctx->cnt_vals);
-    ctx->cnt_keys = m_uk.as<uint64_t>();
-    ctx->cnt_vals = m_uv.as<uint32_t>();
-    m_uk.p = nullptr;
-    m_uv.p = nullptr;
-    ctx->cnt_n = nuniq;
+    ctx->cnt_arenas.push_back(a);
+    ctx->cnt_total += nbytes;
     return RC_OK;
 }
 
@@ -927,36 +899,125 @@ int rc_count_finish(rc_ctx *ctx, int min_count, int64_t *n_kmers)
         return RC_ERR_STATE;
     }
     ctx->cnt_active = false;
-    const size_t runs = ctx->cnt_n;
-    rc_dev_tmp b_keep, b_selk, b_selc, b_seli, b_n, b_tmp;
-    size_t nsel = 0, t_sel = 0;
-    RC_CHECK_HIP(ctx, b_selk.alloc((runs + 1) * 8));
-    RC_CHECK_HIP(ctx, b_selc.alloc((runs + 1) * 4));
-    RC_CHECK_HIP(ctx, b_seli.alloc((runs + 1) * 4));
-    if (runs) {
-        RC_CHECK_HIP(ctx, b_keep.alloc(runs + 1));
-        RC_CHECK_HIP(ctx, b_n.alloc(sizeof(size_t)));
-        uint8_t *keep = b_keep.as<uint8_t>();
-        size_t *d_nsel = b_n.as<size_t>();
-        hipLaunchKernelGGL(k_flag_keep, dim3((unsigned)((runs + 255) / 256)), dim3(256), 0, ctx->stream, ctx->cnt_keys, ctx->cnt_vals, runs, min_count, keep);
-        RC_CHECK_HIP(ctx, rocprim::select(nullptr, t_sel, ctx->cnt_keys, keep, b_selk.as<uint64_t>(), d_nsel, runs, ctx->stream));
-        RC_CHECK_HIP(ctx, b_tmp.alloc(t_sel));
-        RC_CHECK_HIP(ctx, rocprim::select(b_tmp.p, t_sel, ctx->cnt_keys, keep, b_selk.as<uint64_t>(), d_nsel, runs, ctx->stream));
-        RC_CHECK_HIP(ctx, rocprim::select(b_tmp.p, t_sel, ctx->cnt_vals, keep, b_selc.as<uint32_t>(), d_nsel, runs, ctx->stream));
-        RC_CHECK_HIP(ctx, hipMemcpyAsync(&nsel, d_nsel, sizeof(size_t), hipMemcpyDeviceToHost, ctx->stream));
-        RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (nsel) {
-            hipLaunchKernelGGL(k_u32_to_i32_clamped, dim3((unsigned)((nsel + 255) / 256)), dim3(256), 0, ctx->stream, b_selc.as<uint32_t>(), b_seli.as<int32_t>(), nsel);
-            RC_CHECK_HIP(ctx, hipGetLastError());
-        }
+    struct release_on_exit {
+        rc_ctx *c;
+        ~release_on_exit() { rc_count_release(c); }
+    } guard{ctx};
+    const int k = ctx->k;
+    // passes: a pass holds, per k-mer occurrence of its slice, the key (8 B), its sorted copy (8 B), the sort's scratch
+    // (~8 B) and the run-length output (8 + 4 + 1 B)
+    size_t mem = (size_t)24 << 30;
+    if (const char *e = getenv("RC_COUNT_MEM_MB")) mem = (size_t)atoll(e) << 20;
+    const double per_occ = 40.0;
+    uint32_t P = (uint32_t)((double)ctx->cnt_total * per_occ * 1.15 / (double)mem) + 1;
+    if (P > 64) P = 64;
+    rc_dev_tmp b_hist, b_cursor;
+    RC_CHECK_HIP(ctx, b_hist.alloc(64 * 8));
+    RC_CHECK_HIP(ctx, b_cursor.alloc(8));
+    RC_CHECK_HIP(ctx, hipMemsetAsync(b_hist.p, 0, 64 * 8, ctx->stream));
+    for (const auto &a : ctx->cnt_arenas) {
+        const unsigned G = (unsigned)((a.bytes + RC_PROBE_TILE - 1) / RC_PROBE_TILE);
+        hipLaunchKernelGGL(k_count_scan<0>, dim3(G), dim3(RC_PROBE_THREADS), 0, ctx->stream, (const uint8_t *)a.p, a.bytes, k, P, 0u,
+                           b_hist.as<unsigned long long>(), (uint64_t *)nullptr, (unsigned long long *)nullptr);
     }
-    (void)hipFree(ctx->cnt_keys);
-    (void)hipFree(ctx->cnt_vals);
-    ctx->cnt_keys = nullptr;
-    ctx->cnt_vals = nullptr;
-    ctx->cnt_n = 0;
-    int rc = rc_build_table_from_device_pairs(ctx, b_selk.as<uint64_t>(), b_seli.as<int32_t>(), nsel);
-    if (n_kmers) *n_kmers = (int64_t)nsel;
+    RC_CHECK_HIP(ctx, hipGetLastError());
+    unsigned long long hist[64];
+    RC_CHECK_HIP(ctx, hipMemcpyAsync(hist, b_hist.p, sizeof hist, hipMemcpyDeviceToHost, ctx->stream));
+    RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    size_t max_slice = 0;
+    for (uint32_t p = 0; p < P; ++p) max_slice = std::max(max_slice, (size_t)hist[p]);
+    if (max_slice >= (1ull << 32)) {
+        rc_set_error(ctx, "count: a pass of %zu k-mer occurrences exceeds 2^32 (lower RC_COUNT_MEM_MB for more passes)", max_slice);
+        return RC_ERR_ARG;
+    }
+    // kept entries of all passes, in chunks (their number is known only at the end)
+    struct kept {
+        uint64_t *keys;
+        int32_t *counts;
+        size_t n;
+    };
+    std::vector<kept> outs;
+    struct free_outs {
+        std::vector<kept> *o;
+        ~free_outs()
+        {
+            for (auto &x : *o) {
+                (void)hipFree(x.keys);
+                (void)hipFree(x.counts);
+            }
+        }
+    } guard2{&outs};
+    size_t total_kept = 0;
+    if (max_slice > 0) {
+        rc_dev_tmp b_keys, b_keys_s, b_cnt, b_runs, b_keep, b_tmp, b_selk, b_selc;
+        size_t t_sort = 0, t_rle = 0, t_sel = 0;
+        RC_CHECK_HIP(ctx, b_keys.alloc(max_slice * 8));
+        RC_CHECK_HIP(ctx, b_keys_s.alloc(max_slice * 8));
+        RC_CHECK_HIP(ctx, b_cnt.alloc(max_slice * 4));
+        RC_CHECK_HIP(ctx, b_keep.alloc(max_slice));
+        RC_CHECK_HIP(ctx, b_runs.alloc(sizeof(size_t) * 2));
+        uint64_t *keys = b_keys.as<uint64_t>(), *keys_s = b_keys_s.as<uint64_t>();
+        uint32_t *cnt = b_cnt.as<uint32_t>();
+        size_t *d_runs = b_runs.as<size_t>();
+        RC_CHECK_HIP(ctx, rocprim::radix_sort_keys(nullptr, t_sort, keys, keys_s, max_slice, 0, 2 * k > 64 ? 64 : 2 * k, ctx->stream));
+        RC_CHECK_HIP(ctx, rocprim::run_length_encode(nullptr, t_rle, keys_s, (unsigned int)max_slice, keys, cnt, d_runs, ctx->stream));
+        RC_CHECK_HIP(ctx, rocprim::select(nullptr, t_sel, keys, b_keep.as<uint8_t>(), keys_s, d_runs, max_slice, ctx->stream));
+        RC_CHECK_HIP(ctx, b_tmp.alloc(std::max(t_sort, std::max(t_rle, t_sel))));
+        for (uint32_t p = 0; p < P; ++p) {
+            const size_t m = (size_t)hist[p];
+            if (m == 0) continue;
+            RC_CHECK_HIP(ctx, hipMemsetAsync(b_cursor.p, 0, 8, ctx->stream));
+            for (const auto &a : ctx->cnt_arenas) {
+                const unsigned G = (unsigned)((a.bytes + RC_PROBE_TILE - 1) / RC_PROBE_TILE);
+                hipLaunchKernelGGL(k_count_scan<1>, dim3(G), dim3(RC_PROBE_THREADS), 0, ctx->stream, (const uint8_t *)a.p, a.bytes, k, P, p,
+                                   (unsigned long long *)nullptr, keys, b_cursor.as<unsigned long long>());
+            }
+            RC_CHECK_HIP(ctx, hipGetLastError());
+            RC_CHECK_HIP(ctx, rocprim::radix_sort_keys(b_tmp.p, t_sort, keys, keys_s, m, 0, 2 * k > 64 ? 64 : 2 * k, ctx->stream));
+            RC_CHECK_HIP(ctx, rocprim::run_length_encode(b_tmp.p, t_rle, keys_s, (unsigned int)m, keys, cnt, d_runs, ctx->stream));
+            size_t runs = 0;
+            RC_CHECK_HIP(ctx, hipMemcpyAsync(&runs, d_runs, sizeof(size_t), hipMemcpyDeviceToHost, ctx->stream));
+            RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (runs == 0) continue;
+            hipLaunchKernelGGL(k_flag_keep, dim3((unsigned)((runs + 255) / 256)), dim3(256), 0, ctx->stream, keys, cnt, runs, min_count, b_keep.as<uint8_t>());
+            // the kept keys land in keys_s (free again), their counts behind them in the same buffer's upper half is not
+            // possible (8 vs 4 bytes): counts go through a second select into the sort scratch's neighbour, cnt's own copy
+            RC_CHECK_HIP(ctx, rocprim::select(b_tmp.p, t_sel, keys, b_keep.as<uint8_t>(), keys_s, d_runs, runs, ctx->stream));
+            size_t nsel = 0;
+            RC_CHECK_HIP(ctx, hipMemcpyAsync(&nsel, d_runs, sizeof(size_t), hipMemcpyDeviceToHost, ctx->stream));
+            RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (nsel == 0) continue;
+            kept o{nullptr, nullptr, nsel};
+            RC_CHECK_HIP(ctx, hipMalloc((void **)&o.keys, nsel * 8));
+            outs.push_back(o);  // (from here on released by guard2)
+            RC_CHECK_HIP(ctx, hipMalloc((void **)&outs.back().counts, nsel * 4));
+            RC_CHECK_HIP(ctx, hipMemcpyAsync(outs.back().keys, keys_s, nsel * 8, hipMemcpyDeviceToDevice, ctx->stream));
+            uint32_t *selc = reinterpret_cast<uint32_t *>(keys_s);  // (keys_s was copied out: the stream orders the reuse)
+            RC_CHECK_HIP(ctx, rocprim::select(b_tmp.p, t_sel, cnt, b_keep.as<uint8_t>(), selc, d_runs, runs, ctx->stream));
+            hipLaunchKernelGGL(k_u32_to_i32_clamped, dim3((unsigned)((nsel + 255) / 256)), dim3(256), 0, ctx->stream, selc, outs.back().counts, nsel);
+            RC_CHECK_HIP(ctx, hipGetLastError());
+            total_kept += nsel;
+        }
+        RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    rc_count_release(ctx);  // the reads are no longer needed: their memory goes to the table build
+    rc_dev_tmp b_allk, b_allc;
+    RC_CHECK_HIP(ctx, b_allk.alloc((total_kept + 1) * 8));
+    RC_CHECK_HIP(ctx, b_allc.alloc((total_kept + 1) * 4));
+    size_t at = 0;
+    for (auto &x : outs) {
+        RC_CHECK_HIP(ctx, hipMemcpyAsync(b_allk.as<uint64_t>() + at, x.keys, x.n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        RC_CHECK_HIP(ctx, hipMemcpyAsync(b_allc.as<int32_t>() + at, x.counts, x.n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        at += x.n;
+    }
+    RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto &x : outs) {
+        (void)hipFree(x.keys);
+        (void)hipFree(x.counts);
+    }
+    outs.clear();
+    int rc = rc_build_table_from_device_pairs(ctx, b_allk.as<uint64_t>(), b_allc.as<int32_t>(), total_kept);
+    if (n_kmers) *n_kmers = (int64_t)total_kept;
     return rc;
 }
 
@@ -967,7 +1028,7 @@ int rc_count_reads(rc_ctx *ctx, const uint8_t *d_seq, size_t nbytes, int min_cou
         return RC_ERR_ARG;
     }
     int rc = rc_count_begin(ctx);
-    if (rc == RC_OK) rc = rc_count_add(ctx, d_seq, nbytes);
+    if (rc == RC_OK) rc = rc_count_add(ctx, d_seq, nbytes, true);
     if (rc == RC_OK) rc = rc_count_finish(ctx, min_count, n_kmers);
     return rc;
 }

@@ -91,6 +91,36 @@ def test_streaming_count_equals_exact_counts(rc, k):
     assert n5 == keep.sum() and np.array_equal(got_k, want_k[keep]) and np.array_equal(got_c, want_c[keep])
 
 
+@pytest.mark.parametrize("mem_mb,retain_mb", [(1, None), (4, None), (None, 1)])
+def test_count_in_bounded_memory_equals_exact_counts(rc, mem_mb, retain_mb, monkeypatch):
+    """The counter works through the key space in passes sized by RC_COUNT_MEM_MB (what `jellyfish bc` is for in
+    run_rcorrector.pl:262-273: singletons must not decide how much memory the counter takes).  With an artificial cap
+    of 1 / 4 MB, 1.2 M k-mer occurrences at 5 % errors -- nearly all of them singletons -- go through 41 / 11 passes:
+    the table must still be the exact counts >= 2.  And reads beyond what the counter may keep in HBM
+    (RC_COUNT_RETAIN_MB) are refused with a message, not counted wrong."""
+    k = 31
+    s1, _, _, _, _ = synth.make_reads(4100, 10000, 150, n_tx=6, l_tx=900, e=0.05)
+    want_k, want_c = synth.count_kmers([s1], k)
+    if mem_mb is not None:
+        monkeypatch.setenv("RC_COUNT_MEM_MB", str(mem_mb))
+    if retain_mb is not None:
+        monkeypatch.setenv("RC_COUNT_RETAIN_MB", str(retain_mb))
+    ctx = rc.Context(k=k)
+    ctx.count_begin()
+    rows = [s1[i] for i in range(len(s1))]
+    if retain_mb is not None:
+        with pytest.raises(rc.RcorrectorError, match="RC_COUNT_RETAIN_MB"):
+            for lo in range(0, len(rows), 2500):
+                ctx.count_add(arena_of(rows[lo:lo + 2500]))
+        return
+    for lo in range(0, len(rows), 2500):
+        ctx.count_add(arena_of(rows[lo:lo + 2500]))
+    n = ctx.count_finish(2)
+    got_k, got_c = sorted_pairs(*ctx.table_export())
+    assert n == len(want_k) and np.array_equal(got_k, want_k) and np.array_equal(got_c, want_c)
+    assert (want_c >= 2).all() and len(want_k) > 5000
+
+
 def test_count_sequence_errors(rc):
     ctx = rc.Context(k=23)
     with pytest.raises(rc.RcorrectorError):
