@@ -799,40 +799,61 @@ __global__ __launch_bounds__(RC_PROBE_THREADS) void k_count_scan(const uint8_t *
     if (t < 2) s_code[RC_PROBE_TILE / 16 + 2 + t] = 0xFFFFFFFFu;
     __syncthreads();
     const uint32_t *m_inv = reinterpret_cast<const uint32_t *>(s_inv);
-    for (int a = t; a < RC_PROBE_TILE; a += RC_PROBE_THREADS) {
+    // the canonical code of the window at tile position a, if it is a k-mer of a read, and its slice
+    auto window = [&](int a, uint64_t &key, uint32_t &sl) -> bool {
         const size_t g = tile0 + (size_t)a;
-        bool take = false;
-        uint64_t key = 0;
-        uint32_t sl = 0;
-        if (g + (size_t)k <= nbytes) {
-            const int mw = a >> 5, ms = a & 31;
-            const uint64_t invw = (((uint64_t)m_inv[mw] << 32) | m_inv[mw + 1]) << ms;
-            if (!(invw >> (64 - k))) {
-                const int cw = a >> 4, cs = 2 * (a & 15);
-                uint64_t x = ((uint64_t)s_code[cw] << 32) | s_code[cw + 1];
-                if (cs) x = (x << cs) | ((uint64_t)s_code[cw + 2] >> (32 - cs));
-                key = rc_canonical(x >> (64 - 2 * k), k);
-                sl = rc_count_slice(key, P);
-                take = MODE == 0 || sl == p;
-            }
-        }
-        if (MODE == 0) {
-            if (take) atomicAdd(&s_hist[sl & 63u], 1u);  // (P <= 64)
-        } else {
-            // one atomic per wave: the lanes that hold a key of this slice take consecutive places
-            const unsigned long long m = __ballot(take);
-            if (m) {
-                const int lane = t & 63, leader = __ffsll((long long)m) - 1;
-                unsigned long long base = 0;
-                if (lane == leader) base = atomicAdd(cursor, (unsigned long long)__popcll(m));
-                base = __shfl(base, leader, 64);
-                if (take) out[base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull))] = key;
-            }
-        }
-    }
+        if (g + (size_t)k > nbytes) return false;
+        const int mw = a >> 5, ms = a & 31;
+        const uint64_t invw = (((uint64_t)m_inv[mw] << 32) | m_inv[mw + 1]) << ms;
+        if (invw >> (64 - k)) return false;
+        const int cw = a >> 4, cs = 2 * (a & 15);
+        uint64_t x = ((uint64_t)s_code[cw] << 32) | s_code[cw + 1];
+        if (cs) x = (x << cs) | ((uint64_t)s_code[cw + 2] >> (32 - cs));
+        key = rc_canonical(x >> (64 - 2 * k), k);
+        sl = rc_count_slice(key, P);
+        return true;
+    };
+    constexpr int ITER = RC_PROBE_TILE / RC_PROBE_THREADS, WAVES = RC_PROBE_THREADS / 64;
     if (MODE == 0) {
+        for (int it = 0; it < ITER; ++it) {
+            uint64_t key;
+            uint32_t sl;
+            if (window(it * RC_PROBE_THREADS + t, key, sl)) atomicAdd(&s_hist[sl & 63u], 1u);  // (P <= 64)
+        }
         __syncthreads();
         if (t < 64 && s_hist[t]) atomicAdd(hist + t, (unsigned long long)s_hist[t]);
+        return;
+    }
+    // MODE 1: ONE atomic on the output cursor per workgroup (one word sustains ~90 atomics per microsecond; a wave-level
+    // reservation is 60 times as many): count the keys of slice p per (iteration, wave), reserve, then write
+    __shared__ uint32_t s_n[ITER * WAVES + 1];
+    __shared__ unsigned long long s_base;
+    const int wv = t >> 6, lane = t & 63;
+    for (int it = 0; it < ITER; ++it) {
+        uint64_t key;
+        uint32_t sl;
+        const bool take = window(it * RC_PROBE_THREADS + t, key, sl) && sl == p;
+        const unsigned long long m = __ballot(take);
+        if (lane == 0) s_n[it * WAVES + wv] = (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    if (t == 0) {
+        uint32_t run = 0;
+        for (int i = 0; i < ITER * WAVES; ++i) {
+            const uint32_t c = s_n[i];
+            s_n[i] = run;
+            run += c;
+        }
+        s_base = run ? atomicAdd(cursor, (unsigned long long)run) : 0ull;
+    }
+    __syncthreads();
+    const unsigned long long base = s_base;
+    for (int it = 0; it < ITER; ++it) {
+        uint64_t key = 0;
+        uint32_t sl;
+        const bool take = window(it * RC_PROBE_THREADS + t, key, sl) && sl == p;
+        const unsigned long long m = __ballot(take);
+        if (take) out[base + s_n[it * WAVES + wv] + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull))] = key;
     }
 }
 
