@@ -88,6 +88,10 @@ int rc_table_share(rc_ctx *dst, const rc_ctx *src);
  * table built once (main.cpp:294-308 loads one Store for all workers).  rc_estimate_error_rate() keeps
  * working on src only (dst has no dump order of its own until asked: it falls back to the table's). */
 int rc_table_replicate(rc_ctx *dst, const rc_ctx *src);
+/* the same with the copy left in flight on dst's stream (rc_sync(dst) waits for it): a host replicating to the other
+ * GPUs of a node queues all its copies first -- they travel over different xGMI links at the same time.  GPUs without
+ * peer access to the source get their copy staged through page-locked host memory (then complete on return). */
+int rc_table_replicate_async(rc_ctx *dst, const rc_ctx *src);
 /* Store::GetCount (Store.h:59-66) for n valid k-mer codes (host arrays) */
 int rc_table_lookup(rc_ctx *ctx, const uint64_t *codes, size_t n, int32_t *counts_out);
 /* every stored (canonical code, count) pair, unspecified order -- what `jellyfish dump` would

@@ -523,7 +523,9 @@ int rc_table_share(rc_ctx *dst, const rc_ctx *src)
     return RC_OK;
 }
 
-int rc_table_replicate(rc_ctx *dst, const rc_ctx *src)
+// the copy itself is queued on dst's stream (rc_sync(dst) waits for it), so that a host replicating to several GPUs
+// has all its copies in flight at once: the GPUs of a node are linked pairwise (xGMI), one copy per link
+int rc_table_replicate_async(rc_ctx *dst, const rc_ctx *src)
 {
     if (!dst || !src || dst == src) return RC_ERR_ARG;
     if (dst->k != src->k) {
@@ -540,17 +542,75 @@ int rc_table_replicate(rc_ctx *dst, const rc_ctx *src)
     rc_table_release(dst);
     static_cast<rc_ctx_full *>(dst)->dump.valid = false;
     char *base = nullptr;
-    RC_CHECK_HIP(dst, hipMalloc((void **)&base, src->table_bytes + RC_TABLE_PREFIX_BYTES));
+    const size_t bytes = src->table_bytes + RC_TABLE_PREFIX_BYTES;
+    RC_CHECK_HIP(dst, hipMalloc((void **)&base, bytes));
     dst->d_buckets = reinterpret_cast<uint32_t *>(base + RC_TABLE_PREFIX_BYTES);
-    // the bucket array (and its prefix) is the table: one copy over the direct xGMI link between the two GPUs
-    RC_CHECK_HIP(dst, hipMemcpyPeer(base, dst->device, reinterpret_cast<const char *>(src->d_buckets) - RC_TABLE_PREFIX_BYTES, src->device,
-                                    src->table_bytes + RC_TABLE_PREFIX_BYTES));
+    const char *from = reinterpret_cast<const char *>(src->d_buckets) - RC_TABLE_PREFIX_BYTES;
+    // the bucket array (and its prefix) is the table
+    bool staged = getenv("RC_REPLICATE_STAGED") != nullptr;  // tests: the path of GPUs without peer access
+    if (src->device == dst->device) {
+        if (!staged) RC_CHECK_HIP(dst, hipMemcpyAsync(base, from, bytes, hipMemcpyDeviceToDevice, dst->stream));
+    } else if (!staged) {
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, dst->device, src->device) != hipSuccess) can = 0;
+        if (can) {
+            const hipError_t e = hipDeviceEnablePeerAccess(src->device, 0);  // (dst is the current device)
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) can = 0;
+            (void)hipGetLastError();
+        }
+        if (can)
+            RC_CHECK_HIP(dst, hipMemcpyPeerAsync(base, dst->device, from, src->device, bytes, dst->stream));
+        else
+            staged = true;
+    }
+    if (staged) {  // no direct path between the two GPUs: through page-locked host memory, two pieces in flight
+        const size_t CH = (size_t)64 << 20;
+        char *h[2] = {nullptr, nullptr};
+        hipEvent_t up[2] = {nullptr, nullptr};
+        int rc = RC_OK;
+        auto fail = [&](hipError_t e, const char *what) {
+            rc_set_error(dst, "table_replicate: %s failed: %s", what, hipGetErrorString(e));
+            rc = RC_ERR_HIP;
+        };
+        for (int i = 0; i < 2 && rc == RC_OK; ++i) {
+            hipError_t e = hipHostMalloc((void **)&h[i], CH, hipHostMallocPortable);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&up[i], hipEventDisableTiming);
+            if (e != hipSuccess) fail(e, "hipHostMalloc");
+        }
+        size_t piece = 0;
+        for (size_t at = 0; at < bytes && rc == RC_OK; at += CH, ++piece) {
+            const size_t n = std::min(CH, bytes - at);
+            const int b = (int)(piece & 1);
+            hipError_t e = piece >= 2 ? hipEventSynchronize(up[b]) : hipSuccess;  // the upload that last used this buffer
+            if (e == hipSuccess) e = hipSetDevice(src->device);
+            if (e == hipSuccess) e = hipMemcpy(h[b], from + at, n, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipSetDevice(dst->device);
+            if (e == hipSuccess) e = hipMemcpyAsync(base + at, h[b], n, hipMemcpyHostToDevice, dst->stream);
+            if (e == hipSuccess) e = hipEventRecord(up[b], dst->stream);
+            if (e != hipSuccess) fail(e, "staged copy");
+        }
+        (void)hipSetDevice(dst->device);
+        (void)hipStreamSynchronize(dst->stream);
+        for (int i = 0; i < 2; ++i) {
+            if (h[i]) (void)hipHostFree(h[i]);
+            if (up[i]) (void)hipEventDestroy(up[i]);
+        }
+        if (rc) return rc;
+    }
     dst->nb_home = src->nb_home;
     dst->layout = src->layout;
     dst->ext = src->ext;
     dst->nb_alloc = src->nb_alloc;
     dst->n_entries = src->n_entries;
     dst->table_bytes = src->table_bytes;
+    return RC_OK;
+}
+
+int rc_table_replicate(rc_ctx *dst, const rc_ctx *src)
+{
+    int rc = rc_table_replicate_async(dst, src);
+    if (rc) return rc;
+    RC_CHECK_HIP(dst, hipStreamSynchronize(dst->stream));
     return RC_OK;
 }
 

@@ -1075,9 +1075,11 @@ int main(int argc, char **argv)
     if (gpus > 1) {  // replicate the bucket array device to device (xGMI) and make sure the replicas agree
         uint64_t d0 = 0;
         if (rc_table_digest(ctx[0], &d0)) die("rcorrector: %s\n", rc_last_error(ctx[0]));
+        for (int g = 1; g < gpus; ++g)  // every copy is queued before the first one is waited for: one per xGMI link
+            if (rc_table_replicate_async(ctx[g], ctx[0])) die("rcorrector: %s\n", rc_last_error(ctx[g]));
         for (int g = 1; g < gpus; ++g) {
             uint64_t dg = 0;
-            if (rc_table_replicate(ctx[g], ctx[0]) || rc_table_digest(ctx[g], &dg)) die("rcorrector: %s\n", rc_last_error(ctx[g]));
+            if (rc_sync(ctx[g]) || rc_table_digest(ctx[g], &dg)) die("rcorrector: %s\n", rc_last_error(ctx[g]));
             if (dg != d0) die("rcorrector: the k-mer table replica on GPU %d differs from the original\n", g);
         }
     }

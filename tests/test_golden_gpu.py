@@ -182,6 +182,26 @@ def test_cli_two_gpu_path_equals_one_gpu(name, with_dump, tmp_path):
         gu.assert_same_as_reference(name, tmp_path / "g2", outs[1][0])
 
 
+@pytest.mark.parametrize("staged", [False, True])
+def test_cli_eight_gpu_path_two_batches_in_flight_each(staged, tmp_path):
+    """`-gpus 8 -inflight 2` -- sixteen worker threads over eight contexts, the table replicated to seven of them with
+    all copies in flight at once (rc_table_replicate_async), directly device to device or (RC_REPLICATE_STAGED: what
+    GPUs without peer access get) through page-locked host memory -- gives the reference's bytes.  RC_SHARED_GPU=1:
+    all eight "GPUs" are device 0."""
+    import subprocess
+    name = "fx_pe_k23"
+    d = os.path.join(gu.GOLDEN, name)
+    args = open(os.path.join(d, "cmd.txt")).read().split()
+    od = tmp_path / "g8"
+    env = dict(os.environ, RC_SHARED_GPU="1")
+    if staged:
+        env["RC_REPLICATE_STAGED"] = "1"
+    p = subprocess.run([CLI] + args + ["-od", str(od), "-gpus", "8", "-batch", "50", "-inflight", "2"], cwd=d, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr.decode()
+    gu.assert_same_as_reference(name, od, p.stderr)
+
+
 def test_cli_mixed_plain_and_gz_pair(tmp_path):
     """`-p a.fq.gz b.fq`: each output takes its compression from its own input name (Reads::AddReadFile,
     Reads.h:140-147): a gzip stream for the first mates, plain text for the second -- and the other way round."""

@@ -359,6 +359,35 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
 
 
 @pytest.mark.gpu
+def test_bench_eight_ranks_on_one_gpu():
+    """bench.py --gpus 8 as the driver launches it, all eight ranks on GPU 0 with gloo collectives
+    (RC_BENCH_SHARED_GPU=1), 100 k reads per rank: so that the first run on eight real GPUs is not the first run of
+    the eight-rank code path (digest all-reduce over 8 replicas, max-over-ranks timing, summary reduce)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RC_BENCH_SHARED_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1",
+           "--reads", "100000", "--n-tx", "500", "--cpu-sample", "0"]
+    p = subprocess.run(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and "x8" in d["config"]["parallelism"]
+    assert abs(d["value"] - 8 * 100000 / (d["ms_per_step"] / 1e3)) / d["value"] < 1e-6
+    assert d["config"]["table_replicas_identical"] is True and 0.2 < d["config"]["reads_corrected_frac"] < 0.9
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("seed", list(range(400, 420)))
 def test_jfdump_loader_on_quirky_dumps(gpu_ctx_factory, oracle, seed, tmp_path):
     """The multi-threaded dump parser (fast path for the clean layout, general tokeniser for the
