@@ -202,6 +202,67 @@ def test_cli_without_c_reproduces_reference_outputs(name, tmp_path):
     gu.assert_same_as_reference(name, tmp_path, p.stderr)
 
 
+@pytest.mark.parametrize("name,flags", [("fx_se_k23", ["-s", "reads.fq"]), ("fx_pe_k23", ["-1", "reads_1.fq", "-2", "reads_2.fq"]),
+                                        ("fx_il_k23", None), ("fx_k31_mc8", None)])
+def test_wrapper_with_run_rcorrector_pl_flags(name, flags, tmp_path):
+    """tools/run_rcorrector_gpu takes run_rcorrector.pl's command line (-s / -1 / -2 / -i lists, -k, -od, -tmpd, -stage
+    ...): a run from stage 0 counts the k-mers on the GPU and corrects -- the reference's bytes for fixtures whose dump
+    is the exact count of their own reads -- and leaves nothing behind in -tmpd; `-stage 3` restarts from a dump of
+    the name the Perl wrapper derives (tmp_<md5 of the file list>.jf_dump) and removes it afterwards as the Perl
+    wrapper does."""
+    import hashlib
+    import shutil
+    import sys
+    d = os.path.join(gu.GOLDEN, name)
+    args = open(os.path.join(d, "cmd.txt")).read().split()
+    if flags is None:   # translate the fixture's -r / -i / -p command line
+        flags = []
+        i = 0
+        while i < len(args):
+            if args[i] == "-r":
+                flags += ["-s", args[i + 1]]; i += 2
+            elif args[i] == "-i":
+                flags += ["-i", args[i + 1]]; i += 2
+            elif args[i] == "-p":
+                flags += ["-1", args[i + 1], "-2", args[i + 2]]; i += 3
+            else:
+                i += 1
+    rest = []
+    i = 0
+    while i < len(args):   # everything but the inputs and -c
+        if args[i] in ("-r", "-i", "-c"):
+            i += 2
+        elif args[i] == "-p":
+            i += 3
+        else:
+            rest.append(args[i]); i += 1
+    wrapper = os.path.join(gu.ROOT, "tools", "run_rcorrector_gpu")
+    tmpd = tmp_path / "tmp"
+    tmpd.mkdir()
+    od = tmp_path / "o0"
+    p = subprocess.run([sys.executable, wrapper] + flags + rest + ["-od", str(od), "-tmpd", str(tmpd), "-ek", "1000"], cwd=d,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr.decode()
+    gu.assert_same_as_reference(name, od, b"", check_stderr=False)
+    want_err = open(os.path.join(d, "ref", "stderr.txt"), "rb").read()
+    assert p.stderr.endswith(want_err)          # the wrapper's own two lines come first, as the Perl wrapper's do
+    assert os.listdir(tmpd) == []
+    # -stage 3: from the dump the earlier stages would have left
+    files = [f for f in flags if not f.startswith("-")]
+    names = [x for f in files for x in f.split(",")]
+    crc = hashlib.md5("".join(n + " " for n in names).encode()).hexdigest()
+    shutil.copy(os.path.join(d, "dump.jf"), tmpd / ("tmp_%s.jf_dump" % crc))
+    od3 = tmp_path / "o3"
+    p = subprocess.run([sys.executable, wrapper] + flags + rest + ["-od", str(od3), "-tmpd", str(tmpd), "-stage", "3"], cwd=d,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr.decode()
+    gu.assert_same_as_reference(name, od3, b"", check_stderr=False)
+    assert p.stderr.endswith(want_err) and os.listdir(tmpd) == []
+    # the Perl wrapper's own refusals
+    p = subprocess.run([sys.executable, wrapper, "-s", "reads.fq", "-k", "33"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode != 0 and b"can not be greater than 32" in p.stderr
+
+
 def _run(binary, args, cwd, od, more=()):
     os.makedirs(od)
     p = subprocess.run([binary] + args + ["-od", od] + list(more), cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
