@@ -90,6 +90,8 @@ rc_table_view rc_view(const rc_ctx *ctx)
     v.layout = ctx->layout;
     v.ext = ctx->ext;
     v.k = ctx->k;
+    v.filter_words = ctx->filter_words;
+    v.filter = ctx->filter_words ? ctx->d_buckets + ctx->table_bytes / 4 : nullptr;
     return v;
 }
 
@@ -520,6 +522,7 @@ int rc_table_share(rc_ctx *dst, const rc_ctx *src)
     dst->nb_alloc = src->nb_alloc;
     dst->n_entries = src->n_entries;
     dst->table_bytes = src->table_bytes;
+    dst->filter_words = src->filter_words;
     return RC_OK;
 }
 
@@ -542,7 +545,7 @@ int rc_table_replicate_async(rc_ctx *dst, const rc_ctx *src)
     rc_table_release(dst);
     static_cast<rc_ctx_full *>(dst)->dump.valid = false;
     char *base = nullptr;
-    const size_t bytes = src->table_bytes + RC_TABLE_PREFIX_BYTES;
+    const size_t bytes = src->table_bytes + RC_TABLE_PREFIX_BYTES + (size_t)src->filter_words * 4;  // prefix, buckets, filter
     RC_CHECK_HIP(dst, hipMalloc((void **)&base, bytes));
     dst->d_buckets = reinterpret_cast<uint32_t *>(base + RC_TABLE_PREFIX_BYTES);
     const char *from = reinterpret_cast<const char *>(src->d_buckets) - RC_TABLE_PREFIX_BYTES;
@@ -603,6 +606,7 @@ int rc_table_replicate_async(rc_ctx *dst, const rc_ctx *src)
     dst->nb_alloc = src->nb_alloc;
     dst->n_entries = src->n_entries;
     dst->table_bytes = src->table_bytes;
+    dst->filter_words = src->filter_words;
     return RC_OK;
 }
 

@@ -55,7 +55,18 @@ struct rc_table_view {
     int layout;               // 0 wide, 1 packed
     int k;
     int ext;                  // PACKED: remainder bits beyond 32, kept above the count (0 .. RC_PACKED_MAX_EXT)
+    // absence filter of a large PACKED table (nullptr: none): filter_words 32-bit words behind the bucket array.  The word
+    // of a key = the top of (its mixed code * filter_words), i.e. next to its home bucket in key order; three bits
+    // in it, taken from the key's remainder, are set.  A probe whose bits are not all set is a miss that never touches
+    // the bucket array -- which, beyond the reach of the TLB, is what a miss costs (rc_table.hip: build_attempt).
+    const uint32_t *filter;
+    uint32_t filter_words;
 };
+// bits of a key in its filter word (three of 32, from 15 bits of the remainder)
+RC_HD uint32_t rc_filter_mask(uint32_t rem)
+{
+    return (1u << (rem & 31u)) | (1u << ((rem >> 5) & 31u)) | (1u << ((rem >> 10) & 31u));
+}
 #define RC_PACKED_MAX_EXT 8   // counts keep at least 19 bits
 // A count that does not fit the count field is stored as "all ones" and kept in full in a small
 // array IN FRONT of the bucket array (same allocation, so a table is still one pointer): the
@@ -195,13 +206,16 @@ RC_HD uint32_t rc_mulhi32(uint32_t a, uint32_t b)
 // number, home = P >> 64, rem = bits 32..63 of P, xrem = the `ext` bits below those.  Codes that
 // share a home differ by at least 2^(64-2k) * nb_home in P, so by at least one unit of (rem, xrem)
 // when nb_home * 2^ext >= 2^(2k-32).
-RC_HD void rc_packed_addr(uint64_t canon, int k, uint32_t nb_home, int ext, uint32_t *home, uint32_t *rem, uint32_t *xrem)
+// (*top, optional: the most significant 32 bits of the mixed code -- what homes and filter words are cut from)
+RC_HD void rc_packed_addr(uint64_t canon, int k, uint32_t nb_home, int ext, uint32_t *home, uint32_t *rem, uint32_t *xrem,
+                          uint32_t *top = nullptr)
 {
     const int kb = 2 * k;
     const uint64_t m = rc_mix2k(canon, k);
     *xrem = 0;
     if (kb <= 32) {
         const uint32_t a = (uint32_t)m << (32 - kb);
+        if (top) *top = a;
         *home = rc_mulhi32(a, nb_home);
         *rem = a * nb_home;
         return;
@@ -209,6 +223,7 @@ RC_HD void rc_packed_addr(uint64_t canon, int k, uint32_t nb_home, int ext, uint
     const int sh = 64 - kb;
     const uint32_t lo = (uint32_t)m, hi = (uint32_t)(m >> 32);
     const uint32_t a = sh ? ((hi << sh) | (lo >> (32 - sh))) : hi, b = lo << sh;  // m << sh as two words
+    if (top) *top = a;
     const uint32_t tl = a * nb_home, th = rc_mulhi32(a, nb_home), u = rc_mulhi32(b, nb_home);
     const uint32_t sum = tl + u;
     *home = th + (sum < tl ? 1u : 0u);

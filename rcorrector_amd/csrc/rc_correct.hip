@@ -431,6 +431,8 @@ int rc_launch_correct(rc_ctx *ctx, const rc_device_batch_args &a)
         // wall_clock64 ticks at 100 MHz: when the queue ran dry and when the last wave ended
         fprintf(stderr, "\n[rc phase prof] work list %u of %u reads; queue empty at %.2f ms, last wave done at %.2f ms; gather rounds: %.2f per listed read, worst read %llu\n",
                 nwork, a.n, (double)(pc[9] - pc[8]) / 1e5, (double)(pc[10] - pc[8]) / 1e5, (double)pc[11] / (nwork ? nwork : 1), pc[12]);
+        fprintf(stderr, "[rc phase prof] k-mers looked up by the searches: %.1f per listed read, %.1f %% of them not in the table\n",
+                (double)pc[14] / (nwork ? nwork : 1), 100.0 * (double)pc[15] / (double)(pc[14] ? pc[14] : 1));
         fprintf(stderr, "[rc phase prof] bucket reads: %.1f per listed read; work-list sections (first to last): %u / %u / %u / %u reads\n",
                 (double)pc[13] / (nwork ? nwork : 1), nsec[0], nsec[1], nsec[2], nsec[3]);
         static const char *sn[8] = {"node entry+pop", "refill (gather round)", "keep-run", "single node", "gap windows", "jump", "terminal", "-"};

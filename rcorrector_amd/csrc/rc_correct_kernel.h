@@ -189,9 +189,16 @@ struct DevWaveT {
     }
 
     uint32_t n_req = 0;  // PROF builds: bucket reads issued by this lane
+    uint32_t n_probe = 0, n_absent = 0;  // PROF builds: k-mers looked up by this lane / of them not in the table
     __device__ __forceinline__ int get(rc_kmer km)
     {
-        return km.inv == -1 ? rc_table_lookup(T, rc_canonical(km.code, KT ? KT : k), PROF ? &n_req : nullptr) : 0;
+        if (km.inv != -1) return 0;
+        const int c = rc_table_lookup(T, rc_canonical(km.code, KT ? KT : k), PROF ? &n_req : nullptr);
+        if (PROF) {
+            ++n_probe;
+            n_absent += c == 0 ? 1u : 0u;
+        }
+        return c;
     }
 
     __device__ __forceinline__ int lookup(uint64_t code) { return rc_table_lookup(T, rc_canonical(code, KT ? KT : k), PROF ? &n_req : nullptr); }
@@ -726,8 +733,12 @@ __global__ __launch_bounds__(64, rc_k3_waves(CAP)) void k_correct(rc_kernel_args
 #endif
     }
     if (PROF) {
-        const int req = w.reduce_add((int)w.n_req);
-        if (w.lane == 0) atomicAdd(A.phase_cycles + 13, (unsigned long long)(uint32_t)req);
+        const int req = w.reduce_add((int)w.n_req), prb = w.reduce_add((int)w.n_probe), abs_ = w.reduce_add((int)w.n_absent);
+        if (w.lane == 0) {
+            atomicAdd(A.phase_cycles + 13, (unsigned long long)(uint32_t)req);
+            atomicAdd(A.phase_cycles + 14, (unsigned long long)(uint32_t)prb);
+            atomicAdd(A.phase_cycles + 15, (unsigned long long)(uint32_t)abs_);
+        }
     }
 }
 

@@ -37,9 +37,13 @@ __device__ __forceinline__ int rc_table_lookup(const rc_table_view &T, uint64_t 
     // probe order is assigned last and wins without a test (two instructions per slot: the probe
     // kernels are bound by VALU issue).
     if (T.layout) {  // PACKED: 8 x {rem, count | xrem | disp << 27}, continue flag in the last slot's bit 31
-        uint32_t b, rem, xrem;
+        uint32_t b, rem, xrem, top;
         const int ext = EXT ? T.ext : 0;
-        rc_packed_addr(canon, T.k, T.nb_home, ext, &b, &rem, &xrem);
+        rc_packed_addr(canon, T.k, T.nb_home, ext, &b, &rem, &xrem, &top);
+        if (T.filter) {  // (wave-uniform) large tables: most misses end at one word of the filter
+            const uint32_t fm = rc_filter_mask(rem);
+            if ((T.filter[rc_mulhi32(top, T.filter_words)] & fm) != fm) return 0;
+        }
         const uint32_t cmask = RC_PACKED_COUNT_MASK >> ext;  // (uniform)
         const uint64_t mask = ((uint64_t)(0x7FFFFFFFu & ~cmask) << 32) | 0xFFFFFFFFull;
         const uint32_t xhi = xrem << (27 - ext);

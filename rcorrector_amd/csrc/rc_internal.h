@@ -85,6 +85,7 @@ struct rc_ctx {
     uint32_t nb_alloc = 0;
     size_t n_entries = 0;   // accepted entries (duplicates included)
     size_t table_bytes = 0;
+    uint32_t filter_words = 0;  // absence filter behind the bucket array (rc_common.h: rc_table_view::filter), 0 = none
 
     // -verbose support: iterations recorded per read by k_correct (0 = off) and the record buffer
     int trace_cap = 0;

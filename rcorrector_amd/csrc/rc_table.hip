@@ -105,6 +105,16 @@ __global__ void k_scatter(const uint32_t *__restrict__ home_sorted, const uint32
     }
 }
 
+// the absence filter of a PACKED table (rc_common.h: rc_table_view::filter): every entry sets its three bits
+__global__ void k_filter_set(const uint64_t *__restrict__ canon, size_t n, uint32_t nb_home, int k, int ext, uint32_t *__restrict__ filter, uint32_t words)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t h, rem, xrem, top;
+    rc_packed_addr(canon[i], k, nb_home, ext, &h, &rem, &xrem, &top);
+    atomicOr(filter + rc_mulhi32(top, words), rc_filter_mask(rem));
+}
+
 // one attempt at one layout; *ok = false (PACKED only) if a count or a displacement does not fit
 static int build_attempt(rc_ctx *ctx, const uint64_t *d_canon, const int32_t *d_counts, size_t n, int layout, int ext, uint32_t nb_home, bool *ok)
 {
@@ -163,11 +173,27 @@ static int build_attempt(rc_ctx *ctx, const uint64_t *d_canon, const int32_t *d_
     ctx->ext = layout ? ext : 0;
     ctx->nb_alloc = (uint32_t)nb_alloc;
     ctx->table_bytes = (size_t)nb_alloc * RC_BUCKET_BYTES;
-    {   // the bucket array, RC_TABLE_PREFIX_BYTES (zero unless counts overflow, below) in front of it
+    // A bucket array beyond the reach of the TLB (2.7-3.2 GB on the boxes seen) makes every probe a page walk, and most
+    // probes of the search -- 61 % at 0.5 % errors, 72 % at 5 % -- are of k-mers that are not in the table at all: a
+    // filter of 10 bits per entry behind the buckets (a tenth of their size, inside the TLB's reach up to ~2.5 G
+    // entries) answers those without touching the buckets.  PACKED tables beyond 2.5 GiB only: below, a bucket read
+    // costs what a filter word costs.  RC_TABLE_FILTER=force / off for tests and A/B runs.
+    ctx->filter_words = 0;
+    {
+        const char *e = getenv("RC_TABLE_FILTER");
+        const bool force = e && !strcmp(e, "force"), off = e && !strcmp(e, "off");
+        if (layout && n > 0 && !off && (force || ctx->table_bytes > ((size_t)5 << 29))) {
+            uint64_t w = ((uint64_t)n * 10 + 31) / 32 + 64;
+            if (w < (1ull << 32)) ctx->filter_words = (uint32_t)w;
+        }
+    }
+    const size_t filter_bytes = (size_t)ctx->filter_words * 4;
+    {   // the bucket array, RC_TABLE_PREFIX_BYTES (zero unless counts overflow, below) in front of it, the filter behind it
         char *base = nullptr;
-        RC_CHECK_HIP(ctx, hipMalloc((void **)&base, ctx->table_bytes + RC_TABLE_PREFIX_BYTES));  // (hipDeviceMallocContiguous: no effect on the TLB cliff, measured)
+        RC_CHECK_HIP(ctx, hipMalloc((void **)&base, ctx->table_bytes + RC_TABLE_PREFIX_BYTES + filter_bytes));  // (hipDeviceMallocContiguous: no effect on the TLB cliff, measured)
         ctx->d_buckets = reinterpret_cast<uint32_t *>(base + RC_TABLE_PREFIX_BYTES);
         RC_CHECK_HIP(ctx, hipMemsetAsync(base, 0, RC_TABLE_PREFIX_BYTES, ctx->stream));
+        if (filter_bytes) RC_CHECK_HIP(ctx, hipMemsetAsync(base + RC_TABLE_PREFIX_BYTES + ctx->table_bytes, 0, filter_bytes, ctx->stream));
     }
     if (layout && n_overflow) {
         rc_dev_tmp b_o, b_oi, b_on;
@@ -203,6 +229,9 @@ static int build_attempt(rc_ctx *ctx, const uint64_t *d_canon, const int32_t *d_
     if (n > 0) {
         hipLaunchKernelGGL(k_scatter, dim3(G), dim3(B), 0, ctx->stream, b_home_s.as<uint32_t>(), b_idx_s.as<uint32_t>(),
                            b_qm.as<long long>(), d_canon, d_counts, ctx->d_buckets, n, nb_home, layout, ctx->k, ext);
+        if (ctx->filter_words)
+            hipLaunchKernelGGL(k_filter_set, dim3(G), dim3(B), 0, ctx->stream, d_canon, n, nb_home, ctx->k, ext,
+                               ctx->d_buckets + ctx->table_bytes / 4, ctx->filter_words);
         RC_CHECK_HIP(ctx, hipGetLastError());
     }
     RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
