@@ -120,12 +120,13 @@ __device__ __forceinline__ uint32_t row_bits(uint64_t ballot, int row)
 // count_at(g) = K1's count of k-mer g; the caller decides where they come from (HBM for
 // k_threshold_q, the workgroup's LDS for the fused probe kernel).  Writes strong / info / cls and, for
 // reads it can finish, ret / l / m / h of read r; returns the class (1 = k_correct has work to do).
-template <int E_CNT, int E_BASE, class FB, class FC>
+// KT: the k the caller is compiled for (0: A.P.k)
+template <int E_CNT, int E_BASE, int KT = 0, class FB, class FC>
 __device__ __forceinline__ int rcq_threshold_row(const rc_kernel_args &A, uint32_t r, bool live, int len, FB base_at, FC count_at)
 {
     using namespace rcq;
     const int lane = threadIdx.x & 63, row = lane >> 4, l = lane & 15;
-    const int k = A.P.k;
+    const int k = KT ? KT : A.P.k;
     const int kcnt = len >= k ? len - k + 1 : 0;
 
     // bases (as letter codes) and K1's counts, element g in register g/16 of lane g%16
