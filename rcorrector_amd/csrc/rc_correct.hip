@@ -106,7 +106,7 @@ __global__ __launch_bounds__(64) void k_threshold(rc_kernel_args A)
 #ifndef RC_FUSED_SMALL_WAVES
 #define RC_FUSED_SMALL_WAVES 6
 #endif
-template <int RC_FUSED_TILE, int WAVES, bool EXT, int KT = 0>
+template <int RC_FUSED_TILE, int WAVES, bool EXT>
 __global__ __launch_bounds__(RC_PROBE_THREADS) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_probe_threshold_list(rc_kernel_args A, size_t nbytes, const uint32_t *__restrict__ list,
                                                                            uint32_t reads_per_block, int32_t *__restrict__ counts)
 {
@@ -117,12 +117,7 @@ __global__ __launch_bounds__(RC_PROBE_THREADS) __attribute__((amdgpu_waves_per_e
     __shared__ uint32_t s_lpos[RC_PLIST_MAX_READS + 1], s_gpos[RC_PLIST_MAX_READS], s_len1[RC_PLIST_MAX_READS], s_rid[RC_PLIST_MAX_READS];
     __shared__ __attribute__((aligned(16))) int32_t s_cnt[RC_FUSED_TILE + 64];
     __shared__ uint8_t s_cls[RC_PLIST_MAX_READS];
-    const int t = threadIdx.x, k = KT ? KT : A.P.k;
-    rc_table_view T = A.T;  // (KT: compiled for one k and the PACKED layout -- masks, shifts and the slot format become immediates)
-    if (KT) {
-        T.k = KT;
-        T.layout = 1;
-    }
+    const int t = threadIdx.x, k = A.P.k;  // (an instance compiled for k = 23 was measured and dropped: 46.0 vs 41.9 ms)
     const uint8_t *seq = A.seq;
     const uint32_t i0 = blockIdx.x * reads_per_block;
     const uint32_t nr = A.n - i0 < reads_per_block ? A.n - i0 : reads_per_block;
@@ -187,7 +182,7 @@ __global__ __launch_bounds__(RC_PROBE_THREADS) __attribute__((amdgpu_waves_per_e
             const int cw = a >> 4, cs = 2 * (a & 15);
             uint64_t x = ((uint64_t)s_code[cw] << 32) | s_code[cw + 1];
             if (cs) x = (x << cs) | ((uint64_t)s_code[cw + 2] >> (32 - cs));
-            cnt = rc_table_lookup<EXT>(T, rc_canonical(x >> (64 - 2 * k), k));
+            cnt = rc_table_lookup<EXT>(A.T, rc_canonical(x >> (64 - 2 * k), k));
         }
         s_cnt[a] = cnt;
     }
@@ -199,7 +194,7 @@ __global__ __launch_bounds__(RC_PROBE_THREADS) __attribute__((amdgpu_waves_per_e
         const bool live = j < nr;
         const uint32_t lp = live ? s_lpos[j] : 0;
         const int len = live ? (int)s_len1[j] - 1 : 0;
-        const int cls = rcq_threshold_row<8, 10, KT>(
+        const int cls = rcq_threshold_row<8, 10>(
             A, live ? s_rid[j] : 0, live, len, [&](int p) { return (uint32_t)raw8[lp + p]; }, [&](int g) { return s_cnt[lp + g]; });
         if (live && (t & 15) == 0) s_cls[j] = (uint8_t)cls;
     }
@@ -357,8 +352,6 @@ int rc_launch_probe_threshold_list(rc_ctx *ctx, const rc_device_batch_args &a, s
         hipLaunchKernelGGL((k_probe_threshold_list<4096, 6, false>), grid, block, 0, ctx->stream, A, nbytes, list, rpb, counts);
     else if (ctx->ext)
         hipLaunchKernelGGL((k_probe_threshold_list<2816, RC_FUSED_SMALL_WAVES, true>), grid, block, 0, ctx->stream, A, nbytes, list, rpb, counts);
-    else if (ctx->k == 23 && ctx->layout == 1 && !ctx->env_k3_generic)  // (run_rcorrector.pl's default k)
-        hipLaunchKernelGGL((k_probe_threshold_list<2816, RC_FUSED_SMALL_WAVES, false, 23>), grid, block, 0, ctx->stream, A, nbytes, list, rpb, counts);
     else
         hipLaunchKernelGGL((k_probe_threshold_list<2816, RC_FUSED_SMALL_WAVES, false>), grid, block, 0, ctx->stream, A, nbytes, list, rpb, counts);
     rc_timer_end(ctx, RC_T_PROBE);

@@ -658,21 +658,6 @@ __global__ __launch_bounds__(64, rc_k3_waves(CAP)) void k_correct(rc_kernel_args
         continue;
 #endif
         rc_load_read(w, A, S, o, w.uni((int)(me[2] - o) - 1), w.lane, true);
-#ifdef RC_EXP_PREFETCH  // dev experiment: touch the next read's cache lines now (one dword per 64-byte line), use the value at the end
-        uint32_t pf = 0;
-        if (chunk_lo < chunk_hi) {
-            const uint32_t *me2 = meta + (ci + 1) * RC_META_WORDS;
-            const uint32_t o2 = me2[1], e2 = me2[2];
-            const int l = w.lane;
-            const uint32_t b = l < 4 ? o2 + 64u * l : (l < 8 ? o2 + 64u * (l - 4) : 0u);
-            if (l < 4 && b < e2) pf = *reinterpret_cast<const uint32_t *>(A.seq + (b & ~3u));
-            if (l >= 4 && l < 8 && b < e2 && !A.qual_bits) pf = *reinterpret_cast<const uint32_t *>(A.qual + (b & ~3u));
-            if (l >= 8 && l < 24) {
-                const uint32_t c = o2 + 16u * (l - 8);
-                if (c < e2) pf = (uint32_t)A.counts[c];
-            }
-        }
-#endif
 #if defined(RC_EXP_STOP) && RC_EXP_STOP == 1
         if (w.lane == 0) A.ret[r] = (int)S.m_inv[0] + (int)S.pk[1] + S.counts[5] + S.qual[7];
         w.sync();
@@ -728,9 +713,6 @@ __global__ __launch_bounds__(64, rc_k3_waves(CAP)) void k_correct(rc_kernel_args
             A.h[r] = h;
         }
         w.sync();
-#ifdef RC_EXP_PREFETCH
-        asm volatile("" ::"v"(pf));
-#endif
         w.phase(7);
 #ifndef RC_EXP_ROUNDS
         if (PROF) {
