@@ -158,6 +158,7 @@ rc_ctx *rc_create(const rc_config *cfg, char *errbuf, size_t errbuf_len)
     ctx->env_timing = getenv("RC_TIMING") != nullptr;
     ctx->env_no_fuse = getenv("RC_NO_FUSE") != nullptr;
     ctx->env_k3_generic = getenv("RC_K3_GENERIC") != nullptr;
+    ctx->env_no_single = getenv("RC_NO_SINGLE") != nullptr;
     ctx->env_no_alt = getenv("RC_NO_ALT") != nullptr;  // dev / tests: no alternative chains in the search's speculation rounds
     if (const char *e = getenv("RC_LOCALITY")) ctx->locality_mode = !strcmp(e, "force") ? 1 : (!strcmp(e, "off") ? -1 : 0);  // tests / A-B
     if (const char *e = getenv("RC_K3_GRID_WAVES")) ctx->env_k3_grid_waves = atoi(e);
@@ -172,7 +173,7 @@ void rc_destroy(rc_ctx *c)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     rc_dbuf *bufs[] = {&ctx->counts, &ctx->strong, &ctx->info, &ctx->stack, &ctx->work,
                        &ctx->h_seq, &ctx->h_qual, &ctx->h_off, &ctx->h_res, &ctx->trace, &ctx->cls, &ctx->worklist, &ctx->sel_tmp,
-                       &ctx->loc_a, &ctx->loc_list};
+                       &ctx->loc_a, &ctx->loc_list, &ctx->cand, &ctx->single_list};
     for (rc_dbuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (ctx->slots) {
@@ -1008,12 +1009,18 @@ static int correct_device_impl(rc_ctx *ctx, const rc_device_batch *b, uint32_t q
         if ((rc = rc_launch_threshold(ctx, a, true))) return rc;
         ctx->thr_ready = true;
     }
-    if (ctx->cls_ready) {  // the reads the threshold kernel could not finish, as k_correct's work list
+    if (ctx->cls_ready) {  // the reads the threshold kernel could not finish, as a work list
         ctx->work_stride = ((size_t)a.n + 63) & ~(size_t)63;
         if ((rc = rc_dbuf_reserve(ctx, &ctx->worklist, ctx->work_stride * RC_WORK_CLASSES * 4 + 256))) return rc;
-        if ((rc = rc_launch_compact(ctx, (const uint8_t *)ctx->cls.p, a.n, (uint32_t *)ctx->worklist.p, ctx->work_stride,
-                                    (uint32_t *)((char *)ctx->work.p + RC_WORK_NWORK_OFF))))
-            return rc;
+        auto compact = [&]() {
+            return rc_launch_compact(ctx, (const uint8_t *)ctx->cls.p, a.n, (uint32_t *)ctx->worklist.p, ctx->work_stride,
+                                     (uint32_t *)((char *)ctx->work.p + RC_WORK_NWORK_OFF));
+        };
+        // isolated substitutions are finished four reads to a wave (rc_single.h: it clears their cls); what is left is
+        // k_correct's list
+        bool ran = false;
+        if ((rc = rc_launch_single(ctx, a, &ran))) return rc;
+        if ((rc = compact())) return rc;
     }
     if ((rc = rc_launch_correct(ctx, a))) return rc;
     // UpdateSummary (main.cpp:73-79), on the device: the counters live in HBM until rc_summary() asks

@@ -257,6 +257,7 @@ static int fill_args(rc_ctx *ctx, const rc_device_batch_args &a, rc_kernel_args 
     A.strong = (int32_t *)ctx->strong.p;
     A.info = (int32_t *)ctx->info.p;
     A.cls = nullptr;
+    A.cand = nullptr;
     A.worklist = nullptr;
     A.work_stride = 0;
     A.n_work = nullptr;
@@ -290,6 +291,7 @@ static int fill_args(rc_ctx *ctx, const rc_device_batch_args &a, rc_kernel_args 
 int rc_launch_threshold(rc_ctx *ctx, const rc_device_batch_args &a, bool classify)
 {
     ctx->cls_ready = false;
+    ctx->cand_ready = false;
     if (a.n == 0) return RC_OK;
     rc_kernel_args A;
     int rc = fill_args(ctx, a, A);
@@ -301,6 +303,11 @@ int rc_launch_threshold(rc_ctx *ctx, const rc_device_batch_args &a, bool classif
         if ((rc = rc_dbuf_reserve(ctx, &ctx->cls, (size_t)a.n + 256))) return rc;
         A.cls = (uint8_t *)ctx->cls.p;
         ctx->cls_ready = true;
+        if (!ctx->env_no_single && a.max_len <= 160 && a.max_len - ctx->k + 1 <= 128) {  // candidates of k_single (rc_single.h)
+            if ((rc = rc_dbuf_reserve(ctx, &ctx->cand, (size_t)a.n + 256))) return rc;
+            A.cand = (uint8_t *)ctx->cand.p;
+            ctx->cand_ready = true;
+        }
     }
     rc_timer_begin(ctx);
     if (quarter && a.max_len <= 160 && a.max_len - A.P.k + 1 <= 128) {
@@ -322,6 +329,7 @@ int rc_launch_probe_threshold_list(rc_ctx *ctx, const rc_device_batch_args &a, s
 {
     *done = false;
     ctx->cls_ready = false;
+    ctx->cand_ready = false;
     if (a.n == 0 || a.max_len > 160 || a.max_len - ctx->k + 1 > 128 || ctx->k < 4 || ctx->env_k2_wave_per_read || ctx->env_no_fuse) return RC_OK;
     rc_kernel_args A;
     int rc = fill_args(ctx, a, A);
@@ -330,6 +338,11 @@ int rc_launch_probe_threshold_list(rc_ctx *ctx, const rc_device_batch_args &a, s
         if ((rc = rc_dbuf_reserve(ctx, &ctx->cls, (size_t)a.n + 256))) return rc;
         A.cls = (uint8_t *)ctx->cls.p;
         ctx->cls_ready = true;
+        if (!ctx->env_no_single && a.max_len <= 160 && a.max_len - ctx->k + 1 <= 128) {  // candidates of k_single (rc_single.h)
+            if ((rc = rc_dbuf_reserve(ctx, &ctx->cand, (size_t)a.n + 256))) return rc;
+            A.cand = (uint8_t *)ctx->cand.p;
+            ctx->cand_ready = true;
+        }
     }
     // reads per workgroup: a read takes its bases, the NUL and up to 6 bytes of alignment; whole passes
     // of the 16-row threshold code (mates stay together); the small arena unless the large one holds
@@ -357,6 +370,41 @@ int rc_launch_probe_threshold_list(rc_ctx *ctx, const rc_device_batch_args &a, s
     rc_timer_end(ctx, RC_T_PROBE);
     RC_CHECK_HIP(ctx, hipGetLastError());
     *done = true;
+    return RC_OK;
+}
+
+#include "rc_single.h"
+
+// K2s: finish the reads whose correction is one isolated substitution per untrusted stretch (rc_single.h); they leave
+// the work list before it is compacted.  Needs the classification (cls) and K1's counts of the listed reads.
+int rc_launch_single(rc_ctx *ctx, const rc_device_batch_args &a, bool *ran)
+{
+    *ran = false;
+    if (a.n == 0 || !ctx->cls_ready || !ctx->cand_ready || ctx->env_no_single) return RC_OK;
+    if (a.max_len > rcs::MAX_LEN || a.max_len - ctx->k + 1 > rcs::MAX_KCNT || ctx->k < 4 || ctx->P.max_fix_per_k < 2) return RC_OK;
+    rc_kernel_args A;
+    int rc = fill_args(ctx, a, A);
+    if (rc) return rc;
+    // its work list: the reads the threshold kernel flagged as candidates
+    if ((rc = rc_dbuf_reserve(ctx, &ctx->single_list, (size_t)a.n * 4 + 256))) return rc;
+    uint32_t *d_n = (uint32_t *)((char *)ctx->work.p + RC_WORK_NSINGLE_OFF);
+    RC_CHECK_HIP(ctx, hipMemsetAsync(d_n, 0, 16, ctx->stream));
+    if ((rc = rc_launch_compact_flag(ctx, (const uint8_t *)ctx->cand.p, a.n, (uint32_t *)ctx->single_list.p, d_n))) return rc;
+    A.cls = (uint8_t *)ctx->cls.p;
+    A.worklist = (const uint32_t *)ctx->single_list.p;
+    A.work_stride = 0;
+    A.n_work = d_n;
+    rc_timer_begin(ctx);
+    unsigned g = (unsigned)ctx->n_cu * 24u;  // (a few workgroups per CU slot; they walk the list, whose length stays on the device)
+    if (g > (a.n + 15) / 16) g = (a.n + 15) / 16;
+    const dim3 grid(g), block(256);
+    if (ctx->ext)
+        hipLaunchKernelGGL(k_single<true>, grid, block, 0, ctx->stream, A);
+    else
+        hipLaunchKernelGGL(k_single<false>, grid, block, 0, ctx->stream, A);
+    rc_timer_end(ctx, RC_T_SINGLE);
+    RC_CHECK_HIP(ctx, hipGetLastError());
+    *ran = true;
     return RC_OK;
 }
 

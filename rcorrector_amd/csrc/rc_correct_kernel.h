@@ -481,6 +481,7 @@ struct rc_kernel_args {
     const int32_t *counts;  // K1 output, indexed like seq
     int32_t *strong, *info;
     uint8_t *cls;              // K2 -> compaction: 1 = the read still needs k_correct (nullptr: no classification)
+    uint8_t *cand;             // K2 -> k_single: 1 = the read's trusted k-mers have the shape of isolated substitutions (nullptr: not computed)
     const uint32_t *worklist;  // k_correct: the reads to process (nullptr: all of [0, n))
     const uint32_t *n_work;    // k_correct: number of entries of worklist (device memory)
     int32_t *ret, *l, *m, *h;

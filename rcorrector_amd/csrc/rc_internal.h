@@ -54,7 +54,7 @@ struct rc_kernel_timer {
     uint64_t launches = 0;
 };
 
-enum { RC_T_PROBE = 0, RC_T_THRESH = 1, RC_T_CORRECT = 2, RC_T_COUNT };
+enum { RC_T_PROBE = 0, RC_T_THRESH = 1, RC_T_CORRECT = 2, RC_T_SINGLE = 3, RC_T_COUNT };
 
 struct rc_ctx {
     int device = 0;
@@ -102,11 +102,15 @@ struct rc_ctx {
     rc_dbuf info;     // int32 per read
     bool thr_ready = false;  // strong / info hold this batch's thresholds (the threshold kernel ran)
     rc_dbuf cls;      // uint8 per read: 1 = still needs k_correct (written by the threshold kernel)
+    rc_dbuf cand;     // uint8 per read: 1 = candidate of k_single (written by the threshold kernel with cls)
+    rc_dbuf single_list;  // the candidates' read indices, ascending (compaction of cand)
+    bool cand_ready = false;
     rc_dbuf worklist; // RC_WORK_CLASSES sections of work_stride uint32 each: the reads with cls == 4, 3, 2, 1, ascending within a section
     rc_dbuf sel_tmp;  // rocPRIM scratch of the compaction
     rc_dbuf loc_a, loc_list;  // locality order of a batch (rc_launch_locality_order)
     bool env_no_fuse = false;  // RC_NO_FUSE=1 (dev): separate probe and threshold kernels in locality order too
     bool env_k3_generic = false;  // RC_K3_GENERIC=1 (dev / tests): the any-k instance of k_correct even where a compiled-for-k one exists
+    bool env_no_single = false;  // RC_NO_SINGLE=1 (dev / tests): no isolated-substitution kernel, every listed read goes to k_correct
     bool env_no_alt = false;  // RC_NO_ALT=1 (dev / tests): rc_run_params::flags |= RC_PF_NO_ALT
     int locality_mode = 0;  // 0: large batches over large tables, 1: always (RC_LOCALITY=force), -1: never (RC_LOCALITY=off)
     bool cls_ready = false;  // cls / worklist describe this batch
@@ -151,6 +155,7 @@ int rc_launch_digest(rc_ctx *ctx, unsigned long long *d_out);
 int rc_launch_locality_order(rc_ctx *ctx, const struct rc_device_batch_args &a, size_t nbytes);
 int rc_launch_probe_list(rc_ctx *ctx, const struct rc_device_batch_args &a, size_t nbytes, int32_t *d_counts);
 int rc_launch_compact(rc_ctx *ctx, const uint8_t *d_cls, uint32_t n, uint32_t *d_list, size_t stride, uint32_t *d_count);
+int rc_launch_compact_flag(rc_ctx *ctx, const uint8_t *d_flag, uint32_t n, uint32_t *d_list, uint32_t *d_count);
 
 // rc_correct.hip
 struct rc_device_batch_args {
@@ -166,6 +171,7 @@ struct rc_device_batch_args {
 };
 int rc_launch_threshold(rc_ctx *ctx, const rc_device_batch_args &a, bool classify);
 int rc_launch_correct(rc_ctx *ctx, const rc_device_batch_args &a);
+int rc_launch_single(rc_ctx *ctx, const rc_device_batch_args &a, bool *ran);
 int rc_launch_probe_threshold_list(rc_ctx *ctx, const rc_device_batch_args &a, size_t nbytes, bool *done);
 int rc_launch_summary(rc_ctx *ctx, const int32_t *d_ret, uint32_t n);
 
@@ -177,5 +183,6 @@ int rc_launch_summary(rc_ctx *ctx, const int32_t *d_ret, uint32_t n);
 // then the lengths of the work-list sections, then the phase counters of PROF builds
 #define RC_WORK_BYTES 5120
 #define RC_WORK_NWORK_OFF 4096
+#define RC_WORK_NSINGLE_OFF 4160  // 4 x uint32: length of k_single's list, 0, 0, 0 (it reads it like the four section lengths)
 #define RC_WORK_PHASE_OFF 4224
 #define RC_WORK_SUMMARY_OFF 4608  // 2 x uint64: reads, corrected bases (never reset)

@@ -292,6 +292,53 @@ __device__ __forceinline__ int rcq_threshold_row(const rc_kernel_args &A, uint32
         const int vm = __builtin_amdgcn_ds_bpermute((row_lane0 + (im & 15)) << 2, sm);
         const int vh = __builtin_amdgcn_ds_bpermute((row_lane0 + (ih & 15)) << 2, sh);
         if (!screened && n_below < kcnt) cls = n_below >= kcnt - (kcnt >> 3) ? 4 : (n_below >= kcnt - (kcnt >> 2) ? 3 : (n_below >= kcnt - (kcnt >> 1) ? 2 : 1));
+        // Candidate for k_single (rc_single.h, condition (2)): every letter ACGT, and the trusted mask -- counts >= s and
+        // not poly-A at threshold 2 (:870-931) -- starts and ends with a 1, has no 1-run of length one and only 0-runs
+        // of exactly k.  k_single checks it again (it needs the runs' positions anyway); this flag only keeps the
+        // reads that cannot pass out of its work list, so that its rows are filled with reads that mostly do.
+        if (A.cand) {
+            bool cand = false;
+            if constexpr (E_CNT == 8) {
+                uint32_t other = 0, tb[E_CNT];
+#pragma unroll
+                for (int e = 0; e < E_BASE; ++e) other |= row_bits(__ballot(code[e] >= 4 && e * 16 + l < len), row);
+#pragma unroll
+                for (int e = 0; e < E_CNT; ++e) {
+                    const int g = e * 16 + l;
+                    const uint32_t shf = (uint32_t)((e & 1) * 16 + l);
+                    const int na = __popc(__builtin_amdgcn_alignbit(ma[(e >> 1) + 1], ma[e >> 1], shf) & kmask);
+                    const int nt = __popc(__builtin_amdgcn_alignbit(mt[(e >> 1) + 1], mt[e >> 1], shf) & kmask);
+                    const int cg = g < kcnt ? count_at(g) : 0;
+                    tb[e] = row_bits(__ballot(g < kcnt && cg >= s && na < k - 2 && nt < k - 2), row);
+                }
+                if (!clean && !screened && other == 0 && kcnt >= k + 4) {
+                    const uint64_t lo = (uint64_t)tb[0] | ((uint64_t)tb[1] << 16) | ((uint64_t)tb[2] << 32) | ((uint64_t)tb[3] << 48);
+                    const uint64_t hi = (uint64_t)tb[4] | ((uint64_t)tb[5] << 16) | ((uint64_t)tb[6] << 32) | ((uint64_t)tb[7] << 48);
+                    auto get = [&](int i) { return i < 64 ? (lo >> i) & 1ull : (hi >> (i - 64)) & 1ull; };
+                    // Z = zero bits inside [0, kcnt); shifts over the 128-bit pair
+                    const uint64_t mlo = kcnt >= 64 ? ~0ull : ((1ull << kcnt) - 1ull), mhi = kcnt > 64 ? (kcnt >= 128 ? ~0ull : ((1ull << (kcnt - 64)) - 1ull)) : 0ull;
+                    const uint64_t zlo = ~lo & mlo, zhi = ~hi & mhi;
+                    const uint64_t iso_lo = lo & ~(lo << 1) & ~((lo >> 1) | (hi << 63)), iso_hi = hi & ~((hi << 1) | (lo >> 63)) & ~(hi >> 1);
+                    // starts and ends of the 0-runs: paired in order, every end must be its start + k - 1
+                    uint64_t slo = zlo & ~(zlo << 1), shi = zhi & ~((zhi << 1) | (zlo >> 63));
+                    uint64_t elo = zlo & ~((zlo >> 1) | (zhi << 63)), ehi = zhi & ~(zhi >> 1);
+                    const int nruns = __popcll(slo) + __popcll(shi);
+                    bool shape = get(0) && get(kcnt - 1) && (iso_lo | iso_hi) == 0 && nruns >= 1 && nruns <= 3;
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        if (shape && q < nruns) {
+                            const int z0 = slo ? __ffsll((long long)slo) - 1 : 64 + __ffsll((long long)shi) - 1;
+                            const int z1 = elo ? __ffsll((long long)elo) - 1 : 64 + __ffsll((long long)ehi) - 1;
+                            if (slo) slo &= slo - 1; else shi &= shi - 1;
+                            if (elo) elo &= elo - 1; else ehi &= ehi - 1;
+                            shape = z1 - z0 + 1 == k;
+                        }
+                    }
+                    cand = shape;
+                }
+            }
+            if (live && l == 0) A.cand[r] = cand ? 1 : 0;
+        }
         if (clean) {
             cls = 0;
             if (live && l == 0) {

@@ -1,0 +1,361 @@
+// rc_single.h -- K2s, "isolated substitutions": reads whose whole correction is one substitution per untrusted stretch
+// are finished here, four reads per wavefront (one per 16-lane row, as rc_quarter.h), and never reach k_correct.
+//
+// What a sequencing error in the middle of a well-covered read looks like to ErrorCorrection (ErrorCorrection.cpp:682-1480):
+// the k k-mers that contain base p fall below the strong threshold, every other k-mer stays above it.  The function then
+// builds two islands around p (:870-1007), one single-base segment [p, p] (:1009-1046), searches it from the larger
+// anchor (:1125-1175): the first node offers the base's alternatives (:343-371 / :577-607), the k-1 (right) or k (left)
+// nodes behind it lie inside the other island -- no substitutions there (:343 / :577), only "keep the base" -- the path
+// ends with one fix, nothing else is ever explored, no veto applies to a lone fix (:1296-1466), the base is replaced
+// (:1468-1479) and GetKmerInformation re-counts the k k-mers around it (:1567-1602).  This kernel replays exactly that --
+// and ONLY that: every step is guarded by the condition under which the general code takes the same turn, and a read that
+// fails any of them is left untouched for k_correct.  The conditions, with s / t the iteration's strong and weak
+// thresholds (:793-842, pair override included):
+//   (1) every letter is one of ACGT; the screens passed (:735-755);
+//   (2) the trusted mask T[i] = counts[i] >= s && !IsPolyA(i, 2) (:870-931) starts and ends with a 1, its 1-runs are
+//       all at least 2 long (each is an island: no fall-back island, :1002-1007), its 0-runs are all exactly k long --
+//       so consecutive islands are k + 1 k-mers apart and no boundary moves (:934-965 needs a distance <= k), the base
+//       space islands leave exactly the base p = last k-mer of the 0-run between them -- and there are at most
+//       min(3, MAX_FIX_PER_K - 1) of them (below every veto's trigger, :1407, :1432; fixes of different segments are
+//       more than k apart, so the pairwise veto :1314 sees none);
+//   (3) at p's node: the own base fails its threshold (count < threshold, so "keep" is not taken, :302 / :539) and it
+//       is not the accidental-gap case (:313 / :550: threshold == 1 && t <= 2); p's k-mer is not poly-A (:343 / :577
+//       would forbid substitutions); exactly ONE alternative reaches the threshold (a second one would open a second
+//       path), and its count is >= t;
+//   (4) at every node behind p: the keep-base count x is >= t -- the node's threshold never exceeds the t handed down
+//       (:165-172), so the base is kept whatever the other three extensions count -- and, in left searches, which hand the
+//       node's threshold down as the next t (:546), x >= bs[t]: the bound of x, hence of the largest extension, reaches t,
+//       the threshold IS t, t stays (rc_run_params::bs; t >= RC_BS_INLINE is left to k_correct);
+//   (5) the path's bottleneck (the smallest count on it) is >= t, so the terminal adds no fix (:243 / :483) and the
+//       path is accepted with fix count 1 < maxFixCnt (MAX_FIX_PER_K >= 2); with one candidate there is no frame to pop;
+//   (6) the smallest bottleneck over the segments is not below GetBound(s) (:1195 would force another iteration).
+// Then ret = number of segments, the bases are replaced, and l / m / h come from the counts with the k windows around
+// each fix replaced by the counts the path just fetched (the k-th window, which a right search never visits, is
+// fetched for this purpose).  tests: every GPU parity set and fuzz seed runs with this kernel in the path;
+// RC_NO_SINGLE=1 takes it out (knob matrix); a Python restatement of the same conditions was checked against the
+// oracle on every data set first.
+#pragma once
+
+#ifndef RC_K2S_WAVES
+#define RC_K2S_WAVES 6
+#endif
+namespace rcs {
+
+struct u128 {
+    uint64_t lo, hi;
+};
+__device__ __forceinline__ u128 shl1(u128 a) { return u128{a.lo << 1, (a.hi << 1) | (a.lo >> 63)}; }
+__device__ __forceinline__ u128 shr1(u128 a) { return u128{(a.lo >> 1) | (a.hi << 63), a.hi >> 1}; }
+__device__ __forceinline__ u128 band(u128 a, u128 b) { return u128{a.lo & b.lo, a.hi & b.hi}; }
+__device__ __forceinline__ u128 bnot(u128 a) { return u128{~a.lo, ~a.hi}; }
+__device__ __forceinline__ int popc(u128 a) { return __popcll(a.lo) + __popcll(a.hi); }
+__device__ __forceinline__ bool any(u128 a) { return (a.lo | a.hi) != 0; }
+__device__ __forceinline__ int ctz(u128 a) { return a.lo ? __ffsll((long long)a.lo) - 1 : 64 + __ffsll((long long)a.hi) - 1; }  // a != 0
+__device__ __forceinline__ u128 clear_lowest(u128 a)
+{
+    if (a.lo) return u128{a.lo & (a.lo - 1), a.hi};
+    return u128{0, a.hi & (a.hi - 1)};
+}
+__device__ __forceinline__ bool bit(u128 a, int i) { return i < 64 ? (a.lo >> i) & 1ull : (a.hi >> (i - 64)) & 1ull; }
+__device__ __forceinline__ u128 low_mask(int n)  // n in [1, 128]
+{
+    if (n >= 128) return u128{~0ull, ~0ull};
+    if (n >= 64) return u128{~0ull, n == 64 ? 0ull : ((1ull << (n - 64)) - 1ull)};
+    return u128{(1ull << n) - 1ull, 0ull};
+}
+
+constexpr int MAX_KCNT = 128, MAX_LEN = 160, PK_WORDS = MAX_LEN / 16 + 2, MAX_SEG = 3;
+
+}  // namespace rcs
+
+// one 16-lane row, one read (r = 0xFFFFFFFF: none); s_cnt / s_pk: the row's LDS (rows of a wave do not share any)
+template <bool EXT>
+__device__ __forceinline__ void rcs_row(const rc_kernel_args &A, uint32_t r, int32_t *s_cnt_row, uint32_t *s_pk_row)
+{
+    using namespace rcs;
+    const int lane = threadIdx.x & 63, row = lane >> 4, l = lane & 15, row_lane0 = row << 4;
+    const int k = A.P.k, mfk = A.P.max_fix_per_k;
+    const double er = A.P.error_rate;
+    auto wsync = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    auto row_any = [&](bool p) { return rcq::row_bits(__ballot(p), row) != 0; };
+
+    bool ok = r < A.n && mfk >= 2;
+    uint32_t o = 0;
+    int len = 0, strong0 = 0, info0 = 4, pair_t = -1;
+    if (ok) {
+        o = A.off[r];
+        len = (int)(A.off[r + 1] - o) - 1;
+        strong0 = A.strong[r];
+        info0 = A.info[r];
+        if (A.mode == 1) {
+            const uint32_t half = A.n >> 1;
+            const int ms = A.strong[r < half ? r + half : r - half];
+            pair_t = strong0 < ms ? strong0 : ms;
+        } else if (A.mode == 2) {
+            const int ms = A.strong[r ^ 1u];
+            pair_t = strong0 < ms ? strong0 : ms;
+        }
+    }
+    const int kcnt = len - k + 1;
+    ok = ok && !(info0 & 4) && len >= k && len <= MAX_LEN && kcnt <= MAX_KCNT && kcnt >= 5;
+
+    // thresholds of the first iteration, ErrorCorrection.cpp:793-842
+    int s = strong0, t = 2;
+    if (ok) {
+        bool flag = false;
+        int trust = rc_bound_i(s, er);
+        if ((info0 & 1) && s >= 20 && (info0 & 2) && trust < 3) {
+            flag = true;
+            trust = 3;
+        }
+        if (pair_t >= 1 && s > pair_t) {
+            if (!flag || pair_t < 20) trust = rc_bound_i(pair_t, er);
+            s = pair_t;
+        }
+        t = trust < 2 ? 2 : trust;
+    }
+
+    if (!__ballot(ok)) return;  // (no row of this wave has a read: nothing below touches another wave)
+    // bases: codes in registers, the packed read in LDS (ds_or of every base's two bits), letter masks for IsPolyA
+    bool bad_letter = false;
+    if (l < PK_WORDS) s_pk_row[l] = 0;
+    wsync();
+    uint32_t ma[6] = {0, 0, 0, 0, 0, 0}, mt[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < 10; ++e) {
+        const int p = e * 16 + l;
+        const int c = (ok && p < len) ? rc_base_code(A.seq[o + p]) : 7;
+        if (p < len && c >= 4) bad_letter = true;
+        if (ok && p < len) atomicOr(&s_pk_row[e], (uint32_t)(c & 3) << (30 - 2 * l));
+        ma[e >> 1] |= rcq::row_bits(__ballot(c == 0), row) << ((e & 1) * 16);
+        mt[e >> 1] |= rcq::row_bits(__ballot(c == 3), row) << ((e & 1) * 16);
+    }
+    ok = ok && !row_any(ok && bad_letter);
+    const uint32_t kmask = k >= 32 ? 0xffffffffu : ((1u << k) - 1u);
+    // IsPolyA(window g, 2), ErrorCorrection.cpp:53-71: >= k - 2 A's or T's among the window's k letters
+    auto polya2 = [&](int g) -> bool {
+        const int w = g >> 5;
+        const uint32_t sh = (uint32_t)(g & 31);
+        uint32_t a_lo = ma[0], a_hi = ma[1], t_lo = mt[0], t_hi = mt[1];
+#pragma unroll
+        for (int j = 1; j < 5; ++j) {
+            a_lo = w == j ? ma[j] : a_lo;
+            a_hi = w == j ? ma[j + 1] : a_hi;
+            t_lo = w == j ? mt[j] : t_lo;
+            t_hi = w == j ? mt[j + 1] : t_hi;
+        }
+        const int na = __popc(__builtin_amdgcn_alignbit(a_hi, a_lo, sh) & kmask), nt = __popc(__builtin_amdgcn_alignbit(t_hi, t_lo, sh) & kmask);
+        return na >= k - 2 || nt >= k - 2;
+    };
+
+    // K1's counts -> LDS; the trusted mask
+    u128 T{0, 0};
+    {
+        uint32_t tb[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int g = e * 16 + l;
+            int v = 0;
+            if (ok && g < kcnt) v = A.counts[o + g];
+            s_cnt_row[g] = v;
+            // (window g = e * 16 + l: word e / 2, shift (e % 2) * 16 + l -- compile-time word, cf. rc_quarter.h)
+            const uint32_t sh = (uint32_t)((e & 1) * 16 + l);
+            const int na = __popc(__builtin_amdgcn_alignbit(ma[(e >> 1) + 1], ma[e >> 1], sh) & kmask);
+            const int nt = __popc(__builtin_amdgcn_alignbit(mt[(e >> 1) + 1], mt[e >> 1], sh) & kmask);
+            tb[e] = rcq::row_bits(__ballot(ok && g < kcnt && v >= s && na < k - 2 && nt < k - 2), row);
+        }
+        T.lo = (uint64_t)tb[0] | ((uint64_t)tb[1] << 16) | ((uint64_t)tb[2] << 32) | ((uint64_t)tb[3] << 48);
+        T.hi = (uint64_t)tb[4] | ((uint64_t)tb[5] << 16) | ((uint64_t)tb[6] << 32) | ((uint64_t)tb[7] << 48);
+    }
+    wsync();
+    // condition (2)
+    int ns = 0;
+    u128 zs{0, 0}, ze{0, 0};
+    if (ok) {
+        const u128 M = low_mask(kcnt);
+        const u128 Z = band(bnot(T), M);
+        zs = band(Z, bnot(shl1(Z)));
+        ze = band(Z, bnot(band(shr1(Z), M)));
+        ns = popc(zs);
+        const u128 iso = band(band(T, bnot(shl1(T))), bnot(shr1(T)));
+        const int max_seg = mfk - 1 < MAX_SEG ? mfk - 1 : MAX_SEG;
+        ok = bit(T, 0) && bit(T, kcnt - 1) && !any(iso) && ns >= 1 && ns <= max_seg;
+    }
+    if (!__ballot(ok)) return;
+    uint32_t Bt = 0;  // condition (4), left searches
+    const bool bs_ok = A.P.bs[0] != 0 && t < RC_BS_INLINE;
+    if (bs_ok) Bt = A.P.bs[t];
+
+    // 2-bit code of the n <= 32 bases starting at base q (cf. rc_code_at)
+    auto code_at = [&](int q) -> uint64_t {
+        const uint32_t *pk = s_pk_row;
+        const int w0 = q >> 4, sh = 2 * (q & 15);
+        uint64_t x = ((uint64_t)pk[w0] << 32) | pk[w0 + 1];
+        if (sh) x = (x << sh) | ((uint64_t)pk[w0 + 2] >> (32 - sh));
+        return x >> (64 - 2 * k);
+    };
+    auto base_at = [&](int q) -> int { return (int)((s_pk_row[q >> 4] >> (30 - 2 * (q & 15))) & 3u); };
+
+    int fixp0 = 0, fixp1 = 0, fixp2 = 0, fixc0 = 0, fixc1 = 0, fixc2 = 0;  // (named: a run-time index would put them in scratch)
+    int best_bott = 2147483647, prev_z1 = -1;
+    for (int si = 0; si < MAX_SEG; ++si) {
+        if (!__ballot(ok && si < ns)) break;  // (no row of the wave has a segment left)
+        const bool act = ok && si < ns;   // (row-uniform)
+        int z0 = 0, z1 = 0, next_z0 = kcnt;
+        if (act) {
+            z0 = ctz(zs);
+            z1 = ctz(ze);
+            zs = clear_lowest(zs);
+            ze = clear_lowest(ze);
+            if (any(zs)) next_z0 = ctz(zs);
+        }
+        bool good = act && z1 - z0 + 1 == k;
+        const int p = z1;                                                   // the base every k-mer of the 0-run holds
+        const bool right = (z0 - prev_z1 - 1) >= (next_z0 - z1 - 1);        // lanchor >= ranchor (:1136): the islands' lengths
+        prev_z1 = z1;
+        const int win = right ? z0 : z1;                                    // k-mer of p's node: it ends (right) / starts (left) at p
+        const int b = good ? base_at(p) : 0;
+        // round A: the four extensions of the anchor at p (the own base's count is K1's)
+        int cA = 0;
+        if (good && l < 4) {
+            if (l == b)
+                cA = s_cnt_row[win];
+            else {
+                const uint64_t km = code_at(win) ^ ((uint64_t)(b ^ l) << (2 * (k - 1 - (p - win))));
+                cA = rc_table_lookup<EXT>(A.T, rc_canonical(km, k));
+            }
+        }
+        const int c0 = __shfl(cA, row_lane0 + 0, 64), c1 = __shfl(cA, row_lane0 + 1, 64), c2 = __shfl(cA, row_lane0 + 2, 64), c3 = __shfl(cA, row_lane0 + 3, 64);
+        int cstar = 0, cnt_star = 0;
+        if (good) {
+            int mx = c0 > c1 ? c0 : c1;
+            mx = c2 > mx ? c2 : mx;
+            mx = c3 > mx ? c3 : mx;
+            mx = mx > 0 ? mx : 0;
+            int ret = rc_bound_i(mx, er);
+            if (ret < 1) ret = 1;
+            const int thr = (t > ret || t <= 0) ? ret : t;                  // InferPosThreshold, :165-172
+            const int own = b == 0 ? c0 : (b == 1 ? c1 : (b == 2 ? c2 : c3));
+            const int m0 = (b != 0 && c0 >= thr) ? 1 : 0, m1 = (b != 1 && c1 >= thr) ? 1 : 0, m2 = (b != 2 && c2 >= thr) ? 1 : 0, m3 = (b != 3 && c3 >= thr) ? 1 : 0;
+            cstar = m0 ? 0 : (m1 ? 1 : (m2 ? 2 : 3));
+            cnt_star = cstar == 0 ? c0 : (cstar == 1 ? c1 : (cstar == 2 ? c2 : c3));
+            good = own < thr && !(thr == 1 && t <= 2) && !polya2(win) && (m0 + m1 + m2 + m3) == 1 && cnt_star >= t;   // condition (3)
+            if (!right) good = good && bs_ok;
+        }
+        // round B: the other k - 1 windows of the 0-run with p replaced: the nodes behind p and, in a right search, the
+        // window that starts at p (for GetKmerInformation only)
+        int bott = cnt_star;
+        bool fail = false;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int j = h * 16 + l;
+            const int wj = z0 + j;
+            if (good && j < k && wj != win) {
+                const uint64_t km = code_at(wj) ^ ((uint64_t)(b ^ cstar) << (2 * (k - 1 - (p - wj))));
+                const int x = rc_table_lookup<EXT>(A.T, rc_canonical(km, k));
+                const bool node = right ? wj < z1 : true;                   // (right: wj == z1 is the extra window)
+                if (node) {
+                    if (x < t || (!right && (uint32_t)x < Bt)) fail = true;  // condition (4)
+                    bott = x < bott ? x : bott;
+                }
+                s_cnt_row[wj] = x;
+            }
+        }
+        if (good && l == 0) s_cnt_row[win] = cnt_star;
+        good = good && !row_any(fail);
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) {
+            const int y = __shfl_xor(bott, m, 16);
+            bott = y < bott ? y : bott;
+        }
+        good = good && bott >= t;                                           // condition (5)
+        if (act) {
+            ok = good;
+            fixp0 = si == 0 ? p : fixp0;
+            fixp1 = si == 1 ? p : fixp1;
+            fixp2 = si == 2 ? p : fixp2;
+            fixc0 = si == 0 ? cstar : fixc0;
+            fixc1 = si == 1 ? cstar : fixc1;
+            fixc2 = si == 2 ? cstar : fixc2;
+            best_bott = bott < best_bott ? bott : best_bott;
+        }
+        wsync();
+    }
+    if (ok && rc_less_than_bound(best_bott, s, er)) ok = false;             // condition (6)
+    if (!__ballot(ok)) return;
+
+    // GetKmerInformation of the corrected read: sort the counts (0 shown as 1, :1583), pick min / element kcnt/2 / max
+    int x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int g = e * 16 + l;
+        int v = s_cnt_row[g];
+        v = v == 0 ? 1 : v;
+        x[e] = (ok && g < kcnt) ? v : 2147483647;
+    }
+    int c4[4];
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb) c4[bb] = __builtin_amdgcn_sbfe(l, bb, 1) ^ (int)0x80000000;
+    rcq::merges<8, 2>(x, c4);
+    const int im = kcnt > 0 ? kcnt >> 1 : 0, ih = kcnt > 0 ? kcnt - 1 : 0;
+    int sm = x[0], sh = x[0];
+#pragma unroll
+    for (int e = 1; e < 8; ++e) {
+        sm = (im >> 4) == e ? x[e] : sm;
+        sh = (ih >> 4) == e ? x[e] : sh;
+    }
+    const int v0 = __builtin_amdgcn_ds_bpermute(row_lane0 << 2, x[0]);
+    const int vm = __builtin_amdgcn_ds_bpermute((row_lane0 + (im & 15)) << 2, sm);
+    const int vh = __builtin_amdgcn_ds_bpermute((row_lane0 + (ih & 15)) << 2, sh);
+    if (ok) {
+        if (l < ns) {
+            const int fp = l == 0 ? fixp0 : (l == 1 ? fixp1 : fixp2), fc = l == 0 ? fixc0 : (l == 1 ? fixc1 : fixc2);
+            A.seq[o + (uint32_t)fp] = (uint8_t)("ACGT"[fc]);
+        }
+        if (l == 0) {
+            A.ret[r] = ns;
+            A.l[r] = v0;
+            A.m[r] = vm;
+            A.h[r] = vh;
+            A.cls[r] = 0;
+        }
+    }
+}
+
+// reads of up to 160 bases / 128 k-mers; 256 threads = 16 reads per pass.  The reads come off the work list
+// (RC_WORK_CLASSES sections, rc_internal.h), whose length stays on the device: a fixed grid of workgroups walks the
+// concatenated sections (a workgroup per 16 reads would be 1.5 M workgroups for 25 M reads, a third of them empty)
+template <bool EXT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RC_K2S_WAVES, RC_K2S_WAVES))) void k_single(rc_kernel_args A)
+{
+    using namespace rcs;
+    __shared__ int32_t s_cnt[16][MAX_KCNT];
+    __shared__ uint32_t s_pk[16][PK_WORDS];
+    const int rr = (int)(threadIdx.x >> 6) * 4 + (int)((threadIdx.x & 63) >> 4);
+    const uint32_t n0 = A.n_work[0], n1 = A.n_work[1], n2 = A.n_work[2], n3 = A.n_work[3];
+    const uint32_t total = n0 + n1 + n2 + n3;
+    for (uint32_t base = blockIdx.x * 16u; base < total; base += gridDim.x * 16u) {
+        uint32_t g = base + (uint32_t)rr, r = 0xFFFFFFFFu;
+        if (g < total) {
+            int c = 0;
+            if (g >= n0) {
+                g -= n0;
+                c = 1;
+                if (g >= n1) {
+                    g -= n1;
+                    c = 2;
+                    if (g >= n2) {
+                        g -= n2;
+                        c = 3;
+                    }
+                }
+            }
+            r = A.worklist[(size_t)c * A.work_stride + g];
+        }
+        rcs_row<EXT>(A, r, s_cnt[rr], s_pk[rr]);
+    }
+}

@@ -490,6 +490,19 @@ int rc_launch_compact(rc_ctx *ctx, const uint8_t *d_cls, uint32_t n, uint32_t *d
     return RC_OK;
 }
 
+// d_list = the indices i in [0, n) with d_flag[i] == 1, ascending; *d_count = how many
+int rc_launch_compact_flag(rc_ctx *ctx, const uint8_t *d_flag, uint32_t n, uint32_t *d_list, uint32_t *d_count)
+{
+    rocprim::counting_iterator<uint32_t> ids(0);
+    auto flags = rocprim::make_transform_iterator(d_flag, rc_cls_is{(uint8_t)1});
+    size_t tmp = 0;
+    RC_CHECK_HIP(ctx, rocprim::select(nullptr, tmp, ids, flags, d_list, d_count, (size_t)n, ctx->stream));
+    int rc = rc_dbuf_reserve(ctx, &ctx->sel_tmp, tmp);
+    if (rc) return rc;
+    RC_CHECK_HIP(ctx, rocprim::select(ctx->sel_tmp.p, tmp, ids, flags, d_list, d_count, (size_t)n, ctx->stream));
+    return RC_OK;
+}
+
 // ---- locality order of a batch -------------------------------------------------------------------
 // Reads arrive in sequencer order, i.e. random with respect to the transcripts they come from, so the
 // ~130 probes of a read hit ~130 unrelated buckets and nearly every one of them is an HBM access.

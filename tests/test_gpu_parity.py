@@ -727,7 +727,8 @@ def test_k31_maxcork8_on_a_packed_table_with_extension_bits(oracle):
 KNOBS = [{"RC_TABLE_LAYOUT": "wide"}, {"RC_TABLE_LOAD": "0.85"}, {"RC_TABLE_LOAD": "0.25"}, {"RC_LOCALITY": "force"},
          {"RC_NO_FUSE": "1", "RC_LOCALITY": "force"}, {"RC_K2_WAVE_PER_READ": "1"}, {"RC_NO_CLASSIFY": "1"},
          {"RC_NO_ALT": "1"}, {"RC_K3_GENERIC": "1"}, {"RC_K3_GENERIC": "1", "RC_NO_ALT": "1", "RC_LOCALITY": "force"},
-         {"RC_TABLE_FILTER": "force"}, {"RC_TABLE_FILTER": "force", "RC_LOCALITY": "force", "RC_TABLE_LOAD": "0.85"}]
+         {"RC_TABLE_FILTER": "force"}, {"RC_TABLE_FILTER": "force", "RC_LOCALITY": "force", "RC_TABLE_LOAD": "0.85"},
+         {"RC_NO_SINGLE": "1"}, {"RC_NO_SINGLE": "1", "RC_NO_ALT": "1"}]
 
 
 @pytest.mark.gpu
