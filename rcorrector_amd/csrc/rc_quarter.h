@@ -293,8 +293,8 @@ __device__ __forceinline__ int rcq_threshold_row(const rc_kernel_args &A, uint32
         const int vh = __builtin_amdgcn_ds_bpermute((row_lane0 + (ih & 15)) << 2, sh);
         if (!screened && n_below < kcnt) cls = n_below >= kcnt - (kcnt >> 3) ? 4 : (n_below >= kcnt - (kcnt >> 2) ? 3 : (n_below >= kcnt - (kcnt >> 1) ? 2 : 1));
         // Candidate for k_single (rc_single.h, condition (2)): every letter ACGT, and the trusted mask -- counts >= s and
-        // not poly-A at threshold 2 (:870-931) -- starts and ends with a 1, has no 1-run of length one and only 0-runs
-        // of exactly k.  k_single checks it again (it needs the runs' positions anyway); this flag only keeps the
+        // not poly-A at threshold 2 (:870-931) -- has no 1-run of length one and only 0-runs of exactly k, or of at most k
+        // at either end of the read.  k_single checks it again (it needs the runs' positions anyway); this flag only keeps the
         // reads that cannot pass out of its work list, so that its rows are filled with reads that mostly do.
         if (A.cand) {
             bool cand = false;
@@ -311,10 +311,9 @@ __device__ __forceinline__ int rcq_threshold_row(const rc_kernel_args &A, uint32
                     const int cg = g < kcnt ? count_at(g) : 0;
                     tb[e] = row_bits(__ballot(g < kcnt && cg >= s && na < k - 2 && nt < k - 2), row);
                 }
-                if (!clean && !screened && other == 0 && kcnt >= k + 4) {
+                if (!clean && !screened && other == 0 && kcnt >= 5) {
                     const uint64_t lo = (uint64_t)tb[0] | ((uint64_t)tb[1] << 16) | ((uint64_t)tb[2] << 32) | ((uint64_t)tb[3] << 48);
                     const uint64_t hi = (uint64_t)tb[4] | ((uint64_t)tb[5] << 16) | ((uint64_t)tb[6] << 32) | ((uint64_t)tb[7] << 48);
-                    auto get = [&](int i) { return i < 64 ? (lo >> i) & 1ull : (hi >> (i - 64)) & 1ull; };
                     // Z = zero bits inside [0, kcnt); shifts over the 128-bit pair
                     const uint64_t mlo = kcnt >= 64 ? ~0ull : ((1ull << kcnt) - 1ull), mhi = kcnt > 64 ? (kcnt >= 128 ? ~0ull : ((1ull << (kcnt - 64)) - 1ull)) : 0ull;
                     const uint64_t zlo = ~lo & mlo, zhi = ~hi & mhi;
@@ -323,7 +322,7 @@ __device__ __forceinline__ int rcq_threshold_row(const rc_kernel_args &A, uint32
                     uint64_t slo = zlo & ~(zlo << 1), shi = zhi & ~((zhi << 1) | (zlo >> 63));
                     uint64_t elo = zlo & ~((zlo >> 1) | (zhi << 63)), ehi = zhi & ~(zhi >> 1);
                     const int nruns = __popcll(slo) + __popcll(shi);
-                    bool shape = get(0) && get(kcnt - 1) && (iso_lo | iso_hi) == 0 && nruns >= 1 && nruns <= 3;
+                    bool shape = (lo | hi) != 0 && (iso_lo | iso_hi) == 0 && nruns >= 1 && nruns <= 3;
 #pragma unroll
                     for (int q = 0; q < 3; ++q) {
                         if (shape && q < nruns) {
@@ -331,7 +330,7 @@ __device__ __forceinline__ int rcq_threshold_row(const rc_kernel_args &A, uint32
                             const int z1 = elo ? __ffsll((long long)elo) - 1 : 64 + __ffsll((long long)ehi) - 1;
                             if (slo) slo &= slo - 1; else shi &= shi - 1;
                             if (elo) elo &= elo - 1; else ehi &= ehi - 1;
-                            shape = z1 - z0 + 1 == k;
+                            shape = z1 - z0 + 1 == k || ((z0 == 0 || z1 == kcnt - 1) && z1 - z0 + 1 < k);
                         }
                     }
                     cand = shape;

@@ -12,12 +12,14 @@
 // fails any of them is left untouched for k_correct.  The conditions, with s / t the iteration's strong and weak
 // thresholds (:793-842, pair override included):
 //   (1) every letter is one of ACGT; the screens passed (:735-755);
-//   (2) the trusted mask T[i] = counts[i] >= s && !IsPolyA(i, 2) (:870-931) starts and ends with a 1, its 1-runs are
-//       all at least 2 long (each is an island: no fall-back island, :1002-1007), its 0-runs are all exactly k long --
-//       so consecutive islands are k + 1 k-mers apart and no boundary moves (:934-965 needs a distance <= k), the base
-//       space islands leave exactly the base p = last k-mer of the 0-run between them -- and there are at most
-//       min(3, MAX_FIX_PER_K - 1) of them (below every veto's trigger, :1407, :1432; fixes of different segments are
-//       more than k apart, so the pairwise veto :1314 sees none);
+//   (2) the trusted mask T[i] = counts[i] >= s && !IsPolyA(i, 2) (:870-931) has 1-runs that are all at least 2 long (each
+//       is an island: no fall-back island, :1002-1007) and 0-runs that are exactly k long inside the read -- so
+//       consecutive islands are k + 1 k-mers apart and no boundary moves (:934-965 needs a distance <= k), the base space
+//       islands leave exactly the base p = last k-mer of the 0-run between them -- or at most k long at either end of
+//       the read: an error less than k bases from the end, whose segment runs from p to the read's end and is searched
+//       from its only anchor with `extend` = 0 (:1016-1022, :1038-1044, :1138, :1152): p's node, then one node per
+//       remaining base.  There are at most min(3, MAX_FIX_PER_K - 1) 0-runs (below every veto's trigger, :1407, :1432;
+//       fixes of different segments are more than k apart, so the pairwise veto :1314 sees none);
 //   (3) at p's node: the own base fails its threshold (count < threshold, so "keep" is not taken, :302 / :539) and it
 //       is not the accidental-gap case (:313 / :550: threshold == 1 && t <= 2); p's k-mer is not poly-A (:343 / :577
 //       would forbid substitutions); exactly ONE alternative reaches the threshold (a second one would open a second
@@ -183,7 +185,7 @@ __device__ __forceinline__ void rcs_row(const rc_kernel_args &A, uint32_t r, int
         ns = popc(zs);
         const u128 iso = band(band(T, bnot(shl1(T))), bnot(shr1(T)));
         const int max_seg = mfk - 1 < MAX_SEG ? mfk - 1 : MAX_SEG;
-        ok = bit(T, 0) && bit(T, kcnt - 1) && !any(iso) && ns >= 1 && ns <= max_seg;
+        ok = any(T) && !any(iso) && ns >= 1 && ns <= max_seg;
     }
     if (!__ballot(ok)) return;
     uint32_t Bt = 0;  // condition (4), left searches
@@ -213,8 +215,12 @@ __device__ __forceinline__ void rcs_row(const rc_kernel_args &A, uint32_t r, int
             ze = clear_lowest(ze);
             if (any(zs)) next_z0 = ctz(zs);
         }
-        bool good = act && z1 - z0 + 1 == k;
-        const int p = z1;                                                   // the base every k-mer of the 0-run holds
+        // a 0-run inside the read is k long; one at either end of the read is at most k long (the error is less than k
+        // bases from that end) -- the segment then runs to the read's end (:1009-1046, `extend` = 0 at :1138 / :1152)
+        const int zlen = z1 - z0 + 1;
+        const bool at_start = z0 == 0, at_end = z1 == kcnt - 1;
+        bool good = act && (zlen == k || ((at_start || at_end) && zlen < k));
+        const int p = at_start ? z1 : z0 + k - 1;                           // the base every k-mer of the 0-run holds
         const bool right = (z0 - prev_z1 - 1) >= (next_z0 - z1 - 1);        // lanchor >= ranchor (:1136): the islands' lengths
         prev_z1 = z1;
         const int win = right ? z0 : z1;                                    // k-mer of p's node: it ends (right) / starts (left) at p
@@ -254,10 +260,10 @@ __device__ __forceinline__ void rcs_row(const rc_kernel_args &A, uint32_t r, int
         for (int h = 0; h < 2; ++h) {
             const int j = h * 16 + l;
             const int wj = z0 + j;
-            if (good && j < k && wj != win) {
+            if (good && j < zlen && wj != win) {
                 const uint64_t km = code_at(wj) ^ ((uint64_t)(b ^ cstar) << (2 * (k - 1 - (p - wj))));
                 const int x = rc_table_lookup<EXT>(A.T, rc_canonical(km, k));
-                const bool node = right ? wj < z1 : true;                   // (right: wj == z1 is the extra window)
+                const bool node = (right && !at_end) ? wj < z1 : true;      // (right, inside the read: wj == z1 is the extra window)
                 if (node) {
                     if (x < t || (!right && (uint32_t)x < Bt)) fail = true;  // condition (4)
                     bott = x < bott ? x : bott;
