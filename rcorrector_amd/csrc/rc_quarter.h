@@ -292,6 +292,59 @@ __device__ __forceinline__ int rcq_threshold_row(const rc_kernel_args &A, uint32
         const int vm = __builtin_amdgcn_ds_bpermute((row_lane0 + (im & 15)) << 2, sm);
         const int vh = __builtin_amdgcn_ds_bpermute((row_lane0 + (ih & 15)) << 2, sh);
         if (!screened && n_below < kcnt) cls = n_below >= kcnt - (kcnt >> 3) ? 4 : (n_below >= kcnt - (kcnt >> 2) ? 3 : (n_below >= kcnt - (kcnt >> 1) ? 2 : 1));
+        // The same on the REAL counts.  The sorted array hides the windows the threshold scan masks as poly-A (:1530-1541:
+        // >= k - max(7, k/2) A's or T's -- one read in eight has such a window), so v0 < 0 for a read that is clean in every
+        // other respect.  ErrorCorrection itself never looks at that mask (its own, :870-931, asks for >= k - 2): if every
+        // real count reaches t0 and more than half of the k-mers reach s even with the masked ones left out (n_below counts
+        // them as below), the argument above holds word for word.  l / m / h of the real counts: two row reductions and a
+        // descent over the bits of the largest count for the element of rank kcnt / 2 (no second sort).
+        bool clean2 = false;
+        {
+            int y[E_CNT];
+            int rmin = 2147483647, rmax = 0;
+#pragma unroll
+            for (int e = 0; e < E_CNT; ++e) {
+                const int g = e * 16 + l;
+                y[e] = g < kcnt ? count_at(g) : 2147483647;
+                rmin = y[e] < rmin ? y[e] : rmin;
+                rmax = g < kcnt && y[e] > rmax ? y[e] : rmax;
+            }
+            int q;
+            q = row_xor<1>(rmin); rmin = q < rmin ? q : rmin;
+            q = row_xor<2>(rmin); rmin = q < rmin ? q : rmin;
+            q = row_xor<4>(rmin); rmin = q < rmin ? q : rmin;
+            q = row_xor<8>(rmin); rmin = q < rmin ? q : rmin;
+            clean2 = !clean && !screened && kcnt > 0 && rmin >= t0 && kcnt - n_below > (kcnt + 1) / 2;
+            if (__ballot(clean2)) {  // (wave-uniform)
+                q = row_xor<1>(rmax); rmax = q > rmax ? q : rmax;
+                q = row_xor<2>(rmax); rmax = q > rmax ? q : rmax;
+                q = row_xor<4>(rmax); rmax = q > rmax ? q : rmax;
+                q = row_xor<8>(rmax); rmax = q > rmax ? q : rmax;
+                const int wmax = max(max(__builtin_amdgcn_readlane(rmax, 0), __builtin_amdgcn_readlane(rmax, 16)),
+                                     max(__builtin_amdgcn_readlane(rmax, 32), __builtin_amdgcn_readlane(rmax, 48)));
+                int prefix = 0;
+                for (int b = 31 - __builtin_clz((unsigned)wmax | 1u); b >= 0; --b) {
+                    const int cd = prefix | (1 << b);
+                    int below = 0;
+#pragma unroll
+                    for (int e = 0; e < E_CNT; ++e) below += y[e] < cd ? 1 : 0;
+                    below += row_xor<1>(below);
+                    below += row_xor<2>(below);
+                    below += row_xor<4>(below);
+                    below += row_xor<8>(below);
+                    prefix = below <= im ? cd : prefix;  // the largest value with at most im counts below it = the element of rank im
+                }
+                if (clean2) {
+                    cls = 0;
+                    if (live && l == 0) {
+                        A.ret[r] = 0;
+                        A.l[r] = rmin;
+                        A.m[r] = prefix;
+                        A.h[r] = rmax;
+                    }
+                }
+            }
+        }
         // Candidate for k_single (rc_single.h, condition (2)): every letter ACGT, and the trusted mask -- counts >= s and
         // not poly-A at threshold 2 (:870-931) -- has no 1-run of length one and only 0-runs of exactly k, or of at most k
         // at either end of the read.  k_single checks it again (it needs the runs' positions anyway); this flag only keeps the
@@ -311,7 +364,7 @@ __device__ __forceinline__ int rcq_threshold_row(const rc_kernel_args &A, uint32
                     const int cg = g < kcnt ? count_at(g) : 0;
                     tb[e] = row_bits(__ballot(g < kcnt && cg >= s && na < k - 2 && nt < k - 2), row);
                 }
-                if (!clean && !screened && other == 0 && kcnt >= 5) {
+                if (!clean && !clean2 && !screened && other == 0 && kcnt >= 5) {
                     const uint64_t lo = (uint64_t)tb[0] | ((uint64_t)tb[1] << 16) | ((uint64_t)tb[2] << 32) | ((uint64_t)tb[3] << 48);
                     const uint64_t hi = (uint64_t)tb[4] | ((uint64_t)tb[5] << 16) | ((uint64_t)tb[6] << 32) | ((uint64_t)tb[7] << 48);
                     // Z = zero bits inside [0, kcnt); shifts over the 128-bit pair

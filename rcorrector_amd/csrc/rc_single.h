@@ -294,29 +294,71 @@ __device__ __forceinline__ void rcs_row(const rc_kernel_args &A, uint32_t r, int
     if (ok && rc_less_than_bound(best_bott, s, er)) ok = false;             // condition (6)
     if (!__ballot(ok)) return;
 
-    // GetKmerInformation of the corrected read: sort the counts (0 shown as 1, :1583), pick min / element kcnt/2 / max
+    // GetKmerInformation of the corrected read (:1567-1602): min / element kcnt/2 / max of the counts in ascending order,
+    // 0 shown as 1 (:1583).  Minimum and maximum are row reductions; the element of rank kcnt/2 comes from a descent over
+    // the bits of the largest count (one count-the-smaller-ones row reduction per bit: counts of a few hundred make that
+    // a third of the sorting network's instructions); counts of 2^14 and more take the network.
     int x[8];
+    int vmin = 2147483647, vmax = 1;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int g = e * 16 + l;
         int v = s_cnt_row[g];
         v = v == 0 ? 1 : v;
-        x[e] = (ok && g < kcnt) ? v : 2147483647;
+        const bool in = ok && g < kcnt;
+        x[e] = in ? v : 2147483647;
+        vmin = x[e] < vmin ? x[e] : vmin;
+        vmax = in && v > vmax ? v : vmax;
     }
-    int c4[4];
+    auto row_min = [&](int v) {
+        int y;
+        y = rcq::row_xor<1>(v); v = y < v ? y : v;
+        y = rcq::row_xor<2>(v); v = y < v ? y : v;
+        y = rcq::row_xor<4>(v); v = y < v ? y : v;
+        y = rcq::row_xor<8>(v); v = y < v ? y : v;
+        return v;
+    };
+    auto row_max = [&](int v) {
+        int y;
+        y = rcq::row_xor<1>(v); v = y > v ? y : v;
+        y = rcq::row_xor<2>(v); v = y > v ? y : v;
+        y = rcq::row_xor<4>(v); v = y > v ? y : v;
+        y = rcq::row_xor<8>(v); v = y > v ? y : v;
+        return v;
+    };
+    auto row_sum = [&](int v) {
+        v += rcq::row_xor<1>(v);
+        v += rcq::row_xor<2>(v);
+        v += rcq::row_xor<4>(v);
+        v += rcq::row_xor<8>(v);
+        return v;
+    };
+    const int v0 = row_min(vmin), vh = row_max(vmax);
+    const int im = kcnt > 0 ? kcnt >> 1 : 0;
+    int vm;
+    const int wmax = max(max(__builtin_amdgcn_readlane(vh, 0), __builtin_amdgcn_readlane(vh, 16)),
+                         max(__builtin_amdgcn_readlane(vh, 32), __builtin_amdgcn_readlane(vh, 48)));  // (uniform)
+    if (wmax < (1 << 14)) {
+        int prefix = 0;
+        for (int b = 31 - __builtin_clz((unsigned)wmax | 1u); b >= 0; --b) {
+            const int cand = prefix | (1 << b);
+            int below = 0;
 #pragma unroll
-    for (int bb = 0; bb < 4; ++bb) c4[bb] = __builtin_amdgcn_sbfe(l, bb, 1) ^ (int)0x80000000;
-    rcq::merges<8, 2>(x, c4);
-    const int im = kcnt > 0 ? kcnt >> 1 : 0, ih = kcnt > 0 ? kcnt - 1 : 0;
-    int sm = x[0], sh = x[0];
+            for (int e = 0; e < 8; ++e) below += x[e] < cand ? 1 : 0;
+            below = row_sum(below);
+            prefix = below <= im ? cand : prefix;   // the largest value with at most im counts below it: the element of rank im
+        }
+        vm = prefix;
+    } else {
+        int c4[4];
 #pragma unroll
-    for (int e = 1; e < 8; ++e) {
-        sm = (im >> 4) == e ? x[e] : sm;
-        sh = (ih >> 4) == e ? x[e] : sh;
+        for (int bb = 0; bb < 4; ++bb) c4[bb] = __builtin_amdgcn_sbfe(l, bb, 1) ^ (int)0x80000000;
+        rcq::merges<8, 2>(x, c4);
+        int sm = x[0];
+#pragma unroll
+        for (int e = 1; e < 8; ++e) sm = (im >> 4) == e ? x[e] : sm;
+        vm = __builtin_amdgcn_ds_bpermute((row_lane0 + (im & 15)) << 2, sm);
     }
-    const int v0 = __builtin_amdgcn_ds_bpermute(row_lane0 << 2, x[0]);
-    const int vm = __builtin_amdgcn_ds_bpermute((row_lane0 + (im & 15)) << 2, sm);
-    const int vh = __builtin_amdgcn_ds_bpermute((row_lane0 + (ih & 15)) << 2, sh);
     if (ok) {
         if (l < ns) {
             const int fp = l == 0 ? fixp0 : (l == 1 ? fixp1 : fixp2), fc = l == 0 ? fixc0 : (l == 1 ? fixc1 : fixc2);
