@@ -385,14 +385,16 @@ int rc_launch_single(rc_ctx *ctx, const rc_device_batch_args &a, bool *ran)
     rc_kernel_args A;
     int rc = fill_args(ctx, a, A);
     if (rc) return rc;
-    // its work list: the reads the threshold kernel flagged as candidates
-    if ((rc = rc_dbuf_reserve(ctx, &ctx->single_list, (size_t)a.n * 4 + 256))) return rc;
+    // its work list: the reads the threshold kernel flagged as candidates, grouped by their number of untrusted stretches
+    // (the four reads of a wavefront walk their stretches in lock step: the wave takes as long as its longest read)
+    const size_t stride = ((size_t)a.n + 63) & ~(size_t)63;
+    if ((rc = rc_dbuf_reserve(ctx, &ctx->single_list, stride * 3 * 4 + 256))) return rc;
     uint32_t *d_n = (uint32_t *)((char *)ctx->work.p + RC_WORK_NSINGLE_OFF);
     RC_CHECK_HIP(ctx, hipMemsetAsync(d_n, 0, 16, ctx->stream));
-    if ((rc = rc_launch_compact_flag(ctx, (const uint8_t *)ctx->cand.p, a.n, (uint32_t *)ctx->single_list.p, d_n))) return rc;
+    if ((rc = rc_launch_compact_flag(ctx, (const uint8_t *)ctx->cand.p, a.n, (uint32_t *)ctx->single_list.p, stride, d_n))) return rc;
     A.cls = (uint8_t *)ctx->cls.p;
     A.worklist = (const uint32_t *)ctx->single_list.p;
-    A.work_stride = 0;
+    A.work_stride = stride;
     A.n_work = d_n;
     rc_timer_begin(ctx);
     unsigned g = (unsigned)ctx->n_cu * 24u;  // (a few workgroups per CU slot; they walk the list, whose length stays on the device)

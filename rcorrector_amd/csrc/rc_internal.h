@@ -155,7 +155,7 @@ int rc_launch_digest(rc_ctx *ctx, unsigned long long *d_out);
 int rc_launch_locality_order(rc_ctx *ctx, const struct rc_device_batch_args &a, size_t nbytes);
 int rc_launch_probe_list(rc_ctx *ctx, const struct rc_device_batch_args &a, size_t nbytes, int32_t *d_counts);
 int rc_launch_compact(rc_ctx *ctx, const uint8_t *d_cls, uint32_t n, uint32_t *d_list, size_t stride, uint32_t *d_count);
-int rc_launch_compact_flag(rc_ctx *ctx, const uint8_t *d_flag, uint32_t n, uint32_t *d_list, uint32_t *d_count);
+int rc_launch_compact_flag(rc_ctx *ctx, const uint8_t *d_flag, uint32_t n, uint32_t *d_list, size_t stride, uint32_t *d_count);
 
 // rc_correct.hip
 struct rc_device_batch_args {

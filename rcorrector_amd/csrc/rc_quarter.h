@@ -351,6 +351,7 @@ __device__ __forceinline__ int rcq_threshold_row(const rc_kernel_args &A, uint32
         // reads that cannot pass out of its work list, so that its rows are filled with reads that mostly do.
         if (A.cand) {
             bool cand = false;
+            int cand_runs = 1;  // 0-runs of a candidate = segments k_single will walk: its work list is grouped by that number
             if constexpr (E_CNT == 8) {
                 uint32_t other = 0, tb[E_CNT];
 #pragma unroll
@@ -387,9 +388,10 @@ __device__ __forceinline__ int rcq_threshold_row(const rc_kernel_args &A, uint32
                         }
                     }
                     cand = shape;
+                    cand_runs = nruns;
                 }
             }
-            if (live && l == 0) A.cand[r] = cand ? 1 : 0;
+            if (live && l == 0) A.cand[r] = cand ? (uint8_t)cand_runs : 0;
         }
         if (clean) {
             cls = 0;

@@ -188,6 +188,9 @@ __device__ __forceinline__ void rcs_row(const rc_kernel_args &A, uint32_t r, int
         ok = any(T) && !any(iso) && ns >= 1 && ns <= max_seg;
     }
     if (!__ballot(ok)) return;
+#if defined(RC_K2S_STOP) && RC_K2S_STOP == 1  // dev builds: cost of the stages up to here
+    return;
+#endif
     uint32_t Bt = 0;  // condition (4), left searches
     const bool bs_ok = A.P.bs[0] != 0 && t < RC_BS_INLINE;
     if (bs_ok) Bt = A.P.bs[t];
@@ -293,6 +296,9 @@ __device__ __forceinline__ void rcs_row(const rc_kernel_args &A, uint32_t r, int
     }
     if (ok && rc_less_than_bound(best_bott, s, er)) ok = false;             // condition (6)
     if (!__ballot(ok)) return;
+#if defined(RC_K2S_STOP) && RC_K2S_STOP == 2
+    return;
+#endif
 
     // GetKmerInformation of the corrected read (:1567-1602): min / element kcnt/2 / max of the counts in ascending order,
     // 0 shown as 1 (:1583).  Minimum and maximum are row reductions; the element of rank kcnt/2 comes from a descent over

@@ -490,16 +490,19 @@ int rc_launch_compact(rc_ctx *ctx, const uint8_t *d_cls, uint32_t n, uint32_t *d
     return RC_OK;
 }
 
-// d_list = the indices i in [0, n) with d_flag[i] == 1, ascending; *d_count = how many
-int rc_launch_compact_flag(rc_ctx *ctx, const uint8_t *d_flag, uint32_t n, uint32_t *d_list, uint32_t *d_count)
+// section v - 1 (v = 1 .. 3) of d_list, at d_list + (v - 1) * stride = the indices i in [0, n) with d_flag[i] == v,
+// ascending; d_count[v - 1] = how many
+int rc_launch_compact_flag(rc_ctx *ctx, const uint8_t *d_flag, uint32_t n, uint32_t *d_list, size_t stride, uint32_t *d_count)
 {
     rocprim::counting_iterator<uint32_t> ids(0);
-    auto flags = rocprim::make_transform_iterator(d_flag, rc_cls_is{(uint8_t)1});
-    size_t tmp = 0;
-    RC_CHECK_HIP(ctx, rocprim::select(nullptr, tmp, ids, flags, d_list, d_count, (size_t)n, ctx->stream));
-    int rc = rc_dbuf_reserve(ctx, &ctx->sel_tmp, tmp);
-    if (rc) return rc;
-    RC_CHECK_HIP(ctx, rocprim::select(ctx->sel_tmp.p, tmp, ids, flags, d_list, d_count, (size_t)n, ctx->stream));
+    for (int v = 1; v <= 3; ++v) {
+        auto flags = rocprim::make_transform_iterator(d_flag, rc_cls_is{(uint8_t)v});
+        size_t tmp = 0;
+        RC_CHECK_HIP(ctx, rocprim::select(nullptr, tmp, ids, flags, d_list + (v - 1) * stride, d_count + (v - 1), (size_t)n, ctx->stream));
+        int rc = rc_dbuf_reserve(ctx, &ctx->sel_tmp, tmp);
+        if (rc) return rc;
+        RC_CHECK_HIP(ctx, rocprim::select(ctx->sel_tmp.p, tmp, ids, flags, d_list + (v - 1) * stride, d_count + (v - 1), (size_t)n, ctx->stream));
+    }
     return RC_OK;
 }
 

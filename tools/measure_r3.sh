@@ -19,8 +19,8 @@ for c in $CONFIGS; do
   : > $OUT/r3_config${c}_bench_pmc.txt
   for C in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVES SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CU_CYCLES"; do
     rm -rf /tmp/prof_pmc
-    (cd /tmp && timeout 1200 rocprofv3 --pmc $C --kernel-include-regex "k_probe|k_threshold|k_correct" --output-format csv -d /tmp/prof_pmc -- python $REPO/bench.py --config $c --no-extras --steps 1 --warmup 0 > /dev/null 2> /tmp/prof_pmc.err)
-    python tools/prof_summary.py pmc /tmp/prof_pmc | grep -v "^kernel" | grep "k_probe\|k_thresh\|k_correct" >> $OUT/r3_config${c}_bench_pmc.txt
+    (cd /tmp && timeout 1200 rocprofv3 --pmc $C --kernel-include-regex "k_probe|k_threshold|k_correct|k_single" --output-format csv -d /tmp/prof_pmc -- python $REPO/bench.py --config $c --no-extras --steps 1 --warmup 0 > /dev/null 2> /tmp/prof_pmc.err)
+    python tools/prof_summary.py pmc /tmp/prof_pmc | grep -v "^kernel" | grep "k_probe\|k_thresh\|k_correct\|k_single" >> $OUT/r3_config${c}_bench_pmc.txt
   done
 done
 python - "$OUT" $CONFIGS <<'PY'
@@ -33,11 +33,11 @@ doc = json.load(open("profiles/r3_traffic.json")) if os.path.exists("profiles/r3
 if doc.get("sources") != bench.source_hashes():
     doc = {"configs": {}}      # passes of other sources do not mix with these
 doc["sources"] = bench.source_hashes()
-doc["note"] = ("per launch, mean over the launches of one step; `rocprofv3 --pmc <group> --kernel-include-regex 'k_probe|k_threshold|k_correct' -- "
+doc["note"] = ("per launch, mean over the launches of one step; `rocprofv3 --pmc <group> --kernel-include-regex 'k_probe|k_threshold|k_correct|k_single' -- "
                "python bench.py --config i --no-extras --steps 1 --warmup 0` (tools/measure_r3.sh; summaries in profiles/r3_config<i>_bench_pmc.txt); "
                "traffic = 2 x FETCH_SIZE (KB x 1024): gfx950 tallies a 128-byte fabric request as 64 B")
 for c in configs:
-    rec = {"k_probe": {}, "k_correct": {}}
+    rec = {"k_probe": {}, "k_correct": {}, "k_single": {}}
     names = {"FETCH_SIZE": "fetch_size_kb", "WRITE_SIZE": "write_size_kb", "TCC_EA0_RDREQ_sum": "ea_rdreq", "TCC_HIT_sum": "tcc_hit", "TCC_MISS_sum": "tcc_miss",
              "SQ_INSTS_VALU": "insts_valu", "SQ_INSTS_SALU": "insts_salu", "SQ_INSTS_VMEM_RD": "insts_vmem_rd", "SQ_INSTS_LDS": "insts_lds",
              "SQ_ACTIVE_INST_VALU": "active_valu_quadcycles", "SQ_ACTIVE_INST_SCA": "active_scalar_quadcycles", "SQ_WAVE_CYCLES": "wave_quadcycles",
@@ -46,7 +46,7 @@ for c in configs:
         m = re.match(r"(k_\w+)(<.*>)?\s+(\S+)\s+(\d+)\s+(\S+)\s+(\S+)\s*$", line.rstrip())
         if not m or m.group(3) not in names:
             continue
-        kern = "k_correct" if m.group(1) == "k_correct" else ("k_probe" if m.group(1) in ("k_probe_threshold_list", "k_probe_list", "k_probe") else None)
+        kern = m.group(1) if m.group(1) in ("k_correct", "k_single") else ("k_probe" if m.group(1) in ("k_probe_threshold_list", "k_probe_list", "k_probe") else None)
         if kern is None:
             continue
         n_disp, total = int(m.group(4)), float(m.group(6))
@@ -57,6 +57,10 @@ json.dump(doc, open(path, "w"), indent=1)
 print({c: (doc["configs"][c]["k_probe"].get("fetch_size_kb"), doc["configs"][c]["k_correct"].get("insts_valu")) for c in doc["configs"]})
 PY
 cp $OUT/r3_traffic.json profiles/r3_traffic.json   # (on the box: so that the bench lines below report it)
+# host I/O microbenchmarks behind the end-to-end figures (tools/mb): page-cache reads / writes by method and thread count
+(cd tools/mb && g++ -O2 -std=c++17 -pthread -o iob iob.cpp && g++ -O2 -std=c++17 -pthread -o iob2 iob2.cpp)
+{ echo "# $(nproc) cores, $(grep MemTotal /proc/meminfo), /tmp on: $(df -T /tmp | tail -1)"; echo "## tools/mb/iob /tmp 4"; timeout 600 tools/mb/iob /tmp 4; echo "## tools/mb/iob /dev/shm 4"; timeout 600 tools/mb/iob /dev/shm 4; echo "## tools/mb/iob2 /tmp 4"; timeout 600 tools/mb/iob2 /tmp 4; } > $OUT/r3_host_io_microbench.txt 2>&1
+rm -f /tmp/iob.dat /dev/shm/iob.dat
 for c in $CONFIGS; do
   timeout 1800 python bench.py --config $c > $OUT/r3_bench_config$c.json 2> $OUT/r3_bench_config$c.err
   python tools/fmt_bench.py $OUT/r3_bench_config$c.json
