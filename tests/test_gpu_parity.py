@@ -724,6 +724,35 @@ def test_k31_maxcork8_on_a_packed_table_with_extension_bits(oracle):
     ctx.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("scale", [1000, 40000])
+@pytest.mark.parametrize("name", ["se_k23", "pe_k23", "skew"])
+def test_counts_in_the_tens_of_thousands_and_millions(oracle, name, scale):
+    """The medians of the reads the threshold kernel and k_single finish come from a rank selection over the bits of the
+    largest count; counts of 2^14 and more take k_single's sorting network instead (rc_single.h), and the descent of the
+    threshold kernel gets longer (rc_quarter.h).  The test sets' counts are in the tens: the same sets with every count
+    multiplied by 1 000 (tens of thousands) and by 40 000 (millions) -- different thresholds, same code paths end to end."""
+    d = datasets.make(name)
+    counts = (np.asarray(d["counts"], dtype=np.int64) * scale).astype(np.int32)
+    d = dict(d, counts=counts)
+    want = datasets.run_oracle(oracle, d)
+    ctx = rcorrector_amd.Context(k=d["k"], max_fix_per_k=d["mfk"], device=0)
+    ctx.table_build(d["keys"], d["counts"])
+    ctx.set_run_params(d["rate"], b"H")
+    a, off = oracle.pack_reads(d["seqs1"])
+    qa, _ = oracle.pack_reads(d["quals1"])
+    if d["mode"] == 1:
+        a2, off2 = oracle.pack_reads(d["seqs2"])
+        qa2, _ = oracle.pack_reads(d["quals2"])
+        got = ctx.correct_batch(1, a, qa, off, a2, qa2, off2) + (a, a2)
+    else:
+        got = ctx.correct_batch(d["mode"], a, qa, off) + (a,)
+    for w, g, what in zip(want, got, ["ret", "l", "m", "h", "seq1", "seq2"]):
+        assert np.array_equal(w, g), "%s differs on %s with counts x %d" % (what, name, scale)
+    assert int(np.max(want[3])) >= (1 << 14)   # h: the largest count of some read is beyond the selection's limit
+    ctx.close()
+
+
 KNOBS = [{"RC_TABLE_LAYOUT": "wide"}, {"RC_TABLE_LOAD": "0.85"}, {"RC_TABLE_LOAD": "0.25"}, {"RC_LOCALITY": "force"},
          {"RC_NO_FUSE": "1", "RC_LOCALITY": "force"}, {"RC_K2_WAVE_PER_READ": "1"}, {"RC_NO_CLASSIFY": "1"},
          {"RC_NO_ALT": "1"}, {"RC_K3_GENERIC": "1"}, {"RC_K3_GENERIC": "1", "RC_NO_ALT": "1", "RC_LOCALITY": "force"},
