@@ -258,6 +258,7 @@ static int fill_args(rc_ctx *ctx, const rc_device_batch_args &a, rc_kernel_args 
     A.info = (int32_t *)ctx->info.p;
     A.cls = nullptr;
     A.cand = nullptr;
+    A.runs = nullptr;
     A.worklist = nullptr;
     A.work_stride = 0;
     A.n_work = nullptr;
@@ -305,7 +306,9 @@ int rc_launch_threshold(rc_ctx *ctx, const rc_device_batch_args &a, bool classif
         ctx->cls_ready = true;
         if (!ctx->env_no_single && a.max_len <= 160 && a.max_len - ctx->k + 1 <= 128) {  // candidates of k_single (rc_single.h)
             if ((rc = rc_dbuf_reserve(ctx, &ctx->cand, (size_t)a.n + 256))) return rc;
+            if ((rc = rc_dbuf_reserve(ctx, &ctx->runs, (size_t)a.n * 8 + 256))) return rc;
             A.cand = (uint8_t *)ctx->cand.p;
+            A.runs = (uint2 *)ctx->runs.p;
             ctx->cand_ready = true;
         }
     }
@@ -340,7 +343,9 @@ int rc_launch_probe_threshold_list(rc_ctx *ctx, const rc_device_batch_args &a, s
         ctx->cls_ready = true;
         if (!ctx->env_no_single && a.max_len <= 160 && a.max_len - ctx->k + 1 <= 128) {  // candidates of k_single (rc_single.h)
             if ((rc = rc_dbuf_reserve(ctx, &ctx->cand, (size_t)a.n + 256))) return rc;
+            if ((rc = rc_dbuf_reserve(ctx, &ctx->runs, (size_t)a.n * 8 + 256))) return rc;
             A.cand = (uint8_t *)ctx->cand.p;
+            A.runs = (uint2 *)ctx->runs.p;
             ctx->cand_ready = true;
         }
     }
@@ -393,6 +398,7 @@ int rc_launch_single(rc_ctx *ctx, const rc_device_batch_args &a, bool *ran)
     RC_CHECK_HIP(ctx, hipMemsetAsync(d_n, 0, 16, ctx->stream));
     if ((rc = rc_launch_compact_flag(ctx, (const uint8_t *)ctx->cand.p, a.n, (uint32_t *)ctx->single_list.p, stride, d_n))) return rc;
     A.cls = (uint8_t *)ctx->cls.p;
+    A.runs = (uint2 *)ctx->runs.p;
     A.worklist = (const uint32_t *)ctx->single_list.p;
     A.work_stride = stride;
     A.n_work = d_n;

@@ -481,7 +481,8 @@ struct rc_kernel_args {
     const int32_t *counts;  // K1 output, indexed like seq
     int32_t *strong, *info;
     uint8_t *cls;              // K2 -> compaction: 1 = the read still needs k_correct (nullptr: no classification)
-    uint8_t *cand;             // K2 -> k_single: 1 = the read's trusted k-mers have the shape of isolated substitutions (nullptr: not computed)
+    uint8_t *cand;             // K2 -> k_single: > 0 = the read's trusted k-mers have the shape of isolated substitutions: the number of its untrusted stretches (nullptr: not computed)
+    uint2 *runs;               // K2 -> k_single, candidates only: the stretches, (first k-mer | length << 8) 16 bits each: x = run 0 | run 1 << 16, y = run 2 | count << 16
     const uint32_t *worklist;  // k_correct: the reads to process (nullptr: all of [0, n))
     const uint32_t *n_work;    // k_correct: number of entries of worklist (device memory)
     int32_t *ret, *l, *m, *h;

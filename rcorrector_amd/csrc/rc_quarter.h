@@ -377,6 +377,7 @@ __device__ __forceinline__ int rcq_threshold_row(const rc_kernel_args &A, uint32
                     uint64_t elo = zlo & ~((zlo >> 1) | (zhi << 63)), ehi = zhi & ~(zhi >> 1);
                     const int nruns = __popcll(slo) + __popcll(shi);
                     bool shape = (lo | hi) != 0 && (iso_lo | iso_hi) == 0 && nruns >= 1 && nruns <= 3;
+                    uint32_t rr[3] = {0, 0, 0};  // per run: first k-mer | length << 8 (what k_single walks)
 #pragma unroll
                     for (int q = 0; q < 3; ++q) {
                         if (shape && q < nruns) {
@@ -385,10 +386,12 @@ __device__ __forceinline__ int rcq_threshold_row(const rc_kernel_args &A, uint32
                             if (slo) slo &= slo - 1; else shi &= shi - 1;
                             if (elo) elo &= elo - 1; else ehi &= ehi - 1;
                             shape = z1 - z0 + 1 == k || ((z0 == 0 || z1 == kcnt - 1) && z1 - z0 + 1 < k);
+                            rr[q] = (uint32_t)z0 | ((uint32_t)(z1 - z0 + 1) << 8);
                         }
                     }
                     cand = shape;
                     cand_runs = nruns;
+                    if (cand && live && l == 0) A.runs[r] = make_uint2(rr[0] | (rr[1] << 16), rr[2] | ((uint32_t)nruns << 16));
                 }
             }
             if (live && l == 0) A.cand[r] = cand ? (uint8_t)cand_runs : 0;

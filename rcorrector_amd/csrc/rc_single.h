@@ -11,7 +11,9 @@
 // and ONLY that: every step is guarded by the condition under which the general code takes the same turn, and a read that
 // fails any of them is left untouched for k_correct.  The conditions, with s / t the iteration's strong and weak
 // thresholds (:793-842, pair override included):
-//   (1) every letter is one of ACGT; the screens passed (:735-755);
+//   (1) every letter is one of ACGT; the screens passed (:735-755);   [(1) and (2) are checked by the threshold kernel,
+//       rc_quarter.h, which has the letters, the counts and the mask in registers: it flags the read as a candidate and
+//       leaves the stretches it found in rc_kernel_args::runs]
 //   (2) the trusted mask T[i] = counts[i] >= s && !IsPolyA(i, 2) (:870-931) has 1-runs that are all at least 2 long (each
 //       is an island: no fall-back island, :1002-1007) and 0-runs that are exactly k long inside the read -- so
 //       consecutive islands are k + 1 k-mers apart and no boundary moves (:934-965 needs a distance <= k), the base space
@@ -42,29 +44,6 @@
 #define RC_K2S_WAVES 6
 #endif
 namespace rcs {
-
-struct u128 {
-    uint64_t lo, hi;
-};
-__device__ __forceinline__ u128 shl1(u128 a) { return u128{a.lo << 1, (a.hi << 1) | (a.lo >> 63)}; }
-__device__ __forceinline__ u128 shr1(u128 a) { return u128{(a.lo >> 1) | (a.hi << 63), a.hi >> 1}; }
-__device__ __forceinline__ u128 band(u128 a, u128 b) { return u128{a.lo & b.lo, a.hi & b.hi}; }
-__device__ __forceinline__ u128 bnot(u128 a) { return u128{~a.lo, ~a.hi}; }
-__device__ __forceinline__ int popc(u128 a) { return __popcll(a.lo) + __popcll(a.hi); }
-__device__ __forceinline__ bool any(u128 a) { return (a.lo | a.hi) != 0; }
-__device__ __forceinline__ int ctz(u128 a) { return a.lo ? __ffsll((long long)a.lo) - 1 : 64 + __ffsll((long long)a.hi) - 1; }  // a != 0
-__device__ __forceinline__ u128 clear_lowest(u128 a)
-{
-    if (a.lo) return u128{a.lo & (a.lo - 1), a.hi};
-    return u128{0, a.hi & (a.hi - 1)};
-}
-__device__ __forceinline__ bool bit(u128 a, int i) { return i < 64 ? (a.lo >> i) & 1ull : (a.hi >> (i - 64)) & 1ull; }
-__device__ __forceinline__ u128 low_mask(int n)  // n in [1, 128]
-{
-    if (n >= 128) return u128{~0ull, ~0ull};
-    if (n >= 64) return u128{~0ull, n == 64 ? 0ull : ((1ull << (n - 64)) - 1ull)};
-    return u128{(1ull << n) - 1ull, 0ull};
-}
 
 constexpr int MAX_KCNT = 128, MAX_LEN = 160, PK_WORDS = MAX_LEN / 16 + 2, MAX_SEG = 3;
 
@@ -121,73 +100,35 @@ __device__ __forceinline__ void rcs_row(const rc_kernel_args &A, uint32_t r, int
         t = trust < 2 ? 2 : trust;
     }
 
+    // condition (2) was checked by the threshold kernel, which leaves the stretches it found in A.runs (rc_quarter.h: the
+    // same mask -- counts >= s, not poly-A at 2 -- from the same s; condition (1) too: a candidate has ACGT letters only)
+    int ns = 0;
+    uint32_t run01 = 0, run2 = 0;
+    if (ok) {
+        const uint2 rw = A.runs[r];
+        run01 = rw.x;
+        run2 = rw.y & 0xffffu;
+        ns = (int)(rw.y >> 16);
+        const int max_seg = mfk - 1 < MAX_SEG ? mfk - 1 : MAX_SEG;
+        ok = ns >= 1 && ns <= max_seg;
+    }
     if (!__ballot(ok)) return;  // (no row of this wave has a read: nothing below touches another wave)
-    // bases: codes in registers, the packed read in LDS (ds_or of every base's two bits), letter masks for IsPolyA
-    bool bad_letter = false;
+    // the packed read (ds_or of every base's two bits) and K1's counts -> the row's LDS
     if (l < PK_WORDS) s_pk_row[l] = 0;
     wsync();
-    uint32_t ma[6] = {0, 0, 0, 0, 0, 0}, mt[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int e = 0; e < 10; ++e) {
         const int p = e * 16 + l;
-        const int c = (ok && p < len) ? rc_base_code(A.seq[o + p]) : 7;
-        if (p < len && c >= 4) bad_letter = true;
-        if (ok && p < len) atomicOr(&s_pk_row[e], (uint32_t)(c & 3) << (30 - 2 * l));
-        ma[e >> 1] |= rcq::row_bits(__ballot(c == 0), row) << ((e & 1) * 16);
-        mt[e >> 1] |= rcq::row_bits(__ballot(c == 3), row) << ((e & 1) * 16);
+        if (ok && p < len) atomicOr(&s_pk_row[e], (uint32_t)(rc_base_code(A.seq[o + p]) & 3) << (30 - 2 * l));
     }
-    ok = ok && !row_any(ok && bad_letter);
-    const uint32_t kmask = k >= 32 ? 0xffffffffu : ((1u << k) - 1u);
-    // IsPolyA(window g, 2), ErrorCorrection.cpp:53-71: >= k - 2 A's or T's among the window's k letters
-    auto polya2 = [&](int g) -> bool {
-        const int w = g >> 5;
-        const uint32_t sh = (uint32_t)(g & 31);
-        uint32_t a_lo = ma[0], a_hi = ma[1], t_lo = mt[0], t_hi = mt[1];
 #pragma unroll
-        for (int j = 1; j < 5; ++j) {
-            a_lo = w == j ? ma[j] : a_lo;
-            a_hi = w == j ? ma[j + 1] : a_hi;
-            t_lo = w == j ? mt[j] : t_lo;
-            t_hi = w == j ? mt[j + 1] : t_hi;
-        }
-        const int na = __popc(__builtin_amdgcn_alignbit(a_hi, a_lo, sh) & kmask), nt = __popc(__builtin_amdgcn_alignbit(t_hi, t_lo, sh) & kmask);
-        return na >= k - 2 || nt >= k - 2;
-    };
-
-    // K1's counts -> LDS; the trusted mask
-    u128 T{0, 0};
-    {
-        uint32_t tb[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int g = e * 16 + l;
-            int v = 0;
-            if (ok && g < kcnt) v = A.counts[o + g];
-            s_cnt_row[g] = v;
-            // (window g = e * 16 + l: word e / 2, shift (e % 2) * 16 + l -- compile-time word, cf. rc_quarter.h)
-            const uint32_t sh = (uint32_t)((e & 1) * 16 + l);
-            const int na = __popc(__builtin_amdgcn_alignbit(ma[(e >> 1) + 1], ma[e >> 1], sh) & kmask);
-            const int nt = __popc(__builtin_amdgcn_alignbit(mt[(e >> 1) + 1], mt[e >> 1], sh) & kmask);
-            tb[e] = rcq::row_bits(__ballot(ok && g < kcnt && v >= s && na < k - 2 && nt < k - 2), row);
-        }
-        T.lo = (uint64_t)tb[0] | ((uint64_t)tb[1] << 16) | ((uint64_t)tb[2] << 32) | ((uint64_t)tb[3] << 48);
-        T.hi = (uint64_t)tb[4] | ((uint64_t)tb[5] << 16) | ((uint64_t)tb[6] << 32) | ((uint64_t)tb[7] << 48);
+    for (int e = 0; e < 8; ++e) {
+        const int g = e * 16 + l;
+        int v = 0;
+        if (ok && g < kcnt) v = A.counts[o + g];
+        s_cnt_row[g] = v;
     }
     wsync();
-    // condition (2)
-    int ns = 0;
-    u128 zs{0, 0}, ze{0, 0};
-    if (ok) {
-        const u128 M = low_mask(kcnt);
-        const u128 Z = band(bnot(T), M);
-        zs = band(Z, bnot(shl1(Z)));
-        ze = band(Z, bnot(band(shr1(Z), M)));
-        ns = popc(zs);
-        const u128 iso = band(band(T, bnot(shl1(T))), bnot(shr1(T)));
-        const int max_seg = mfk - 1 < MAX_SEG ? mfk - 1 : MAX_SEG;
-        ok = any(T) && !any(iso) && ns >= 1 && ns <= max_seg;
-    }
-    if (!__ballot(ok)) return;
 #if defined(RC_K2S_STOP) && RC_K2S_STOP == 1  // dev builds: cost of the stages up to here
     return;
 #endif
@@ -204,6 +145,13 @@ __device__ __forceinline__ void rcs_row(const rc_kernel_args &A, uint32_t r, int
         return x >> (64 - 2 * k);
     };
     auto base_at = [&](int q) -> int { return (int)((s_pk_row[q >> 4] >> (30 - 2 * (q & 15))) & 3u); };
+    // IsPolyA(window g, 2), ErrorCorrection.cpp:53-71: >= k - 2 A's (code 0) or T's (code 3) among the window's k letters
+    auto polya2 = [&](int g) -> bool {
+        const uint64_t x = code_at(g);
+        const uint64_t m = (k >= 32 ? ~0ull : ((1ull << (2 * k)) - 1ull)) & 0x5555555555555555ull;
+        const uint64_t lo = x & m, hi = (x >> 1) & m;
+        return __popcll(lo & hi) >= k - 2 || __popcll(~(lo | hi) & m) >= k - 2;
+    };
 
     int fixp0 = 0, fixp1 = 0, fixp2 = 0, fixc0 = 0, fixc1 = 0, fixc2 = 0;  // (named: a run-time index would put them in scratch)
     int best_bott = 2147483647, prev_z1 = -1;
@@ -212,11 +160,11 @@ __device__ __forceinline__ void rcs_row(const rc_kernel_args &A, uint32_t r, int
         const bool act = ok && si < ns;   // (row-uniform)
         int z0 = 0, z1 = 0, next_z0 = kcnt;
         if (act) {
-            z0 = ctz(zs);
-            z1 = ctz(ze);
-            zs = clear_lowest(zs);
-            ze = clear_lowest(ze);
-            if (any(zs)) next_z0 = ctz(zs);
+            const uint32_t rs = si == 0 ? (run01 & 0xffffu) : (si == 1 ? (run01 >> 16) : run2);
+            const uint32_t rn = si == 0 ? (run01 >> 16) : run2;   // the run after this one
+            z0 = (int)(rs & 0xffu);
+            z1 = z0 + (int)(rs >> 8) - 1;
+            if (si + 1 < ns) next_z0 = (int)(rn & 0xffu);
         }
         // a 0-run inside the read is k long; one at either end of the read is at most k long (the error is less than k
         // bases from that end) -- the segment then runs to the read's end (:1009-1046, `extend` = 0 at :1138 / :1152)
