@@ -403,7 +403,7 @@ int rc_launch_single(rc_ctx *ctx, const rc_device_batch_args &a, bool *ran)
     A.work_stride = stride;
     A.n_work = d_n;
     rc_timer_begin(ctx);
-    unsigned g = (unsigned)ctx->n_cu * 24u;  // (a few workgroups per CU slot; they walk the list, whose length stays on the device)
+    unsigned g = (unsigned)ctx->n_cu * (unsigned)RC_K2S_GRID;  // (a few workgroups per CU slot; they walk the list, whose length stays on the device)
     if (g > (a.n + 15) / 16) g = (a.n + 15) / 16;
     const dim3 grid(g), block(256);
     if (ctx->ext)
