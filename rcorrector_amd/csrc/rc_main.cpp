@@ -932,7 +932,10 @@ int main(int argc, char **argv)
     batch_reads &= ~(size_t)1;
     {
         unsigned hc = std::thread::hardware_concurrency();
-        g_threads = t_flag > 1 ? t_flag : (int)std::min<unsigned>(hc ? hc : 8, 32);
+        // (default: 16 -- the loops these threads share are memory copies and page-cache calls, and beyond that
+        // they get in each other's way: 16 M x 150 bp pairs, files to files, 0.53 / 0.50 / 0.49 / 0.51 / 0.52 / 0.62 s
+        // at 8 / 12 / 16 / 20 / 24 / 32 threads on a 2 x 64-core host)
+        g_threads = t_flag > 1 ? t_flag : (int)std::min<unsigned>(hc ? hc : 8, 16);
         if (g_threads < 1) g_threads = 1;
     }
     g_timing = getenv("RC_TIMING") != nullptr;
