@@ -853,6 +853,7 @@ static void print_help()
             "\t-stdout: output the corrected sequences to stdout (default: not used)\n"
             "\t-verbose: output some correction information to stdout (default: not used)\n"
             "MI355X build only:\n"
+            "\t(-t: host threads that read, pack, format and write around the GPU; without it, or with -t 1: 16)\n"
             "\t-gpus INT: number of GPUs to shard the reads over, k-mer table replicated (default: 1)\n"
             "\twithout -c the k-mers are counted here (exact counts >= 2); ERROR_RATE is then estimated over this program's own\n"
             "\t\tdump order, not Jellyfish's: self-consistent, not byte-comparable with a jellyfish + reference run on large inputs\n"
