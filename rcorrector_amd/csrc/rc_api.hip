@@ -136,6 +136,7 @@ rc_ctx *rc_create(const rc_config *cfg, char *errbuf, size_t errbuf_len)
     ctx->P.error_rate = 0.01;
     ctx->P.bad_qual = 0;
     memset(ctx->P.bs, 0, sizeof ctx->P.bs);
+    ctx->P.bs_ext = nullptr;
     ctx->P.flags = 0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
@@ -173,7 +174,7 @@ void rc_destroy(rc_ctx *c)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     rc_dbuf *bufs[] = {&ctx->counts, &ctx->strong, &ctx->info, &ctx->stack, &ctx->work,
                        &ctx->h_seq, &ctx->h_qual, &ctx->h_off, &ctx->h_res, &ctx->trace, &ctx->cls, &ctx->worklist, &ctx->sel_tmp,
-                       &ctx->loc_a, &ctx->loc_list, &ctx->cand, &ctx->single_list, &ctx->runs};
+                       &ctx->loc_a, &ctx->loc_list, &ctx->cand, &ctx->single_list, &ctx->runs, &ctx->bs_dev};
     for (rc_dbuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (ctx->slots) {
@@ -905,6 +906,13 @@ int rc_set_run_params(rc_ctx *ctx, double error_rate, char bad_quality)
     uint32_t steps[RC_BOUND_STEPS];
     rc_bound_steps_build(error_rate, steps);
     for (int v = 0; v < RC_BS_INLINE; ++v) ctx->P.bs[v] = steps[v];
+    // ... and the whole table stays in device memory for the thresholds beyond those
+    RC_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = rc_dbuf_reserve(ctx, &ctx->bs_dev, sizeof steps);
+    if (rc) return rc;
+    RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (a batch in flight may still read the old table)
+    RC_CHECK_HIP(ctx, hipMemcpy(ctx->bs_dev.p, steps, sizeof steps, hipMemcpyHostToDevice));
+    ctx->P.bs_ext = getenv("RC_NO_BS_EXT") ? nullptr : (const uint32_t *)ctx->bs_dev.p;
     ctx->P.flags = ctx->env_no_alt ? RC_PF_NO_ALT : 0;
     ctx->params_set = true;
     return RC_OK;

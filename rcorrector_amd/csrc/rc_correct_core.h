@@ -43,7 +43,19 @@ struct rc_run_params {
     // Part of the kernel arguments, i.e. read with scalar loads.
     uint32_t bs[RC_BS_INLINE];
     int flags;  // RC_PF_*
+    // the whole table (RC_BOUND_STEPS entries, in device memory for the kernels): thresholds of RC_BS_INLINE and more --
+    // reads of transcripts covered thousands of times -- take one load per read from here (nullptr: none)
+    const uint32_t *bs_ext;
 };
+// the smallest count whose bound reaches t (t >= 2), or 0 if that is not known (no table, t beyond it, never reached)
+RC_HD uint32_t rc_bs_lookup(const rc_run_params &P, int t)
+{
+    if (!P.bs[0] || t < 2) return 0;
+    if (t < RC_BS_INLINE) return P.bs[t];
+    if (!P.bs_ext || t >= RC_BOUND_STEPS) return 0;
+    const uint32_t v = P.bs_ext[t];
+    return v == RC_BOUND_NEVER ? 0 : v;
+}
 #define RC_PF_NO_ALT 1  // dev / tests: no alternative chains in the speculation rounds of the search
 
 struct rc_island {
@@ -585,8 +597,8 @@ RC_HD int rc_alt_run(W &w, rc_read_state &S, const rc_run_params &P, int a, int 
     if (na == 0 || t < 1) return 0;
     uint32_t Bt = 0;
     if (dir < 0) {
-        if (t >= RC_BS_INLINE || !P.bs[0]) return 0;
-        Bt = P.bs[t];
+        Bt = RC_U(rc_bs_lookup(P, t));
+        if (!Bt) return 0;
     }
     const int eb = 4 * (az + 1) + a * am;
     const uint64_t okm = w.ballot64(0, na, [&](int j) {

@@ -105,6 +105,7 @@ struct rc_ctx {
     rc_dbuf cand;     // uint8 per read: 1 = candidate of k_single (written by the threshold kernel with cls)
     rc_dbuf single_list;  // the candidates' read indices, ascending (compaction of cand)
     rc_dbuf runs;     // uint2 per read, candidates only: their untrusted stretches (rc_kernel_args::runs)
+    rc_dbuf bs_dev;   // RC_BOUND_STEPS uint32: the inverse of GetBound at the run's ERROR_RATE (rc_run_params::bs_ext)
     bool cand_ready = false;
     rc_dbuf worklist; // RC_WORK_CLASSES sections of work_stride uint32 each: the reads with cls == 4, 3, 2, 1, ascending within a section
     rc_dbuf sel_tmp;  // rocPRIM scratch of the compaction

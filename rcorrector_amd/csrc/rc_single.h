@@ -29,7 +29,7 @@
 //   (4) at every node behind p: the keep-base count x is >= t -- the node's threshold never exceeds the t handed down
 //       (:165-172), so the base is kept whatever the other three extensions count -- and, in left searches, which hand the
 //       node's threshold down as the next t (:546), x >= bs[t]: the bound of x, hence of the largest extension, reaches t,
-//       the threshold IS t, t stays (rc_run_params::bs; t >= RC_BS_INLINE is left to k_correct);
+//       the threshold IS t, t stays (rc_bs_lookup: the inverse of GetBound, a table built on the host);
 //   (5) the path's bottleneck (the smallest count on it) is >= t, so the terminal adds no fix (:243 / :483) and the
 //       path is accepted with fix count 1 < maxFixCnt (MAX_FIX_PER_K >= 2); with one candidate there is no frame to pop;
 //   (6) the smallest bottleneck over the segments is not below GetBound(s) (:1195 would force another iteration).
@@ -136,8 +136,8 @@ __device__ __forceinline__ void rcs_row(const rc_kernel_args &A, uint32_t r, int
     return;
 #endif
     uint32_t Bt = 0;  // condition (4), left searches
-    const bool bs_ok = A.P.bs[0] != 0 && t < RC_BS_INLINE;
-    if (bs_ok) Bt = A.P.bs[t];
+    if (ok) Bt = rc_bs_lookup(A.P, t);
+    const bool bs_ok = Bt != 0;
 
     // 2-bit code of the n <= 32 bases starting at base q (cf. rc_code_at)
     auto code_at = [&](int q) -> uint64_t {

@@ -731,7 +731,9 @@ def test_counts_in_the_tens_of_thousands_and_millions(oracle, name, scale):
     """The medians of the reads the threshold kernel and k_single finish come from a rank selection over the bits of the
     largest count; counts of 2^14 and more take k_single's sorting network instead (rc_single.h), and the descent of the
     threshold kernel gets longer (rc_quarter.h).  The test sets' counts are in the tens: the same sets with every count
-    multiplied by 1 000 (tens of thousands) and by 40 000 (millions) -- different thresholds, same code paths end to end."""
+    multiplied by 1 000 (tens of thousands) and by 40 000 (millions) -- different thresholds, same code paths end to end.
+    The weak thresholds are then in the tens and hundreds: left searches take the inverse of GetBound from the table in
+    device memory (rc_bs_lookup beyond RC_BS_INLINE), in k_single and in the alternative chains of k_correct."""
     d = datasets.make(name)
     counts = (np.asarray(d["counts"], dtype=np.int64) * scale).astype(np.int32)
     d = dict(d, counts=counts)
@@ -757,7 +759,7 @@ KNOBS = [{"RC_TABLE_LAYOUT": "wide"}, {"RC_TABLE_LOAD": "0.85"}, {"RC_TABLE_LOAD
          {"RC_NO_FUSE": "1", "RC_LOCALITY": "force"}, {"RC_K2_WAVE_PER_READ": "1"}, {"RC_NO_CLASSIFY": "1"},
          {"RC_NO_ALT": "1"}, {"RC_K3_GENERIC": "1"}, {"RC_K3_GENERIC": "1", "RC_NO_ALT": "1", "RC_LOCALITY": "force"},
          {"RC_TABLE_FILTER": "force"}, {"RC_TABLE_FILTER": "force", "RC_LOCALITY": "force", "RC_TABLE_LOAD": "0.85"},
-         {"RC_NO_SINGLE": "1"}, {"RC_NO_SINGLE": "1", "RC_NO_ALT": "1"}]
+         {"RC_NO_SINGLE": "1"}, {"RC_NO_SINGLE": "1", "RC_NO_ALT": "1"}, {"RC_NO_BS_EXT": "1"}]
 
 
 @pytest.mark.gpu
