@@ -903,15 +903,17 @@ int rc_set_run_params(rc_ctx *ctx, double error_rate, char bad_quality)
     ctx->P.bad_qual = (int)(signed char)bad_quality;
     // the first integer steps of GetBound at this rate (rc_common.h), computed here with the host's -- the
     // reference's -- arithmetic; they travel to the correction kernel with its arguments
-    uint32_t steps[RC_BOUND_STEPS];
+    std::vector<uint32_t> steps_v(RC_BOUND_STEPS);
+    uint32_t *steps = steps_v.data();
     rc_bound_steps_build(error_rate, steps);
     for (int v = 0; v < RC_BS_INLINE; ++v) ctx->P.bs[v] = steps[v];
     // ... and the whole table stays in device memory for the thresholds beyond those
     RC_CHECK_HIP(ctx, hipSetDevice(ctx->device));
-    int rc = rc_dbuf_reserve(ctx, &ctx->bs_dev, sizeof steps);
+    const size_t steps_bytes = (size_t)RC_BOUND_STEPS * sizeof(uint32_t);
+    int rc = rc_dbuf_reserve(ctx, &ctx->bs_dev, steps_bytes);
     if (rc) return rc;
     RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (a batch in flight may still read the old table)
-    RC_CHECK_HIP(ctx, hipMemcpy(ctx->bs_dev.p, steps, sizeof steps, hipMemcpyHostToDevice));
+    RC_CHECK_HIP(ctx, hipMemcpy(ctx->bs_dev.p, steps, steps_bytes, hipMemcpyHostToDevice));
     ctx->P.bs_ext = getenv("RC_NO_BS_EXT") ? nullptr : (const uint32_t *)ctx->bs_dev.p;
     ctx->P.flags = ctx->env_no_alt ? RC_PF_NO_ALT : 0;
     ctx->params_set = true;

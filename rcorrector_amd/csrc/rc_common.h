@@ -328,7 +328,7 @@ RC_HD int rc_bound_i(int c, double e)
 //   B[v], v in [2, RC_BOUND_STEPS): as above, or RC_BOUND_NEVER if no count below 2^31 reaches v.
 //   B[0] = number of valid entries (0: table unusable -- the bound overflows int for large counts
 //   at this error rate, which breaks monotonicity -- every caller then evaluates GetBound itself).
-#define RC_BOUND_STEPS 1024
+#define RC_BOUND_STEPS 65536  // (thresholds up to there: counts of ~16 M at ERROR_RATE 0.004)
 #define RC_BOUND_NEVER 0x80000000u
 inline void rc_bound_steps_build(double e, uint32_t *B)  // host only
 {
