@@ -72,15 +72,16 @@ listed = ctx2.profile_correct_counters()[0]
 dev_ret = r4[0].cpu().numpy()
 print("device: %d of %d reads listed for k_correct (%.1f %% finished early); results equal the oracle's: %s" % (listed, nn, 100 - 100.0 * listed / nn, bool(np.array_equal(dev_ret, ret))), flush=True)
 strong, info = M.front_end(Pp, T, seqs, k)
-acc0 = acc1 = bad = ch1 = accd = 0
+acc0 = acc1 = bad = ch1 = accd = pure = 0
 t0 = time.time()
 for i in range(len(seqs)):
     pt = -1 if mate is None else int(min(strong[i], strong[mate(i)]))
     r0 = M.finished_early(Pp, T, seqs[i], k, P["maxcork"], int(strong[i]), int(info[i]), pt)
     r1 = M.finished_early(Pp, T, seqs[i], k, P["maxcork"], int(strong[i]), int(info[i]), pt, allow_weak=True)
     acc0 += r0 is not None; acc1 += r1 is not None
+    pure += r0 is None and r1 is not None and r1[0] == 0
     accd += M.finished_early(Pp, T, seqs[i], k, P["maxcork"], int(strong[i]), int(info[i]), pt, bs_limit=16) is not None
     if r1 is not None:
         ch1 += r1[0] > 0
         if r1 != (int(ret[i]), out[i], int(l[i]), int(m[i]), int(hh[i])): bad += 1
-print("config %d: %d reads, changed %.1f %%; finished early: model %.1f %%, model with the 16-entry step table %.1f %%, with weak stretches %.1f %% (mismatches %d)" % (c, len(seqs), 100 * float((ret > 0).sum()) / len(seqs), 100 * acc0 / len(seqs), 100 * accd / len(seqs), 100 * acc1 / len(seqs), bad), flush=True)
+print("config %d: %d reads, changed %.1f %%; finished early: model %.1f %%, model with the 16-entry step table %.1f %%, with weak stretches %.1f %% (of which unchanged reads: %.1f %%) (mismatches %d)" % (c, len(seqs), 100 * float((ret > 0).sum()) / len(seqs), 100 * acc0 / len(seqs), 100 * accd / len(seqs), 100 * acc1 / len(seqs), 100 * pure / len(seqs), bad), flush=True)
