@@ -1138,7 +1138,8 @@ int main(int argc, char **argv)
         bad_q = rc_bad_quality_from_hist(fh.data(), lh.data(), total);
     }
     fprintf(stderr, "Bad quality threshold is '%c'\n", bad_q);
-    for (int c = 0; c < nctx; ++c) rc_set_run_params(ctx[c], rate, bad_q);
+    for (int c = 0; c < nctx; ++c)
+        if (rc_set_run_params(ctx[c], rate, bad_q)) die("rcorrector: %s\n", rc_last_error(ctx[c]));
     const double t_setup = now_s();
 
     // pipeline: reader (this thread) -> one worker per GPU -> writer thread (input order)
