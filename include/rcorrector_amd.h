@@ -123,7 +123,9 @@ int rc_estimate_error_rate(rc_ctx *ctx, double wk, double *rate_out);
  * the first <= 1,000,000 records (first_hist[q] = #reads whose first quality char is q,
  * last_hist likewise for the last base) */
 char rc_bad_quality_from_hist(const int32_t first_hist[300], const int32_t last_hist[300], int32_t total);
-/* sets ERROR_RATE and badQualityThreshold for subsequent corrections */
+/* sets ERROR_RATE and badQualityThreshold (the globals of main.cpp:24-27) for subsequent corrections; also builds
+ * the inverse of GetBound (ErrorCorrection.cpp:139-142) at this rate on the host -- the reference's own arithmetic,
+ * ~20 ms -- and leaves it in device memory for the kernels: call it once per run, with no batch in flight */
 int rc_set_run_params(rc_ctx *ctx, double error_rate, char bad_quality);
 
 /* Quality as one bit per base.  The correction only ever compares a quality with badQualityThreshold
