@@ -67,8 +67,49 @@ def adversarial_reads(seed=7, n=600, length=100):
     return out_r, out_q
 
 
+def polya_boundary_reads(k, seed=4242, n_tx=6, l_tx=400, cover=40, length=100):
+    """Reads over transcripts that carry A-rich / T-rich stretches whose k-windows sit right at the two IsPolyA
+    thresholds the path uses (ErrorCorrection.cpp:53-71): k - 2 A's or T's (the trusted mask, :870-931, and the veto on
+    substitutions, :343 / :577) and k - max(7, k/2) (the mask of GetStrongTrustedThreshold, :1530-1541) -- windows with
+    exactly the threshold count, one below and one above, for both letters; 0.5 % substitutions on top."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    thr7 = max(7, k // 2)
+    txs = []
+    for t in range(n_tx):
+        tx = rng.integers(0, 4, l_tx).astype(np.uint8)
+        letter = 0 if t % 2 == 0 else 3
+        other = [c for c in range(4) if c != letter]
+        pos = 40
+        for want in (k - 2, k - 3, k - 1, k, k - thr7, k - thr7 - 1, k - thr7 + 1):
+            w = np.full(k, letter, np.uint8)
+            holes = rng.choice(k, k - want, replace=False)
+            w[holes] = rng.choice(other, len(holes))
+            tx[pos:pos + k] = w
+            # (the windows around it hold fewer of the letter: the flanks are random)
+            pos += k + 17
+        txs.append(tx)
+    reads, quals = [], []
+    for tx in txs:
+        for _ in range(cover * l_tx // length):
+            a = int(rng.integers(0, l_tx - length + 1))
+            r = tx[a:a + length].copy()
+            e = rng.random(length) < 0.005
+            r[e] = (r[e] + rng.integers(1, 4, int(e.sum()))) % 4
+            if rng.random() < 0.5:
+                r = (3 - r)[::-1]
+            reads.append(np.frombuffer(b"ACGT", np.uint8)[r])
+            quals.append(np.full(length, ord("I"), np.uint8))
+    return np.stack(reads), np.stack(quals)
+
+
 def make(name):
     """Returns dict(k, mfk, rate, mode, keys, counts, seqs1, quals1, seqs2, quals2) as python bytes lists."""
+    if name.startswith("polya_k"):
+        k = int(name[len("polya_k"):])
+        s1, q1 = polya_boundary_reads(k)
+        keys, cnt = synth.count_kmers([s1], k)
+        return dict(k=k, mfk=4, rate=0.0041, mode=0, keys=keys, counts=cnt, seqs1=[r.tobytes() for r in s1],
+                    quals1=[q.tobytes() for q in q1], seqs2=None, quals2=None)
     if name == "edge":
         r, q = adversarial_reads()
         s1, _, _, _, _ = synth.make_reads(7, 600, 100, e=0.01)

@@ -67,7 +67,7 @@ def test_table_empty_and_tiny(gpu_ctx_factory):
     assert ctx.lookup(np.array([0, 1], dtype=np.uint64)).tolist() == [7, 0]
 
 
-@pytest.mark.parametrize("name", ["se_k23", "k31_mc8", "nrich", "varlen", "k15", "k32", "edge", "max1023", "k11"])
+@pytest.mark.parametrize("name", ["se_k23", "k31_mc8", "nrich", "varlen", "k15", "k32", "edge", "max1023", "k11", "polya_k23"])
 def test_probe_kernel_counts(gpu_ctx_factory, oracle, name):
     import torch
     d = datasets.make(name)
@@ -90,7 +90,7 @@ def test_probe_kernel_counts(gpu_ctx_factory, oracle, name):
 
 
 @pytest.mark.parametrize("name", ["se_k23", "pe_k23", "il_k23", "k31_mc8", "skew", "nrich", "varlen", "k15", "k32", "pe_var", "edge",
-                                  "long300", "long600_k31", "max1023", "k11"])
+                                  "long300", "long600_k31", "max1023", "k11", "polya_k23", "polya_k31", "polya_k15"])
 def test_correct_batch_matches_oracle(gpu_ctx_factory, oracle, name):
     d = datasets.make(name)
     want = datasets.run_oracle(oracle, d)
@@ -577,7 +577,7 @@ def test_quality_bits_give_the_same_results_as_quality_bytes(gpu_ctx_factory, or
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["se_k23", "pe_k23", "il_k23", "pe_var", "varlen", "edge", "k31_mc8", "long600_k31"])
+@pytest.mark.parametrize("name", ["se_k23", "pe_k23", "il_k23", "pe_var", "varlen", "edge", "k31_mc8", "long600_k31", "polya_k23"])
 def test_locality_order_does_not_change_results(oracle, name, monkeypatch):
     """Large batches are processed in min-hash order (overlapping reads next to each other, rc_table.hip):
     a pure reordering -- forced here on the small parity sets, ragged, paired and interleaved ones included,
