@@ -222,6 +222,19 @@ int rc_correct_device(rc_ctx *ctx, const rc_device_batch *b);
  * function's return value for read r (-1 for reads it screens out). */
 int rc_strong_threshold_device(rc_ctx *ctx, const uint8_t *d_seq, const uint32_t *d_off, uint32_t n_reads,
                                uint64_t nbytes, int32_t max_read_len, int32_t *d_strong);
+/* The three functions of ErrorCorrection.h:26-28 at the reference's own granularity, one NUL-terminated read per call
+ * (each a batch of one: a kernel launch and two small copies -- for bindings that work read by read and for spot checks;
+ * throughput lives in the batch calls above).  The table and the run parameters must be set.
+ *   rc_strong_threshold_read  = GetStrongTrustedThreshold(seq, qual, kcode, kmers), ErrorCorrection.cpp:1482-1565
+ *       (the function never reads qual);
+ *   rc_correct_read           = ErrorCorrection(id, seq, qual, pairStrongTrustThreshold, kcode, kmers), :682-1480: seq is
+ *       corrected in place, *ret = the return value; pair_strong_threshold = min of the two mates' strong thresholds, or
+ *       -1 for a read without a mate (:96-106); qual == NULL stands for a FASTA record (qual[0] == 0, Reads.h:241);
+ *       counted by rc_summary like any batch;
+ *   rc_kmer_info_read         = GetKmerInformation(seq, kmerLength, kmers, l, m, h), :1567-1602, of the read as given. */
+int rc_strong_threshold_read(rc_ctx *ctx, const char *seq, int32_t *strong);
+int rc_correct_read(rc_ctx *ctx, char *seq, const char *qual, int32_t pair_strong_threshold, int32_t *ret);
+int rc_kmer_info_read(rc_ctx *ctx, const char *seq, int32_t *l, int32_t *m, int32_t *h);
 /* the hash-probe kernel alone: d_counts[a] = count of the k-mer starting at arena byte a
  * (ErrorCorrection.cpp:716-723 for every read of the arena) */
 int rc_probe_device(rc_ctx *ctx, const uint8_t *d_seq, uint64_t nbytes, int32_t *d_counts);

@@ -16,6 +16,7 @@ ABI_SYMBOLS = [
     "rc_table_count_reads_device", "rc_table_write_jfdump", "rc_table_share", "rc_table_replicate", "rc_table_replicate_async", "rc_table_lookup", "rc_table_export", "rc_table_digest", "rc_table_layout", "rc_table_stats",
     "rc_estimate_error_rate", "rc_bad_quality_from_hist", "rc_set_run_params", "rc_set_quality_bits", "rc_pack_quality_bits",
     "rc_correct_batch", "rc_submit", "rc_wait", "rc_host_alloc", "rc_host_free", "rc_host_register", "rc_host_unregister", "rc_correct_batch_traced", "rc_correct_device", "rc_strong_threshold_device", "rc_probe_device", "rc_sync",
+    "rc_strong_threshold_read", "rc_correct_read", "rc_kmer_info_read",
     "rc_profile_enable", "rc_profile_get", "rc_profile_reset", "rc_profile_correct_counters", "rc_selftest_get_bound", "rc_summary",
 ]
 
@@ -116,6 +117,9 @@ def load_library():
     L.rc_probe_device.argtypes = [vp, vp, C.c_uint64, vp]
     L.rc_strong_threshold_device.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint64, C.c_int32, vp]
     L.rc_sync.argtypes = [vp]
+    L.rc_strong_threshold_read.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int32)]
+    L.rc_correct_read.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_int32, C.POINTER(C.c_int32)]
+    L.rc_kmer_info_read.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.rc_profile_enable.argtypes = [vp, C.c_int]
     L.rc_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.rc_profile_reset.argtypes = [vp]
@@ -372,6 +376,26 @@ class Context:
 
     def strong_threshold_device(self, d_seq, d_off, n_reads, nbytes, max_read_len, d_strong):
         self._ck(self._L.rc_strong_threshold_device(self._h, _ptr(d_seq), _ptr(d_off), n_reads, nbytes, max_read_len, _ptr(d_strong)))
+
+    # ---- one read per call (ErrorCorrection.h:26-28) ----
+    def strong_threshold_read(self, seq):
+        """GetStrongTrustedThreshold of one read (bytes)."""
+        out = C.c_int32(0)
+        self._ck(self._L.rc_strong_threshold_read(self._h, bytes(seq), C.byref(out)))
+        return out.value
+
+    def correct_read(self, seq, qual, pair_strong_threshold=-1):
+        """ErrorCorrection of one read: returns (return value, corrected read as bytes)."""
+        buf = C.create_string_buffer(bytes(seq))
+        out = C.c_int32(0)
+        self._ck(self._L.rc_correct_read(self._h, buf, None if qual is None else bytes(qual), int(pair_strong_threshold), C.byref(out)))
+        return out.value, buf.value
+
+    def kmer_info_read(self, seq):
+        """GetKmerInformation of one read: (l, m, h)."""
+        l, m, h = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        self._ck(self._L.rc_kmer_info_read(self._h, bytes(seq), C.byref(l), C.byref(m), C.byref(h)))
+        return l.value, m.value, h.value
 
     def probe_device(self, d_seq, nbytes, d_counts):
         self._ck(self._L.rc_probe_device(self._h, _ptr(d_seq), nbytes, _ptr(d_counts)))

@@ -79,6 +79,9 @@ void rc_table_release(rc_ctx *ctx)
     if (ctx->d_buckets && !ctx->buckets_borrowed) (void)hipFree(reinterpret_cast<char *>(ctx->d_buckets) - RC_TABLE_PREFIX_BYTES);
     ctx->d_buckets = nullptr;
     ctx->buckets_borrowed = false;
+    ctx->filter_words = 0;
+    ctx->table_bytes = 0;
+    ctx->n_entries = 0;
 }
 
 rc_table_view rc_view(const rc_ctx *ctx)
@@ -158,6 +161,11 @@ rc_ctx *rc_create(const rc_config *cfg, char *errbuf, size_t errbuf_len)
     ctx->env_no_classify = getenv("RC_NO_CLASSIFY") != nullptr;            // dev: every read goes through k_correct
     ctx->env_timing = getenv("RC_TIMING") != nullptr;
     ctx->env_no_fuse = getenv("RC_NO_FUSE") != nullptr;
+    ctx->env_no_tier = getenv("RC_NO_TIER") != nullptr;
+    if (const char *e = getenv("RC_FORCE_EC")) {
+        const int v = atoi(e);
+        if (v == 9 || v == 10) ctx->env_force_ec = v;
+    }
     ctx->env_k3_generic = getenv("RC_K3_GENERIC") != nullptr;
     ctx->env_no_single = getenv("RC_NO_SINGLE") != nullptr;
     ctx->env_no_alt = getenv("RC_NO_ALT") != nullptr;  // dev / tests: no alternative chains in the search's speculation rounds
@@ -546,10 +554,12 @@ int rc_table_replicate_async(rc_ctx *dst, const rc_ctx *src)
     RC_CHECK_HIP(dst, hipSetDevice(dst->device));
     rc_table_release(dst);
     static_cast<rc_ctx_full *>(dst)->dump.valid = false;
-    char *base = nullptr;
+    // the new allocation belongs to a guard until every copy is queued: an error on the way leaves dst without a table
+    // (d_buckets == nullptr), not with a pointer whose geometry still describes the previous one
+    rc_dev_tmp guard;
     const size_t bytes = src->table_bytes + RC_TABLE_PREFIX_BYTES + (size_t)src->filter_words * 4;  // prefix, buckets, filter
-    RC_CHECK_HIP(dst, hipMalloc((void **)&base, bytes));
-    dst->d_buckets = reinterpret_cast<uint32_t *>(base + RC_TABLE_PREFIX_BYTES);
+    RC_CHECK_HIP(dst, guard.alloc(bytes));
+    char *base = guard.as<char>();
     const char *from = reinterpret_cast<const char *>(src->d_buckets) - RC_TABLE_PREFIX_BYTES;
     // the bucket array (and its prefix) is the table
     bool staged = getenv("RC_REPLICATE_STAGED") != nullptr;  // tests: the path of GPUs without peer access
@@ -602,6 +612,8 @@ int rc_table_replicate_async(rc_ctx *dst, const rc_ctx *src)
         }
         if (rc) return rc;
     }
+    dst->d_buckets = reinterpret_cast<uint32_t *>(base + RC_TABLE_PREFIX_BYTES);
+    guard.p = nullptr;  // (dst owns it now)
     dst->nb_home = src->nb_home;
     dst->layout = src->layout;
     dst->ext = src->ext;
@@ -999,10 +1011,67 @@ static int correct_device_impl(rc_ctx *ctx, const rc_device_batch *b, uint32_t q
     a.m = b->d_m;
     a.h = b->d_h;
     a.max_len = b->max_read_len;
+    // the reads the threshold kernel could not finish, as a work list; isolated substitutions are finished four reads to
+    // a wave first (rc_single.h: it clears their cls), what is left is k_correct's list
+    auto single_and_compact = [&](const rc_device_batch_args &at) -> int {
+        if (!ctx->cls_ready) return RC_OK;
+        ctx->work_stride = ((size_t)at.n + 63) & ~(size_t)63;
+        int e;
+        if ((e = rc_dbuf_reserve(ctx, &ctx->worklist, ctx->work_stride * RC_WORK_CLASSES * 4 + 256))) return e;
+        bool ran = false;
+        if ((e = rc_launch_single(ctx, at, &ran))) return e;
+        return rc_launch_compact(ctx, (const uint8_t *)ctx->cls.p, at.n, (uint32_t *)ctx->worklist.p, ctx->work_stride,
+                                 (uint32_t *)((char *)ctx->work.p + RC_WORK_NWORK_OFF));
+    };
     // large batches over a table that does not fit the caches are probed in min-hash order (rc_table.hip),
     // so that overlapping reads meet in the L2 / Infinity Cache
-    if (ctx->locality_mode >= 0 && (ctx->locality_mode > 0 || (a.n >= (1u << 18) && ctx->table_bytes > ((size_t)128 << 20))) &&
-        a.max_len + 8 <= 4000) {
+    const bool locality = ctx->locality_mode >= 0 && (ctx->locality_mode > 0 || (a.n >= (1u << 18) && ctx->table_bytes > ((size_t)128 << 20))) &&
+                          a.max_len + 8 <= 4000;
+    // Length tiers.  The reference treats every read of up to 1 023 bases alike (utils.h:7, ErrorCorrection.cpp:682-1480);
+    // here the fast kernels -- the fused probe + threshold kernel, k_single, the compiled-for-k k_correct -- hold reads
+    // of up to 160 bases, the quarter-wave threshold kernel 320, and the longest read of a batch used to decide for all
+    // of them.  A batch with longer reads is now processed in up to three passes over the same arena, one per tier a
+    // unit's longer read falls into: S (<= 160 bases), M (the quarter-wave layout: <= 320 bases / 256 k-mers), L (the
+    // rest); each pass = threshold kernel -> (k_single) -> compaction -> k_correct with the tier's capacity class, and the
+    // threshold kernel of a pass marks the other tiers' reads cls = 0.  Same results (a read's result depends on its unit
+    // alone), the short reads of a mixed batch keep their kernels.  Needs the classification (work lists).
+    const int S_HI = 160;
+    const int m_hi = RC_Q_MAX_KCNT - 1 + ctx->k < RC_Q_MAX_LEN ? RC_Q_MAX_KCNT - 1 + ctx->k : RC_Q_MAX_LEN;
+    const bool tiered = a.max_len > S_HI && !ctx->env_no_tier && !ctx->env_no_classify && !ctx->env_k2_wave_per_read && ctx->trace_cap == 0;
+    if (tiered) {
+        rc_device_batch_args at = a;
+        at.tier_lo = -1;
+        at.tier_hi = S_HI;
+        at.max_len = S_HI;
+        if (locality) {
+            if ((rc = rc_launch_locality_order(ctx, a, (size_t)b->nbytes))) return rc;
+            if ((rc = rc_launch_probe_threshold_list(ctx, at, (size_t)b->nbytes, &fused))) return rc;
+            if ((rc = rc_launch_probe_list(ctx, a, (size_t)b->nbytes, (int32_t *)ctx->counts.p, fused ? S_HI : -1))) return rc;
+        } else if ((rc = rc_launch_probe(ctx, b->d_seq, (size_t)b->nbytes, (int32_t *)ctx->counts.p)))
+            return rc;
+        ctx->thr_ready = true;  // every pass runs a threshold kernel: k_correct never computes a threshold itself
+        for (int tier = 0; tier < 3; ++tier) {
+            if (tier == 1) {
+                at.tier_lo = S_HI;
+                at.tier_hi = m_hi;
+                at.max_len = a.max_len < m_hi ? a.max_len : m_hi;
+            } else if (tier == 2) {
+                if (a.max_len <= m_hi) break;
+                at.tier_lo = m_hi;
+                at.tier_hi = RC_TIER_ALL;
+                at.max_len = a.max_len;
+            }
+            if (!(tier == 0 && fused) && (rc = rc_launch_threshold(ctx, at, true))) return rc;
+            if (!ctx->cls_ready) {
+                rc_set_error(ctx, "correct: internal: a length tier ran without classification");
+                return RC_ERR_STATE;
+            }
+            if ((rc = single_and_compact(at))) return rc;
+            if ((rc = rc_launch_correct(ctx, at))) return rc;
+        }
+        return rc_launch_summary(ctx, a.ret, a.n);
+    }
+    if (locality) {
         if ((rc = rc_launch_locality_order(ctx, a, (size_t)b->nbytes))) return rc;
         // probe + threshold + classification in one kernel where the reads fit it
         if ((rc = rc_launch_probe_threshold_list(ctx, a, (size_t)b->nbytes, &fused))) return rc;
@@ -1019,19 +1088,7 @@ static int correct_device_impl(rc_ctx *ctx, const rc_device_batch *b, uint32_t q
         if ((rc = rc_launch_threshold(ctx, a, true))) return rc;
         ctx->thr_ready = true;
     }
-    if (ctx->cls_ready) {  // the reads the threshold kernel could not finish, as a work list
-        ctx->work_stride = ((size_t)a.n + 63) & ~(size_t)63;
-        if ((rc = rc_dbuf_reserve(ctx, &ctx->worklist, ctx->work_stride * RC_WORK_CLASSES * 4 + 256))) return rc;
-        auto compact = [&]() {
-            return rc_launch_compact(ctx, (const uint8_t *)ctx->cls.p, a.n, (uint32_t *)ctx->worklist.p, ctx->work_stride,
-                                     (uint32_t *)((char *)ctx->work.p + RC_WORK_NWORK_OFF));
-        };
-        // isolated substitutions are finished four reads to a wave (rc_single.h: it clears their cls); what is left is
-        // k_correct's list
-        bool ran = false;
-        if ((rc = rc_launch_single(ctx, a, &ran))) return rc;
-        if ((rc = compact())) return rc;
-    }
+    if ((rc = single_and_compact(a))) return rc;
     if ((rc = rc_launch_correct(ctx, a))) return rc;
     // UpdateSummary (main.cpp:73-79), on the device: the counters live in HBM until rc_summary() asks
     return rc_launch_summary(ctx, a.ret, a.n);
@@ -1053,8 +1110,7 @@ int rc_strong_threshold_device(rc_ctx *ctx, const uint8_t *d_seq, const uint32_t
     if ((rc = rc_dbuf_reserve(ctx, &ctx->counts, (size_t)nbytes * 4 + 256))) return rc;
     if ((rc = rc_dbuf_reserve(ctx, &ctx->strong, (size_t)n_reads * 4 + 256))) return rc;
     if ((rc = rc_dbuf_reserve(ctx, &ctx->info, (size_t)n_reads * 4 + 256))) return rc;
-    rc_device_batch_args a;
-    memset(&a, 0, sizeof a);
+    rc_device_batch_args a = rc_device_batch_args();  // (value-initialised: zeros, and the members with defaults -- no tiers)
     a.mode = 0;
     a.n = n_reads;
     a.seq = const_cast<uint8_t *>(d_seq);
@@ -1063,6 +1119,108 @@ int rc_strong_threshold_device(rc_ctx *ctx, const uint8_t *d_seq, const uint32_t
     if ((rc = rc_launch_probe(ctx, d_seq, (size_t)nbytes, (int32_t *)ctx->counts.p))) return rc;
     if ((rc = rc_launch_threshold(ctx, a, false))) return rc;
     RC_CHECK_HIP(ctx, hipMemcpyAsync(d_strong, ctx->strong.p, (size_t)n_reads * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    return RC_OK;
+}
+
+// ---- per-read entry points: the granularity of ErrorCorrection.h:26-28, each a batch of one through the kernels above
+// (a launch and two copies per call -- for bindings that work read by read and for spot checks, not for throughput)
+static int one_read_upload(rc_ctx *ctx, const char *seq, const char *qual, rc_device_batch_args &a, size_t *len1)
+{
+    if (!seq) return RC_ERR_ARG;
+    const size_t n1 = strlen(seq) + 1;
+    if (n1 > RC_MAX_READ_LENGTH) {
+        rc_set_error(ctx, "read of %zu bases exceeds the %d-base limit (utils.h:7)", n1 - 1, RC_MAX_READ_LENGTH - 1);
+        return RC_ERR_ARG;
+    }
+    if (ctx->qual_bits) {
+        rc_set_error(ctx, "the per-read entry points take quality bytes (rc_set_quality_bits is on)");
+        return RC_ERR_STATE;
+    }
+    RC_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = rc_dbuf_reserve(ctx, &ctx->h_seq, n1 + 64))) return rc;
+    if ((rc = rc_dbuf_reserve(ctx, &ctx->h_qual, n1 + 64))) return rc;
+    if ((rc = rc_dbuf_reserve(ctx, &ctx->h_off, 2 * 4))) return rc;
+    if ((rc = rc_dbuf_reserve(ctx, &ctx->h_res, 4 * 4))) return rc;
+    if ((rc = rc_dbuf_reserve(ctx, &ctx->counts, n1 * 4 + 256))) return rc;
+    if ((rc = rc_dbuf_reserve(ctx, &ctx->strong, 4 + 256))) return rc;
+    if ((rc = rc_dbuf_reserve(ctx, &ctx->info, 4 + 256))) return rc;
+    const uint32_t off[2] = {0u, (uint32_t)n1};
+    RC_CHECK_HIP(ctx, hipMemcpyAsync(ctx->h_seq.p, seq, n1, hipMemcpyHostToDevice, ctx->stream));
+    RC_CHECK_HIP(ctx, hipMemsetAsync(ctx->h_qual.p, 0, n1, ctx->stream));  // (no qualities: the FASTA marker qual[0] == 0)
+    if (qual) {
+        const size_t q1 = strnlen(qual, n1 - 1);
+        RC_CHECK_HIP(ctx, hipMemcpyAsync(ctx->h_qual.p, qual, q1, hipMemcpyHostToDevice, ctx->stream));
+    }
+    RC_CHECK_HIP(ctx, hipMemcpyAsync(ctx->h_off.p, off, sizeof off, hipMemcpyHostToDevice, ctx->stream));
+    RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (off and possibly seq are on the caller's stack)
+    int32_t *d_res = (int32_t *)ctx->h_res.p;
+    a = rc_device_batch_args();
+    a.mode = 0;
+    a.n = 1;
+    a.seq = (uint8_t *)ctx->h_seq.p;
+    a.qual = (const uint8_t *)ctx->h_qual.p;
+    a.off = (const uint32_t *)ctx->h_off.p;
+    a.ret = d_res;
+    a.l = d_res + 1;
+    a.m = d_res + 2;
+    a.h = d_res + 3;
+    a.max_len = (int)n1 - 1;
+    *len1 = n1;
+    return RC_OK;
+}
+
+int rc_strong_threshold_read(rc_ctx *ctx, const char *seq, int32_t *strong)
+{
+    if (!ctx || !seq || !strong) return RC_ERR_ARG;
+    rc_device_batch_args a;
+    size_t n1;
+    int rc = one_read_upload(ctx, seq, nullptr, a, &n1);
+    if (rc) return rc;
+    if ((rc = rc_launch_probe(ctx, a.seq, n1, (int32_t *)ctx->counts.p))) return rc;
+    if ((rc = rc_launch_threshold(ctx, a, false))) return rc;
+    RC_CHECK_HIP(ctx, hipMemcpyAsync(strong, ctx->strong.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RC_OK;
+}
+
+int rc_correct_read(rc_ctx *ctx, char *seq, const char *qual, int32_t pair_strong_threshold, int32_t *ret)
+{
+    if (!ctx || !seq || !ret) return RC_ERR_ARG;
+    rc_device_batch_args a;
+    size_t n1;
+    int rc = one_read_upload(ctx, seq, qual, a, &n1);
+    if (rc) return rc;
+    a.pair_override = pair_strong_threshold;
+    if ((rc = rc_launch_probe(ctx, a.seq, n1, (int32_t *)ctx->counts.p))) return rc;
+    // no threshold kernel, no classification: k_correct computes the read's own threshold (its single-end front end) and
+    // takes the pair's from the argument, exactly the reference's call
+    ctx->thr_ready = false;
+    ctx->cls_ready = false;
+    ctx->cand_ready = false;
+    if ((rc = rc_launch_correct(ctx, a))) return rc;
+    if ((rc = rc_launch_summary(ctx, a.ret, 1))) return rc;
+    RC_CHECK_HIP(ctx, hipMemcpyAsync(seq, a.seq, n1 - 1, hipMemcpyDeviceToHost, ctx->stream));
+    RC_CHECK_HIP(ctx, hipMemcpyAsync(ret, a.ret, 4, hipMemcpyDeviceToHost, ctx->stream));
+    RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RC_OK;
+}
+
+int rc_kmer_info_read(rc_ctx *ctx, const char *seq, int32_t *l, int32_t *m, int32_t *h)
+{
+    if (!ctx || !seq || !l || !m || !h) return RC_ERR_ARG;
+    rc_device_batch_args a;
+    size_t n1;
+    int rc = one_read_upload(ctx, seq, nullptr, a, &n1);
+    if (rc) return rc;
+    if ((rc = rc_launch_probe(ctx, a.seq, n1, (int32_t *)ctx->counts.p))) return rc;
+    if ((rc = rc_launch_kmer_info(ctx, a))) return rc;
+    int32_t out[3];
+    RC_CHECK_HIP(ctx, hipMemcpyAsync(out, a.l, 12, hipMemcpyDeviceToHost, ctx->stream));
+    RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *l = out[0];
+    *m = out[1];
+    *h = out[2];
     return RC_OK;
 }
 

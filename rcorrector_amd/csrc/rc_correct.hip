@@ -46,20 +46,24 @@ __global__ __launch_bounds__(64) void k_threshold(rc_kernel_args A)
         }
     };
     fetch(o_cur, e_cur);
+    const bool tiers = A.tier_hi != RC_TIER_ALL || A.tier_lo >= 0;
     for (;;) {
         const uint32_t o = o_cur;
         const int len = (int)(e_cur - o) - 1;
+        // another tier's read: not touched (its own pass computes its threshold), and not on this pass's work list
+        const bool mine = !tiers || rc_in_tier(A, rc_unit_max_len(A, r, len));
+        if (A.cls && lane == 0) A.cls[r] = mine ? 1 : 0;
         S.len = len;
         S.kcnt = len >= k ? len - k + 1 : 0;
 #pragma unroll
         for (int c = 0; c < RC_K2_PF; ++c) {
             const int i = c * 64 + lane;
-            if (i < len) {
+            if (mine && i < len) {
                 S.base[i] = (unsigned char)rc_base_code(pb[c]);
                 S.counts[i] = pc[c];
             }
         }
-        for (int i = RC_K2_PF * 64 + lane; i < len; i += 64) {
+        for (int i = RC_K2_PF * 64 + lane; mine && i < len; i += 64) {
             S.base[i] = (unsigned char)rc_base_code(A.seq[o + i]);
             S.counts[i] = i < S.kcnt ? A.counts[o + i] : 0;
         }
@@ -76,18 +80,49 @@ __global__ __launch_bounds__(64) void k_threshold(rc_kernel_args A)
             }
         }
         w.sync();
-        rc_build_masks(w, S);
-        int info;
-        const int strong = rc_front_end(w, S, A.P, &info);
-        if (lane == 0) {
-            A.strong[r] = strong;
-            A.info[r] = info;
+        if (mine) {  // (wave-uniform)
+            rc_build_masks(w, S);
+            int info;
+            const int strong = rc_front_end(w, S, A.P, &info);
+            if (lane == 0) {
+                A.strong[r] = strong;
+                A.info[r] = info;
+            }
         }
         w.sync();
         if (!more) break;
         r = rn;
     }
 }
+
+// GetKmerInformation (ErrorCorrection.h:28, ErrorCorrection.cpp:1567-1602) of every read of a batch AS IT IS (no
+// correction): one wave per read over K1's counts -- the code k_correct ends every read with (rc_kmer_info with no fix).
+__global__ __launch_bounds__(64) void k_kmer_info(rc_kernel_args A)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const rc_lds_layout L = rc_layout(A.cap);
+    rc_read_state S;
+    rc_carve(lds, L, S);
+    DevWave w;
+    w.lane = threadIdx.x;
+    w.T = A.T;
+    w.k = A.P.k;
+    w.stack = nullptr;
+    for (uint32_t r = blockIdx.x; r < A.n; r += gridDim.x) {
+        const uint32_t o = A.off[r];
+        rc_load_read(w, A, S, o, (int)(A.off[r + 1] - o) - 1, w.lane, false);
+        int l, m, h;
+        rc_kmer_info(w, S, A.P, 0, &l, &m, &h);
+        if (w.lane == 0) {
+            A.l[r] = l;
+            A.m[r] = m;
+            A.h[r] = h;
+        }
+        w.sync();
+    }
+}
+
+int rc_launch_kmer_info(rc_ctx *ctx, const rc_device_batch_args &a);
 
 #include "rc_quarter.h"
 
@@ -106,7 +141,10 @@ __global__ __launch_bounds__(64) void k_threshold(rc_kernel_args A)
 #ifndef RC_FUSED_SMALL_WAVES
 #define RC_FUSED_SMALL_WAVES 6
 #endif
-template <int RC_FUSED_TILE, int WAVES, bool EXT>
+// EC = count registers per lane of the threshold rows (rc_quarter.h): 8 for reads of up to 128 k-mers, 9 for 144 (151-base
+// reads at k = 23), 10 for every read of up to 160 bases.  A read the tier of this launch does not hold (rc_kernel_args::
+// tier_lo / tier_hi: a longer read, or the mate of one) is left out -- no bases copied, no counts, cls = 0.
+template <int RC_FUSED_TILE, int WAVES, bool EXT, int EC = 8>
 __global__ __launch_bounds__(RC_PROBE_THREADS) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_probe_threshold_list(rc_kernel_args A, size_t nbytes, const uint32_t *__restrict__ list,
                                                                            uint32_t reads_per_block, int32_t *__restrict__ counts)
 {
@@ -129,6 +167,20 @@ __global__ __launch_bounds__(RC_PROBE_THREADS) __attribute__((amdgpu_waves_per_e
         s_len1[t] = A.off[r + 1] - g0;  // bases + the NUL
     }
     __syncthreads();
+    if (A.tier_hi != RC_TIER_ALL) {  // (uniform) the list keeps mates adjacent and nr is even in paired / interleaved batches
+        bool other = false;
+        if ((uint32_t)t < nr) {
+            int ml = (int)s_len1[t] - 1;
+            if (A.mode != 0) {
+                const int mm = (int)s_len1[t ^ 1] - 1;
+                ml = mm > ml ? mm : ml;
+            }
+            other = !rc_in_tier(A, ml);
+        }
+        __syncthreads();
+        if (other) s_len1[t] = 0;  // 0 = not a read of this launch
+        __syncthreads();
+    }
     if (t == 0) {  // local start of each read: same alignment modulo 4 as in memory, a NUL in front
         uint32_t lp = 4;
         for (uint32_t j = 0; j < nr; ++j) {
@@ -140,6 +192,7 @@ __global__ __launch_bounds__(RC_PROBE_THREADS) __attribute__((amdgpu_waves_per_e
     }
     __syncthreads();
     for (uint32_t j = (uint32_t)t >> 6; j < nr; j += RC_PROBE_THREADS / 64) {  // copy, aligned dwords, outside bytes masked to NUL
+        if (!s_len1[j]) continue;
         const uint32_t g0 = s_gpos[j], lp = s_lpos[j], g1 = g0 + s_len1[j] - 1;
         const uint32_t w0 = g0 >> 2, w1 = (g1 + 3) >> 2;
         for (uint32_t w = w0 + ((uint32_t)t & 63u); w < w1; w += 64u) {
@@ -191,12 +244,17 @@ __global__ __launch_bounds__(RC_PROBE_THREADS) __attribute__((amdgpu_waves_per_e
     const uint8_t *raw8 = reinterpret_cast<const uint8_t *>(s_raw);
     for (uint32_t j0 = 0; j0 < nr; j0 += RC_PROBE_THREADS / 16) {
         const uint32_t j = j0 + ((uint32_t)t >> 4);
-        const bool live = j < nr;
+        const bool live = j < nr && s_len1[j] != 0;
         const uint32_t lp = live ? s_lpos[j] : 0;
         const int len = live ? (int)s_len1[j] - 1 : 0;
-        const int cls = rcq_threshold_row<8, 10>(
+        const int cls = rcq_threshold_row<EC, 10>(
             A, live ? s_rid[j] : 0, live, len, [&](int p) { return (uint32_t)raw8[lp + p]; }, [&](int g) { return s_cnt[lp + g]; });
         if (live && (t & 15) == 0) s_cls[j] = (uint8_t)cls;
+        if (j < nr && !live && (t & 15) == 0) {  // another tier's read
+            s_cls[j] = 0;
+            if (A.cls) A.cls[s_rid[j]] = 0;
+            if (A.cand) A.cand[s_rid[j]] = 0;
+        }
     }
     __syncthreads();
     // the counts k_correct will read: those of the reads that still need it, four per lane (a read
@@ -204,7 +262,7 @@ __global__ __launch_bounds__(RC_PROBE_THREADS) __attribute__((amdgpu_waves_per_e
     // first count and behind its last one belong to NULs and to the last k-1 positions of a read,
     // which hold no count -- k >= 4, rc_launch_probe_threshold_list)
     for (uint32_t j = (uint32_t)t >> 6; j < nr; j += RC_PROBE_THREADS / 64) {
-        if (A.cls && !s_cls[j]) continue;
+        if (!s_len1[j] || (A.cls && !s_cls[j])) continue;
         const int kcnt = (int)s_len1[j] - 1 - k + 1;
         const uint32_t lp = s_lpos[j], g0 = s_gpos[j], head = lp & 3u;
         const int4 *src = reinterpret_cast<const int4 *>(s_cnt + (lp - head));
@@ -284,11 +342,26 @@ static int fill_args(rc_ctx *ctx, const rc_device_batch_args &a, rc_kernel_args 
     A.trace = nullptr;
     A.trace_cap = 0;
     A.fused_front_end = a.mode == 0 && !ctx->thr_ready;
+    A.tier_lo = a.tier_lo;
+    A.tier_hi = a.tier_hi;
+    A.pair_override = a.pair_override;
     return RC_OK;
 }
 
+// count registers per lane the threshold rows / k_single need for reads of up to max_len bases (rc_quarter.h): 8 / 9 / 10,
+// 0 = the reads do not fit the 160-base instances
+static int rc_short_ec(const rc_ctx *ctx, int max_len, int k)
+{
+    if (max_len > 160) return 0;
+    const int kcnt = max_len - k + 1;
+    const int ec = kcnt <= 128 ? 8 : (kcnt <= 144 ? 9 : 10);
+    return ec < ctx->env_force_ec ? ctx->env_force_ec : ec;  // RC_FORCE_EC=9|10 (dev / tests): the wider instances on shorter reads
+}
+
 // classify: let the quarter-wave kernel finish the reads that need no correction (ret, l, m, h
-// written there) and flag the others in ctx->cls; ctx->cls_ready tells the caller whether it did
+// written there) and flag the others in ctx->cls; ctx->cls_ready tells the caller whether it did.
+// a.tier_lo / a.tier_hi: the pass of one length tier (a.max_len = the longest read of that tier): every kernel
+// then writes cls -- 0 for the reads of the other tiers.
 int rc_launch_threshold(rc_ctx *ctx, const rc_device_batch_args &a, bool classify)
 {
     ctx->cls_ready = false;
@@ -298,13 +371,15 @@ int rc_launch_threshold(rc_ctx *ctx, const rc_device_batch_args &a, bool classif
     int rc = fill_args(ctx, a, A);
     if (rc) return rc;
     const rc_lds_layout L = rc_layout(A.cap);
+    const bool tiered = a.tier_hi != RC_TIER_ALL || a.tier_lo >= 0;
     // four reads per wave when every read of the batch fits the quarter-wave layout (rc_quarter.h)
     const bool quarter = a.max_len <= rcq::MAX_LEN && a.max_len - A.P.k + 1 <= rcq::MAX_KCNT && !ctx->env_k2_wave_per_read;
-    if (quarter && classify && a.ret && ctx->trace_cap == 0 && !ctx->env_no_classify) {
+    const int ec = rc_short_ec(ctx, a.max_len, A.P.k);
+    if ((quarter || tiered) && classify && a.ret && ctx->trace_cap == 0 && !ctx->env_no_classify) {
         if ((rc = rc_dbuf_reserve(ctx, &ctx->cls, (size_t)a.n + 256))) return rc;
         A.cls = (uint8_t *)ctx->cls.p;
         ctx->cls_ready = true;
-        if (!ctx->env_no_single && a.max_len <= 160 && a.max_len - ctx->k + 1 <= 128) {  // candidates of k_single (rc_single.h)
+        if (quarter && !ctx->env_no_single && ec) {  // candidates of k_single (rc_single.h)
             if ((rc = rc_dbuf_reserve(ctx, &ctx->cand, (size_t)a.n + 256))) return rc;
             if ((rc = rc_dbuf_reserve(ctx, &ctx->runs, (size_t)a.n * 8 + 256))) return rc;
             A.cand = (uint8_t *)ctx->cand.p;
@@ -313,10 +388,15 @@ int rc_launch_threshold(rc_ctx *ctx, const rc_device_batch_args &a, bool classif
         }
     }
     rc_timer_begin(ctx);
-    if (quarter && a.max_len <= 160 && a.max_len - A.P.k + 1 <= 128) {
-        hipLaunchKernelGGL((k_threshold_q<8, 10>), dim3((a.n + 15) / 16), dim3(256), 0, ctx->stream, A);
+    const dim3 qgrid((a.n + 15) / 16), qblock(256);
+    if (quarter && ec == 8) {
+        hipLaunchKernelGGL((k_threshold_q<8, 10>), qgrid, qblock, 0, ctx->stream, A);
+    } else if (quarter && ec == 9) {
+        hipLaunchKernelGGL((k_threshold_q<9, 10>), qgrid, qblock, 0, ctx->stream, A);
+    } else if (quarter && ec == 10) {
+        hipLaunchKernelGGL((k_threshold_q<10, 10>), qgrid, qblock, 0, ctx->stream, A);
     } else if (quarter) {
-        hipLaunchKernelGGL((k_threshold_q<16, 20>), dim3((a.n + 15) / 16), dim3(256), 0, ctx->stream, A);
+        hipLaunchKernelGGL((k_threshold_q<16, 20>), qgrid, qblock, 0, ctx->stream, A);
     } else {
         unsigned grid = (unsigned)ctx->n_cu * 32u;
         if (grid > a.n) grid = a.n;
@@ -328,12 +408,14 @@ int rc_launch_threshold(rc_ctx *ctx, const rc_device_batch_args &a, bool classif
 }
 
 // K1 + K2 in one kernel over the locality list (ctx->loc_list); *done = false if the batch does not fit it
+// (a.max_len: the longest read of the tier the launch is for, at most 160 bases)
 int rc_launch_probe_threshold_list(rc_ctx *ctx, const rc_device_batch_args &a, size_t nbytes, bool *done)
 {
     *done = false;
     ctx->cls_ready = false;
     ctx->cand_ready = false;
-    if (a.n == 0 || a.max_len > 160 || a.max_len - ctx->k + 1 > 128 || ctx->k < 4 || ctx->env_k2_wave_per_read || ctx->env_no_fuse) return RC_OK;
+    const int ec = rc_short_ec(ctx, a.max_len, ctx->k);
+    if (a.n == 0 || !ec || ctx->k < 4 || ctx->env_k2_wave_per_read || ctx->env_no_fuse) return RC_OK;
     rc_kernel_args A;
     int rc = fill_args(ctx, a, A);
     if (rc) return rc;
@@ -341,7 +423,7 @@ int rc_launch_probe_threshold_list(rc_ctx *ctx, const rc_device_batch_args &a, s
         if ((rc = rc_dbuf_reserve(ctx, &ctx->cls, (size_t)a.n + 256))) return rc;
         A.cls = (uint8_t *)ctx->cls.p;
         ctx->cls_ready = true;
-        if (!ctx->env_no_single && a.max_len <= 160 && a.max_len - ctx->k + 1 <= 128) {  // candidates of k_single (rc_single.h)
+        if (!ctx->env_no_single) {  // candidates of k_single (rc_single.h)
             if ((rc = rc_dbuf_reserve(ctx, &ctx->cand, (size_t)a.n + 256))) return rc;
             if ((rc = rc_dbuf_reserve(ctx, &ctx->runs, (size_t)a.n * 8 + 256))) return rc;
             A.cand = (uint8_t *)ctx->cand.p;
@@ -364,14 +446,30 @@ int rc_launch_probe_threshold_list(rc_ctx *ctx, const rc_device_batch_args &a, s
     const dim3 grid((a.n + rpb - 1) / rpb), block(RC_PROBE_THREADS);
     const uint32_t *list = (const uint32_t *)ctx->loc_list.p;
     int32_t *counts = (int32_t *)ctx->counts.p;
-    if (large && ctx->ext)
-        hipLaunchKernelGGL((k_probe_threshold_list<4096, 6, true>), grid, block, 0, ctx->stream, A, nbytes, list, rpb, counts);
-    else if (large)
-        hipLaunchKernelGGL((k_probe_threshold_list<4096, 6, false>), grid, block, 0, ctx->stream, A, nbytes, list, rpb, counts);
-    else if (ctx->ext)
-        hipLaunchKernelGGL((k_probe_threshold_list<2816, RC_FUSED_SMALL_WAVES, true>), grid, block, 0, ctx->stream, A, nbytes, list, rpb, counts);
-    else
-        hipLaunchKernelGGL((k_probe_threshold_list<2816, RC_FUSED_SMALL_WAVES, false>), grid, block, 0, ctx->stream, A, nbytes, list, rpb, counts);
+#define RC_FUSED_LAUNCH(TILE, WAVES, EXT, EC) \
+    hipLaunchKernelGGL((k_probe_threshold_list<TILE, WAVES, EXT, EC>), grid, block, 0, ctx->stream, A, nbytes, list, rpb, counts)
+    if (large) {  // (reads of up to 119 bases: at most 116 k-mers)
+        if (ctx->ext)
+            RC_FUSED_LAUNCH(4096, 6, true, 8);
+        else
+            RC_FUSED_LAUNCH(4096, 6, false, 8);
+    } else if (ec == 8) {
+        if (ctx->ext)
+            RC_FUSED_LAUNCH(2816, RC_FUSED_SMALL_WAVES, true, 8);
+        else
+            RC_FUSED_LAUNCH(2816, RC_FUSED_SMALL_WAVES, false, 8);
+    } else if (ec == 9) {
+        if (ctx->ext)
+            RC_FUSED_LAUNCH(2816, RC_FUSED_SMALL_WAVES, true, 9);
+        else
+            RC_FUSED_LAUNCH(2816, RC_FUSED_SMALL_WAVES, false, 9);
+    } else {
+        if (ctx->ext)
+            RC_FUSED_LAUNCH(2816, RC_FUSED_SMALL_WAVES, true, 10);
+        else
+            RC_FUSED_LAUNCH(2816, RC_FUSED_SMALL_WAVES, false, 10);
+    }
+#undef RC_FUSED_LAUNCH
     rc_timer_end(ctx, RC_T_PROBE);
     RC_CHECK_HIP(ctx, hipGetLastError());
     *done = true;
@@ -386,7 +484,8 @@ int rc_launch_single(rc_ctx *ctx, const rc_device_batch_args &a, bool *ran)
 {
     *ran = false;
     if (a.n == 0 || !ctx->cls_ready || !ctx->cand_ready || ctx->env_no_single) return RC_OK;
-    if (a.max_len > rcs::MAX_LEN || a.max_len - ctx->k + 1 > rcs::MAX_KCNT || ctx->k < 4 || ctx->P.max_fix_per_k < 2) return RC_OK;
+    const int ec = rc_short_ec(ctx, a.max_len, ctx->k);
+    if (!ec || ctx->k < 4 || ctx->P.max_fix_per_k < 2) return RC_OK;
     rc_kernel_args A;
     int rc = fill_args(ctx, a, A);
     if (rc) return rc;
@@ -406,13 +505,39 @@ int rc_launch_single(rc_ctx *ctx, const rc_device_batch_args &a, bool *ran)
     unsigned g = (unsigned)ctx->n_cu * (unsigned)RC_K2S_GRID;  // (a few workgroups per CU slot; they walk the list, whose length stays on the device)
     if (g > (a.n + 15) / 16) g = (a.n + 15) / 16;
     const dim3 grid(g), block(256);
-    if (ctx->ext)
-        hipLaunchKernelGGL(k_single<true>, grid, block, 0, ctx->stream, A);
-    else
-        hipLaunchKernelGGL(k_single<false>, grid, block, 0, ctx->stream, A);
+    if (ec == 8) {
+        if (ctx->ext)
+            hipLaunchKernelGGL((k_single<true, 8>), grid, block, 0, ctx->stream, A);
+        else
+            hipLaunchKernelGGL((k_single<false, 8>), grid, block, 0, ctx->stream, A);
+    } else if (ec == 9) {
+        if (ctx->ext)
+            hipLaunchKernelGGL((k_single<true, 9>), grid, block, 0, ctx->stream, A);
+        else
+            hipLaunchKernelGGL((k_single<false, 9>), grid, block, 0, ctx->stream, A);
+    } else {
+        if (ctx->ext)
+            hipLaunchKernelGGL((k_single<true, 10>), grid, block, 0, ctx->stream, A);
+        else
+            hipLaunchKernelGGL((k_single<false, 10>), grid, block, 0, ctx->stream, A);
+    }
     rc_timer_end(ctx, RC_T_SINGLE);
     RC_CHECK_HIP(ctx, hipGetLastError());
     *ran = true;
+    return RC_OK;
+}
+
+int rc_launch_kmer_info(rc_ctx *ctx, const rc_device_batch_args &a)
+{
+    if (a.n == 0) return RC_OK;
+    rc_kernel_args A;
+    int rc = fill_args(ctx, a, A);
+    if (rc) return rc;
+    const rc_lds_layout L = rc_layout(A.cap);
+    unsigned grid = (unsigned)ctx->n_cu * 16u;
+    if (grid > a.n) grid = a.n;
+    hipLaunchKernelGGL(k_kmer_info, dim3(grid), dim3(64), L.total, ctx->stream, A);
+    RC_CHECK_HIP(ctx, hipGetLastError());
     return RC_OK;
 }
 

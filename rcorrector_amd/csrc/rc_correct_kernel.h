@@ -496,7 +496,24 @@ struct rc_kernel_args {
     int fused_front_end;               // 1: k_correct computes the read's own threshold (single-end, no threshold kernel ran)
     int32_t *trace;                    // TRACE builds only: n x (2 + trace_cap * RC_TRACE_WORDS) words
     int trace_cap;
+    // Length tiers (rc_api.hip: correct_device_impl).  A batch whose reads do not all fit the fastest kernels is
+    // processed tier by tier; a unit (a read, or a pair: mates need each other's threshold) belongs to the tier
+    // (tier_lo, tier_hi] that holds the length of its longer read, and a threshold kernel launched for one tier
+    // leaves the reads of the others alone (cls = 0: not on this pass's work list).  RC_TIER_ALL: no tiers.
+    int tier_lo, tier_hi;
+    // single-end batches only: the pairStrongTrustThreshold every read is corrected with (ErrorCorrection.h:27; -1 = none,
+    // what ErrorCorrection_Thread passes for a read without a mate, ErrorCorrection.cpp:121) -- rc_correct_read
+    int pair_override;
 };
+// the unit of read r: its own length and, in paired / interleaved batches, its mate's (off: n + 1 offsets, NULs counted)
+__device__ __forceinline__ int rc_unit_max_len(const rc_kernel_args &A, uint32_t r, int len)
+{
+    if (A.mode == 0) return len;
+    const uint32_t half = A.n >> 1, mr = A.mode == 1 ? (r < half ? r + half : r - half) : (r ^ 1u);
+    const int ml = (int)(A.off[mr + 1] - A.off[mr]) - 1;
+    return ml > len ? ml : len;
+}
+__device__ __forceinline__ bool rc_in_tier(const rc_kernel_args &A, int unit_max_len) { return unit_max_len > A.tier_lo && unit_max_len <= A.tier_hi; }
 
 template <class W>
 __device__ __forceinline__ void rc_load_read(W &w, const rc_kernel_args &A, rc_read_state &S, uint32_t o, int len, int lane, bool with_qual)
@@ -673,7 +690,7 @@ __global__ __launch_bounds__(64, rc_k3_waves(CAP)) void k_correct(rc_kernel_args
             strong0 = w.uni((int)me[3]);
             info0 = w.uni((int)me[4]);
         }
-        int pair_t = -1;
+        int pair_t = A.pair_override;
         if (A.mode != 0) pair_t = rc_min(strong0, w.uni((int)me[5]));
         w.phase(1);
         if (!A.fused_front_end && S.kcnt > 0 && !(info0 & 4)) rc_polya_flags(w, S, RC_K(A.P));

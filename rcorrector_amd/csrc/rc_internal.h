@@ -111,6 +111,8 @@ struct rc_ctx {
     rc_dbuf sel_tmp;  // rocPRIM scratch of the compaction
     rc_dbuf loc_a, loc_list;  // locality order of a batch (rc_launch_locality_order)
     bool env_no_fuse = false;  // RC_NO_FUSE=1 (dev): separate probe and threshold kernels in locality order too
+    int env_force_ec = 0;      // RC_FORCE_EC=9|10 (dev / tests): at least this many count registers per lane in the 160-base instances
+    bool env_no_tier = false;  // RC_NO_TIER=1 (dev / tests): no length tiers, the longest read of a batch decides every kernel
     bool env_k3_generic = false;  // RC_K3_GENERIC=1 (dev / tests): the any-k instance of k_correct even where a compiled-for-k one exists
     bool env_no_single = false;  // RC_NO_SINGLE=1 (dev / tests): no isolated-substitution kernel, every listed read goes to k_correct
     bool env_no_alt = false;  // RC_NO_ALT=1 (dev / tests): rc_run_params::flags |= RC_PF_NO_ALT
@@ -155,11 +157,14 @@ int rc_table_entries_in_dump_order(rc_ctx *ctx, std::vector<uint64_t> *codes, st
 int rc_launch_last_base_variants(rc_ctx *ctx, const uint64_t *d_codes, size_t n, int32_t *d_max2);
 int rc_launch_digest(rc_ctx *ctx, unsigned long long *d_out);
 int rc_launch_locality_order(rc_ctx *ctx, const struct rc_device_batch_args &a, size_t nbytes);
-int rc_launch_probe_list(rc_ctx *ctx, const struct rc_device_batch_args &a, size_t nbytes, int32_t *d_counts);
+int rc_launch_probe_list(rc_ctx *ctx, const struct rc_device_batch_args &a, size_t nbytes, int32_t *d_counts, int skip_hi = -1);
 int rc_launch_compact(rc_ctx *ctx, const uint8_t *d_cls, uint32_t n, uint32_t *d_list, size_t stride, uint32_t *d_count);
 int rc_launch_compact_flag(rc_ctx *ctx, const uint8_t *d_flag, uint32_t n, uint32_t *d_list, size_t stride, uint32_t *d_count);
 
 // rc_correct.hip
+#define RC_TIER_ALL 0x7fffffff  // rc_kernel_args::tier_hi: no length tiers
+#define RC_Q_MAX_KCNT 256        // the quarter-wave threshold kernel's widest instance (rc_quarter.h): k-mers / bases per read
+#define RC_Q_MAX_LEN 320
 struct rc_device_batch_args {
     int mode;            // 0 single, 1 paired (reads [0,n/2) are mates of [n/2,n)), 2 interleaved
     uint32_t n;          // reads
@@ -170,12 +175,15 @@ struct rc_device_batch_args {
     const uint32_t *off; // n+1
     int32_t *ret, *l, *m, *h;
     int max_len;         // longest read in the batch (bases)
+    int tier_lo = -1, tier_hi = RC_TIER_ALL;  // length tier of this pass (rc_kernel_args::tier_lo / tier_hi)
+    int pair_override = -1;                   // rc_kernel_args::pair_override
 };
 int rc_launch_threshold(rc_ctx *ctx, const rc_device_batch_args &a, bool classify);
 int rc_launch_correct(rc_ctx *ctx, const rc_device_batch_args &a);
 int rc_launch_single(rc_ctx *ctx, const rc_device_batch_args &a, bool *ran);
 int rc_launch_probe_threshold_list(rc_ctx *ctx, const rc_device_batch_args &a, size_t nbytes, bool *done);
 int rc_launch_summary(rc_ctx *ctx, const int32_t *d_ret, uint32_t n);
+int rc_launch_kmer_info(rc_ctx *ctx, const rc_device_batch_args &a);
 
 // k_correct's work list comes in RC_WORK_CLASSES sections, taken in order: the reads expected to be
 // the most expensive first, so that the last waves of a launch are not left alone with them

@@ -55,7 +55,16 @@ static int g_threads = 8;
 
 static double g_w_reader = 0, g_w_writer = 0, g_w_worker = 0;  // RC_TIMING: time blocked on the neighbouring stage
 static double g_t_read = 0, g_t_pack = 0, g_t_gpu = 0, g_t_format = 0, g_t_write = 0;  // RC_TIMING stage totals (thread-seconds)
-static double g_t_fill = 0, g_t_nl = 0, g_t_idx = 0;  // RC_TIMING: inside take_records (all files): pread, newline scan, line index
+// RC_TIMING: inside take_records (all files): pread, newline scan, line index.  The reader thread and the mate thread of a
+// paired input add to them concurrently.
+static std::mutex g_t_mu;
+static double g_t_fill = 0, g_t_nl = 0, g_t_idx = 0;
+static void timing_add(double &acc, double dt)
+{
+    if (!g_timing) return;
+    std::lock_guard<std::mutex> lk(g_t_mu);
+    acc += dt;
+}
 
 static double now_s()
 {
@@ -80,7 +89,7 @@ static void die(const char *fmt, ...)
 #include <functional>
 struct Pool {
     struct Call {
-        std::atomic<size_t> left{0};
+        size_t left = 0;  // guarded by m: the caller may destroy the Call as soon as it has seen 0 under the lock
         std::mutex m;
         std::condition_variable c;
     };
@@ -108,9 +117,10 @@ struct Pool {
                         q.pop_front();
                     }
                     (*t.fn)(t.idx);
-                    if (t.call->left.fetch_sub(1) == 1) {
+                    {   // decrement and notify under the call's mutex: run() cannot return (and free the Call on its
+                        // stack) between the two, it needs the mutex to leave its wait
                         std::lock_guard<std::mutex> lk(t.call->m);
-                        t.call->c.notify_all();
+                        if (--t.call->left == 0) t.call->c.notify_all();
                     }
                 }
             });
@@ -130,7 +140,7 @@ struct Pool {
         cv.notify_all();
         fn(0);
         std::unique_lock<std::mutex> lk(call.m);
-        call.c.wait(lk, [&] { return call.left.load() == 0; });
+        call.c.wait(lk, [&] { return call.left == 0; });
     }
     ~Pool()
     {
@@ -144,8 +154,10 @@ struct Pool {
 };
 static Pool g_pool;
 
-// binds the calling thread (and the threads it creates from now on) to the CPUs of one NUMA node; memory it
-// touches first then comes from that node too.  Returns false if the node's CPU list cannot be read.
+// binds the calling thread (and the threads it creates from now on) to the CPUs of one NUMA node that it is allowed
+// to run on already (taskset / a scheduler's pinning is narrowed, never widened); memory it touches first then comes
+// from that node too.  Returns false if the node's CPU list cannot be read or shares no CPU with the current mask.
+// (The helper threads of g_pool are shared by all GPUs' workers and stay unbound.)
 static bool bind_to_numa_node(int node)
 {
     char path[96];
@@ -156,8 +168,10 @@ static bool bind_to_numa_node(int node)
     const bool ok = fgets(buf, sizeof buf, fp) != nullptr;
     fclose(fp);
     if (!ok) return false;
-    cpu_set_t set;
+    cpu_set_t set, cur;
     CPU_ZERO(&set);
+    CPU_ZERO(&cur);
+    const bool have_cur = sched_getaffinity(0, sizeof cur, &cur) == 0;
     int n_cpu = 0;
     for (char *p = buf; *p;) {  // "0-63,128-191"
         char *e;
@@ -166,6 +180,7 @@ static bool bind_to_numa_node(int node)
         long b = a;
         if (*e == '-') b = strtol(e + 1, &e, 10);
         for (long c = a; c <= b && c < CPU_SETSIZE; ++c) {
+            if (have_cur && !CPU_ISSET((int)c, &cur)) continue;
             CPU_SET((int)c, &set);
             ++n_cpu;
         }
@@ -396,7 +411,7 @@ static void take_records(Source &s, size_t max_records, int lines_per_record, Bl
     for (;;) {
         const double tn0 = now_s();
         find_newlines(b.text.p, scanned, have, nl);
-        g_t_nl += now_s() - tn0;
+        timing_add(g_t_nl, now_s() - tn0);
         scanned = have;
         if (nl.size() >= want_lines) break;
         if (s.eof) break;
@@ -410,7 +425,7 @@ static void take_records(Source &s, size_t max_records, int lines_per_record, Bl
         b.text.need(have + want + 64);
         const double tf0 = now_s();
         have += s.fill(b.text.p + have, want);
-        g_t_fill += now_s() - tf0;
+        timing_add(g_t_fill, now_s() - tf0);
     }
     size_t n_lines = std::min(nl.size(), want_lines), end;
     if (nl.size() >= want_lines) {
@@ -448,7 +463,7 @@ static void take_records(Source &s, size_t max_records, int lines_per_record, Bl
     parallel_for(n_lines, [&](size_t lo, size_t hi) {
         for (size_t i = lo; i < hi; ++i) b.line[i + 1] = nl[i] + 1;
     });
-    g_t_idx += now_s() - ti0;
+    timing_add(g_t_idx, now_s() - ti0);
 }
 
 struct ReadFile {
@@ -519,10 +534,13 @@ static void open_file(ReadFile &f, const char *path, bool paired, bool interleav
         if (!f.out) die("ERROR: Could not access file %s\n", outp.c_str());
         // the output of a plain input is the input plus a few bytes per record: its blocks are reserved up front
         // (buffered writes into preallocated space: 11.8 GB/s against 10.1 on the GPU box's host, tools/mb/iob2.cpp)
-        // and the file is cut to its real length when it is closed
+        // -- FALLOC_FL_KEEP_SIZE: the file's length stays what has been written, so a run that ends abnormally leaves a
+        // valid prefix and not gigabytes of NUL bytes; a file system without fallocate fails fast (glibc's posix_fallocate
+        // would write into every block instead) and the output is simply not preallocated.  The ftruncate at close
+        // releases the blocks that were not needed.
         struct stat st;
         if (f.src.seekable && fstat(f.src.fd, &st) == 0 && st.st_size > ((off_t)64 << 20) &&
-            posix_fallocate(fileno(f.out), 0, st.st_size + st.st_size / 8) == 0)
+            fallocate(fileno(f.out), FALLOC_FL_KEEP_SIZE, 0, st.st_size + st.st_size / 8) == 0)
             f.preallocated = true;
     }
 }

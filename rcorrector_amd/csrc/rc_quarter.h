@@ -18,10 +18,12 @@
 
 namespace rcq {
 
-// two instantiations: <8, 10> = up to 128 windows / 160 bases per read, <16, 20> = 256 / 320
+// instantiations: <8, 10> = up to 128 windows / 160 bases per read, <9, 10> = 144 / 160 (151-base reads at
+// k = 23 have 129 windows), <10, 10> = every read of up to 160 bases, <16, 20> = 256 / 320
 // (EC count registers and EB base registers per lane, 16 lanes per read)
 constexpr int MAX_KCNT = 16 * 16;
 constexpr int MAX_LEN = 20 * 16;
+static_assert(MAX_KCNT == RC_Q_MAX_KCNT && MAX_LEN == RC_Q_MAX_LEN, "rc_internal.h");
 
 template <int CTRL>
 __device__ __forceinline__ int dpp(int v)
@@ -58,10 +60,15 @@ __device__ __forceinline__ int med3(int a, int b, int c)
 }
 constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
 
-// ascending bitonic network over the 128 elements (e, l) of each row, all-ascending ("flip")
+// ascending bitonic network over the EC * 16 elements (e, l) of each row, all-ascending ("flip")
 // formulation: the first stage of a merge pairs g with g ^ (size-1), the others g with g ^ stride,
 // the lower index keeps the minimum.  c[b] = bit b of l ? INT_MAX : INT_MIN turns one v_med3_i32
 // into "min on the lower side, max on the upper side".
+// EC need not be a power of two: the network is the one of the next power of two with the registers
+// beyond EC left out.  They would hold the padding value INT_MAX (every caller pads its own tail
+// with it), and since the lower index always keeps the minimum, a compare-exchange between a real
+// register and a padding one changes neither: 9 registers (144 windows: 151-base reads at k = 23)
+// cost 9/8 of the in-row steps of 8 and 13 register-to-register exchanges more, not the 2.6 x of 16.
 template <int EC, int X, int BIT>
 __device__ __forceinline__ void cx_row(int (&x)[EC], const int (&c)[4])
 {
@@ -75,7 +82,7 @@ __device__ __forceinline__ void strides(int (&x)[EC], const int (&c)[4])
 #pragma unroll
         for (int e = 0; e < EC; ++e) {
             const int pe = e ^ (STRIDE >> 4);
-            if (pe > e) {
+            if (pe > e && pe < EC) {
                 const int lo = x[e] < x[pe] ? x[e] : x[pe];
                 const int hi = x[e] < x[pe] ? x[pe] : x[e];
                 x[e] = lo;
@@ -96,7 +103,7 @@ __device__ __forceinline__ void merges(int (&x)[EC], const int (&c)[4])
 #pragma unroll
         for (int e = 0; e < EC; ++e) {
             const int pe = e ^ ((SIZE >> 4) - 1);
-            if (pe > e) {
+            if (pe > e && pe < EC) {
                 const int ye = row_xor<15>(x[pe]), yp = row_xor<15>(x[e]);
                 x[e] = x[e] < ye ? x[e] : ye;
                 x[pe] = x[pe] < yp ? yp : x[pe];
@@ -352,10 +359,13 @@ __device__ __forceinline__ int rcq_threshold_row(const rc_kernel_args &A, uint32
         if (A.cand) {
             bool cand = false;
             int cand_runs = 1;  // 0-runs of a candidate = segments k_single will walk: its work list is grouped by that number
-            if constexpr (E_CNT == 8) {
-                uint32_t other = 0, tb[E_CNT];
+            if constexpr (E_CNT <= 12) {
+                constexpr int NW = (E_CNT + 3) / 4;  // 64-bit words of the mask
+                uint32_t other = 0, tb[4 * NW];
 #pragma unroll
                 for (int e = 0; e < E_BASE; ++e) other |= row_bits(__ballot(code[e] >= 4 && e * 16 + l < len), row);
+#pragma unroll
+                for (int e = 0; e < 4 * NW; ++e) tb[e] = 0;
 #pragma unroll
                 for (int e = 0; e < E_CNT; ++e) {
                     const int g = e * 16 + l;
@@ -366,25 +376,47 @@ __device__ __forceinline__ int rcq_threshold_row(const rc_kernel_args &A, uint32
                     tb[e] = row_bits(__ballot(g < kcnt && cg >= s && na < k - 2 && nt < k - 2), row);
                 }
                 if (!clean && !clean2 && !screened && other == 0 && kcnt >= 5) {
-                    const uint64_t lo = (uint64_t)tb[0] | ((uint64_t)tb[1] << 16) | ((uint64_t)tb[2] << 32) | ((uint64_t)tb[3] << 48);
-                    const uint64_t hi = (uint64_t)tb[4] | ((uint64_t)tb[5] << 16) | ((uint64_t)tb[6] << 32) | ((uint64_t)tb[7] << 48);
-                    // Z = zero bits inside [0, kcnt); shifts over the 128-bit pair
-                    const uint64_t mlo = kcnt >= 64 ? ~0ull : ((1ull << kcnt) - 1ull), mhi = kcnt > 64 ? (kcnt >= 128 ? ~0ull : ((1ull << (kcnt - 64)) - 1ull)) : 0ull;
-                    const uint64_t zlo = ~lo & mlo, zhi = ~hi & mhi;
-                    const uint64_t iso_lo = lo & ~(lo << 1) & ~((lo >> 1) | (hi << 63)), iso_hi = hi & ~((hi << 1) | (lo >> 63)) & ~(hi >> 1);
-                    // starts and ends of the 0-runs: paired in order, every end must be its start + k - 1
-                    uint64_t slo = zlo & ~(zlo << 1), shi = zhi & ~((zhi << 1) | (zlo >> 63));
-                    uint64_t elo = zlo & ~((zlo >> 1) | (zhi << 63)), ehi = zhi & ~(zhi >> 1);
-                    const int nruns = __popcll(slo) + __popcll(shi);
-                    bool shape = (lo | hi) != 0 && (iso_lo | iso_hi) == 0 && nruns >= 1 && nruns <= 3;
+                    // T = the trusted mask, Z = its zero bits inside [0, kcnt); shifts run over the NW-word number
+                    uint64_t T[NW], Z[NW], S[NW], E[NW];
+                    uint64_t any = 0, iso = 0;
+#pragma unroll
+                    for (int q = 0; q < NW; ++q) {
+                        T[q] = (uint64_t)tb[4 * q] | ((uint64_t)tb[4 * q + 1] << 16) | ((uint64_t)tb[4 * q + 2] << 32) | ((uint64_t)tb[4 * q + 3] << 48);
+                        const int left = kcnt - 64 * q;
+                        const uint64_t mq = left >= 64 ? ~0ull : (left > 0 ? ((1ull << left) - 1ull) : 0ull);
+                        Z[q] = ~T[q] & mq;
+                        any |= T[q];
+                    }
+                    int nruns = 0;
+#pragma unroll
+                    for (int q = 0; q < NW; ++q) {
+                        const uint64_t t_up = (T[q] << 1) | (q > 0 ? T[q - 1] >> 63 : 0ull), t_dn = (T[q] >> 1) | (q + 1 < NW ? T[q + 1] << 63 : 0ull);
+                        const uint64_t z_up = (Z[q] << 1) | (q > 0 ? Z[q - 1] >> 63 : 0ull), z_dn = (Z[q] >> 1) | (q + 1 < NW ? Z[q + 1] << 63 : 0ull);
+                        iso |= T[q] & ~t_up & ~t_dn;
+                        S[q] = Z[q] & ~z_up;  // starts and ends of the 0-runs: paired in order, every end must be its start + k - 1
+                        E[q] = Z[q] & ~z_dn;
+                        nruns += __popcll(S[q]);
+                    }
+                    bool shape = any != 0 && iso == 0 && nruns >= 1 && nruns <= 3;
                     uint32_t rr[3] = {0, 0, 0};  // per run: first k-mer | length << 8 (what k_single walks)
 #pragma unroll
                     for (int q = 0; q < 3; ++q) {
                         if (shape && q < nruns) {
-                            const int z0 = slo ? __ffsll((long long)slo) - 1 : 64 + __ffsll((long long)shi) - 1;
-                            const int z1 = elo ? __ffsll((long long)elo) - 1 : 64 + __ffsll((long long)ehi) - 1;
-                            if (slo) slo &= slo - 1; else shi &= shi - 1;
-                            if (elo) elo &= elo - 1; else ehi &= ehi - 1;
+                            int z0 = 0, z1 = 0;
+                            bool got0 = false, got1 = false;
+#pragma unroll
+                            for (int v = 0; v < NW; ++v) {
+                                if (!got0 && S[v]) {
+                                    z0 = 64 * v + __ffsll((long long)S[v]) - 1;
+                                    S[v] &= S[v] - 1;
+                                    got0 = true;
+                                }
+                                if (!got1 && E[v]) {
+                                    z1 = 64 * v + __ffsll((long long)E[v]) - 1;
+                                    E[v] &= E[v] - 1;
+                                    got1 = true;
+                                }
+                            }
                             shape = z1 - z0 + 1 == k || ((z0 == 0 || z1 == kcnt - 1) && z1 - z0 + 1 < k);
                             rr[q] = (uint32_t)z0 | ((uint32_t)(z1 - z0 + 1) << 8);
                         }
@@ -437,6 +469,22 @@ __global__ __launch_bounds__(256) void k_threshold_q(rc_kernel_args A)
     if (live) {
         o = A.off[r];
         len = (int)(A.off[r + 1] - o) - 1;
+    }
+    if (A.tier_hi != RC_TIER_ALL || A.tier_lo >= 0) {  // (uniform) another tier's read: cls = 0, nothing else
+        int ml = len;
+        if (A.mode != 0) {
+            const int mm = __shfl(len, (threadIdx.x & 63) ^ 16, 64);
+            ml = mm > ml ? mm : ml;
+        }
+        if (live && !rc_in_tier(A, ml)) {
+            if ((threadIdx.x & 15) == 0) {
+                if (A.cls) A.cls[r] = 0;
+                if (A.cand) A.cand[r] = 0;
+            }
+            live = false;
+            len = 0;
+        }
+        if (!__ballot(live)) return;
     }
     rcq_threshold_row<E_CNT, E_BASE>(
         A, r, live, len, [&](int p) { return (uint32_t)A.seq[o + p]; }, [&](int g) { return A.counts[o + g]; });

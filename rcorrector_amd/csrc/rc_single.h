@@ -48,15 +48,18 @@
 #endif
 namespace rcs {
 
-constexpr int MAX_KCNT = 128, MAX_LEN = 160, PK_WORDS = MAX_LEN / 16 + 2, MAX_SEG = 3;
+// instances for reads of up to EC * 16 k-mers, EC = 8 / 9 / 10 count registers per lane (rc_quarter.h: the same three
+// as the threshold code); every read of up to 160 bases fits the last
+constexpr int MAX_KCNT = 160, MAX_LEN = 160, PK_WORDS = MAX_LEN / 16 + 2, MAX_SEG = 3;
 
 }  // namespace rcs
 
 // one 16-lane row, one read (r = 0xFFFFFFFF: none); s_cnt / s_pk: the row's LDS (rows of a wave do not share any)
-template <bool EXT>
+template <bool EXT, int EC>
 __device__ __forceinline__ void rcs_row(const rc_kernel_args &A, uint32_t r, int32_t *s_cnt_row, uint32_t *s_pk_row)
 {
     using namespace rcs;
+    constexpr int MAX_KCNT = EC * 16;
     const int lane = threadIdx.x & 63, row = lane >> 4, l = lane & 15, row_lane0 = row << 4;
     const int k = A.P.k, mfk = A.P.max_fix_per_k;
     const double er = A.P.error_rate;
@@ -125,7 +128,7 @@ __device__ __forceinline__ void rcs_row(const rc_kernel_args &A, uint32_t r, int
         if (ok && p < len) atomicOr(&s_pk_row[e], (uint32_t)(rc_base_code(A.seq[o + p]) & 3) << (30 - 2 * l));
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
+    for (int e = 0; e < EC; ++e) {
         const int g = e * 16 + l;
         int v = 0;
         if (ok && g < kcnt) v = A.counts[o + g];
@@ -255,10 +258,10 @@ __device__ __forceinline__ void rcs_row(const rc_kernel_args &A, uint32_t r, int
     // 0 shown as 1 (:1583).  Minimum and maximum are row reductions; the element of rank kcnt/2 comes from a descent over
     // the bits of the largest count (one count-the-smaller-ones row reduction per bit: counts of a few hundred make that
     // a third of the sorting network's instructions); counts of 2^14 and more take the network.
-    int x[8];
+    int x[EC];
     int vmin = 2147483647, vmax = 1;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
+    for (int e = 0; e < EC; ++e) {
         const int g = e * 16 + l;
         int v = s_cnt_row[g];
         v = v == 0 ? 1 : v;
@@ -301,7 +304,7 @@ __device__ __forceinline__ void rcs_row(const rc_kernel_args &A, uint32_t r, int
             const int cand = prefix | (1 << b);
             int below = 0;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) below += x[e] < cand ? 1 : 0;
+            for (int e = 0; e < EC; ++e) below += x[e] < cand ? 1 : 0;
             below = row_sum(below);
             prefix = below <= im ? cand : prefix;   // the largest value with at most im counts below it: the element of rank im
         }
@@ -310,10 +313,10 @@ __device__ __forceinline__ void rcs_row(const rc_kernel_args &A, uint32_t r, int
         int c4[4];
 #pragma unroll
         for (int bb = 0; bb < 4; ++bb) c4[bb] = __builtin_amdgcn_sbfe(l, bb, 1) ^ (int)0x80000000;
-        rcq::merges<8, 2>(x, c4);
+        rcq::merges<EC, 2>(x, c4);
         int sm = x[0];
 #pragma unroll
-        for (int e = 1; e < 8; ++e) sm = (im >> 4) == e ? x[e] : sm;
+        for (int e = 1; e < EC; ++e) sm = (im >> 4) == e ? x[e] : sm;
         vm = __builtin_amdgcn_ds_bpermute((row_lane0 + (im & 15)) << 2, sm);
     }
     if (ok) {
@@ -331,14 +334,14 @@ __device__ __forceinline__ void rcs_row(const rc_kernel_args &A, uint32_t r, int
     }
 }
 
-// reads of up to 160 bases / 128 k-mers; 256 threads = 16 reads per pass.  The reads come off the work list
+// reads of up to 160 bases / EC * 16 k-mers; 256 threads = 16 reads per pass.  The reads come off the work list
 // (RC_WORK_CLASSES sections, rc_internal.h), whose length stays on the device: a fixed grid of workgroups walks the
 // concatenated sections (a workgroup per 16 reads would be 1.5 M workgroups for 25 M reads, a third of them empty)
-template <bool EXT>
+template <bool EXT, int EC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RC_K2S_WAVES, RC_K2S_WAVES))) void k_single(rc_kernel_args A)
 {
     using namespace rcs;
-    __shared__ int32_t s_cnt[16][MAX_KCNT];
+    __shared__ int32_t s_cnt[16][EC * 16];
     __shared__ uint32_t s_pk[16][PK_WORDS];
     const int rr = (int)(threadIdx.x >> 6) * 4 + (int)((threadIdx.x & 63) >> 4);
     const uint32_t n0 = A.n_work[0], n1 = A.n_work[1], n2 = A.n_work[2], n3 = A.n_work[3];
@@ -361,6 +364,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RC_K2S_WAVE
             }
             r = A.worklist[(size_t)c * A.work_stride + g];
         }
-        rcs_row<EXT>(A, r, s_cnt[rr], s_pk[rr]);
+        rcs_row<EXT, EC>(A, r, s_cnt[rr], s_pk[rr]);
     }
 }

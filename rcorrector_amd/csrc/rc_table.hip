@@ -665,10 +665,13 @@ __global__ __launch_bounds__(RC_PROBE_THREADS) void k_probe(rc_table_view T, con
 // K1 over a list of reads (locality order): the workgroup's reads are copied into a local arena in
 // LDS -- each at the byte alignment it has in memory, NULs in between -- packed and probed as in
 // k_probe; a count goes to the position of its k-mer in the caller's arena.
+// skip_hi >= 0: the reads of units (a read, or a pair: mode as in rc_kernel_args) whose longer read has at most skip_hi
+// bases are left out -- the fused probe + threshold kernel of the short tier has their counts (rc_correct.hip).
 template <bool EXT>
 __global__ __launch_bounds__(RC_PROBE_THREADS) void k_probe_list(rc_table_view T, const uint8_t *__restrict__ seq, size_t nbytes,
                                                                  const uint32_t *__restrict__ off, const uint32_t *__restrict__ list,
-                                                                 uint32_t n, uint32_t reads_per_block, int k, int32_t *__restrict__ counts)
+                                                                 uint32_t n, uint32_t reads_per_block, int k, int32_t *__restrict__ counts,
+                                                                 int mode, int skip_hi)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_raw[(RC_PROBE_TILE + 64) / 4];
     __shared__ uint32_t s_code[RC_PROBE_TILE / 16 + 4];
@@ -681,8 +684,18 @@ __global__ __launch_bounds__(RC_PROBE_THREADS) void k_probe_list(rc_table_view T
     for (int c = t; c < (RC_PROBE_TILE + 64) / 4; c += RC_PROBE_THREADS) s_raw[c] = 0;
     if ((uint32_t)t < nr) {
         const uint32_t r = list[i0 + t], g0 = off[r];
+        uint32_t len1 = off[r + 1] - g0;  // bases + the NUL
+        if (skip_hi >= 0) {
+            uint32_t ml1 = len1;
+            if (mode != 0) {
+                const uint32_t half = n >> 1, mr = mode == 1 ? (r < half ? r + half : r - half) : (r ^ 1u);
+                const uint32_t m1 = off[mr + 1] - off[mr];
+                ml1 = m1 > ml1 ? m1 : ml1;
+            }
+            if ((int)ml1 - 1 <= skip_hi) len1 = 0;  // 0 = not a read of this launch
+        }
         s_gpos[t] = g0;
-        s_len1[t] = off[r + 1] - g0;  // bases + the NUL
+        s_len1[t] = len1;
     }
     __syncthreads();
     if (t == 0) {  // local start of each read: same alignment modulo 4 as in memory, a NUL in front
@@ -697,6 +710,7 @@ __global__ __launch_bounds__(RC_PROBE_THREADS) void k_probe_list(rc_table_view T
     __syncthreads();
     // copy: one 64-lane group per read, aligned dwords, bytes outside the read masked to NUL
     for (uint32_t j = (uint32_t)t >> 6; j < nr; j += RC_PROBE_THREADS / 64) {
+        if (!s_len1[j]) continue;
         const uint32_t g0 = s_gpos[j], lp = s_lpos[j], g1 = g0 + s_len1[j] - 1;  // [g0, g1): the bases
         const uint32_t w0 = g0 >> 2, w1 = (g1 + 3) >> 2;
         for (uint32_t w = w0 + ((uint32_t)t & 63u); w < w1; w += 64u) {
@@ -754,7 +768,7 @@ __global__ __launch_bounds__(RC_PROBE_THREADS) void k_probe_list(rc_table_view T
     }
 }
 
-int rc_launch_probe_list(rc_ctx *ctx, const rc_device_batch_args &a, size_t nbytes, int32_t *d_counts)
+int rc_launch_probe_list(rc_ctx *ctx, const rc_device_batch_args &a, size_t nbytes, int32_t *d_counts, int skip_hi)
 {
     if (a.n == 0) return RC_OK;
     if (!ctx->d_buckets) {
@@ -767,10 +781,10 @@ int rc_launch_probe_list(rc_ctx *ctx, const rc_device_batch_args &a, size_t nbyt
     rc_timer_begin(ctx);
     if (ctx->ext)
         hipLaunchKernelGGL(k_probe_list<true>, dim3((a.n + rpb - 1) / rpb), dim3(RC_PROBE_THREADS), 0, ctx->stream, rc_view(ctx), a.seq, nbytes, a.off,
-                           (const uint32_t *)ctx->loc_list.p, a.n, rpb, ctx->k, d_counts);
+                           (const uint32_t *)ctx->loc_list.p, a.n, rpb, ctx->k, d_counts, a.mode, skip_hi);
     else
         hipLaunchKernelGGL(k_probe_list<false>, dim3((a.n + rpb - 1) / rpb), dim3(RC_PROBE_THREADS), 0, ctx->stream, rc_view(ctx), a.seq, nbytes, a.off,
-                           (const uint32_t *)ctx->loc_list.p, a.n, rpb, ctx->k, d_counts);
+                           (const uint32_t *)ctx->loc_list.p, a.n, rpb, ctx->k, d_counts, a.mode, skip_hi);
     rc_timer_end(ctx, RC_T_PROBE);
     RC_CHECK_HIP(ctx, hipGetLastError());
     return RC_OK;

@@ -19,7 +19,37 @@ CONFIGS = {
     "max1023": dict(k=23, mfk=4, rate=0.01, mode=0, kw=dict(seed=114, n=80, length=1023, e=0.008, n_tx=4, l_tx=1500, var_len=True)),
     "k11": dict(k=11, mfk=4, rate=0.01, mode=0, kw=dict(seed=115, n=1500, length=60, e=0.01, n_tx=6, l_tx=300)),
     "pe_var": dict(k=23, mfk=4, rate=0.02, mode=1, kw=dict(seed=111, n=1500, length=120, e=0.03, paired=True, var_len=True, p_n=0.005)),
+    # 129 k-mers per read: one more than eight count registers per lane hold (rc_quarter.h: the <9, 10> instances)
+    "se_151": dict(k=23, mfk=4, rate=0.01, mode=0, kw=dict(seed=116, n=3000, length=151, e=0.01)),
+    "pe_151": dict(k=23, mfk=4, rate=0.01, mode=1, kw=dict(seed=117, n=1500, length=151, e=0.006, paired=True)),
+    # 146 k-mers per read: the <10, 10> instances
+    "pe_160_k15": dict(k=15, mfk=4, rate=0.01, mode=1, kw=dict(seed=118, n=1200, length=160, e=0.006, paired=True, n_tx=60)),
 }
+
+# read lengths either side of every tier boundary of rc_api.hip (k = 23: S <= 160 < M <= 278 < L), mates drawn independently
+TIER_LENGTHS = [60, 100, 128, 150, 150, 150, 151, 151, 160, 161, 200, 250, 278, 279, 320, 321, 400]
+
+
+def tier_reads(mode, seed=119, n=1800, k=23):
+    """Mixed-length batches: most reads short, some either side of the length tiers, the two mates of a pair of different
+    lengths more often than not (a unit is routed by its longer read)."""
+    length = max(TIER_LENGTHS)
+    s1, q1, s2, q2, _ = synth.make_reads(seed, n, length, e=0.008, paired=mode != 0, n_tx=12, l_tx=1500, frag_len=500)
+    rng = np.random.Generator(np.random.PCG64(seed + 1))
+    lens1 = rng.choice(TIER_LENGTHS, n)
+    lens2 = rng.choice(TIER_LENGTHS, n)
+    keys, cnt = synth.count_kmers([s1, s2], k, [lens1, lens2])
+    r1 = [s1[i, :lens1[i]].tobytes() for i in range(n)]
+    qq1 = [q1[i, :lens1[i]].tobytes() for i in range(n)]
+    r2 = qq2 = None
+    if mode != 0:
+        r2 = [s2[i, :lens2[i]].tobytes() for i in range(n)]
+        qq2 = [q2[i, :lens2[i]].tobytes() for i in range(n)]
+    if mode == 2:
+        r1 = [x for p in zip(r1, r2) for x in p]
+        qq1 = [x for p in zip(qq1, qq2) for x in p]
+        r2 = qq2 = None
+    return dict(k=k, mfk=4, rate=0.01, mode=mode, keys=keys, counts=cnt, seqs1=r1, quals1=qq1, seqs2=r2, quals2=qq2)
 
 
 def adversarial_reads(seed=7, n=600, length=100):
@@ -110,6 +140,8 @@ def make(name):
         keys, cnt = synth.count_kmers([s1], k)
         return dict(k=k, mfk=4, rate=0.0041, mode=0, keys=keys, counts=cnt, seqs1=[r.tobytes() for r in s1],
                     quals1=[q.tobytes() for q in q1], seqs2=None, quals2=None)
+    if name in ("tiers_se", "tiers_pe", "tiers_il"):
+        return tier_reads({"se": 0, "pe": 1, "il": 2}[name[-2:]])
     if name == "edge":
         r, q = adversarial_reads()
         s1, _, _, _, _ = synth.make_reads(7, 600, 100, e=0.01)

@@ -1,5 +1,7 @@
 """GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle on the same
 seeded inputs.  Integer / byte work => bit-exact everywhere."""
+import os
+
 import numpy as np
 import pytest
 
@@ -90,7 +92,8 @@ def test_probe_kernel_counts(gpu_ctx_factory, oracle, name):
 
 
 @pytest.mark.parametrize("name", ["se_k23", "pe_k23", "il_k23", "k31_mc8", "skew", "nrich", "varlen", "k15", "k32", "pe_var", "edge",
-                                  "long300", "long600_k31", "max1023", "k11", "polya_k23", "polya_k31", "polya_k15"])
+                                  "long300", "long600_k31", "max1023", "k11", "polya_k23", "polya_k31", "polya_k15",
+                                  "se_151", "pe_151", "pe_160_k15", "tiers_se", "tiers_pe", "tiers_il"])
 def test_correct_batch_matches_oracle(gpu_ctx_factory, oracle, name):
     d = datasets.make(name)
     want = datasets.run_oracle(oracle, d)
@@ -274,11 +277,12 @@ def test_get_bound_device_equals_x86(gpu_ctx_factory, oracle, rate):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("k,length", [(23, 150), (23, 100), (31, 158), (15, 90), (32, 159), (19, 146), (11, 138),
-                                      (25, 250), (25, 280), (32, 287), (23, 161), (21, 320), (23, 300)])
+                                      (25, 250), (25, 280), (32, 287), (23, 161), (21, 320), (23, 300),
+                                      (23, 151), (23, 160), (17, 160), (16, 160), (15, 160)])
 def test_strong_threshold_quarter_wave_equals_wave_per_read_and_oracle(gpu_ctx_factory, oracle, k, length, monkeypatch):
     """GetStrongTrustedThreshold through both threshold kernels -- four reads per wave
-    (rc_quarter.h: two register layouts, up to 128 k-mers / 160 bases and up to 256 / 320; the last
-    case is beyond both) and one read per wave
+    (rc_quarter.h: four register layouts, up to 128 / 144 / 160 k-mers in 160 bases and up to 256 in 320;
+    (23, 300) is beyond all of them) and one read per wave
     -- and through the oracle, on reads with ragged lengths (also < k), N runs, poly-A/T tails and
     count spectra with and without a 'drop'."""
     import torch
@@ -356,6 +360,31 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     assert 0.2 < d["config"]["reads_corrected_frac"] < 0.9
     # every rank rebuilt the same replicated table (deterministic generator) and the digests were compared
     assert d["config"]["table_replicas_identical"] is True and len(d["config"]["table_digest"]) == 16
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config", [1, 3, 4])
+def test_full_size_presets_match_the_oracle_on_a_sample(config):
+    """BASELINE.json configs[1], [3] and [4] at FULL size (configs[2] is the driver's default bench run): 10 M x 100 bp,
+    50 M x 150 bp with the skewed spectrum, 100 M x 150 bp at k = 31 / maxcorK 8 / 5 % errors over the 871 M-k-mer table
+    counted from all of them -- one timed step each through bench.py, then the oracle on the first 200 000 reads of the
+    same batch with the same table: return values and corrected bases must be identical."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--config", str(config), "--steps", "1", "--warmup", "0",
+           "--parity-only", "--cpu-sample", "200000"]
+    p = subprocess.run(cmd, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["config"]["preset"] == config and d["n_gpus"] == 1
+    assert d["config"]["reads_per_gpu"] == {1: 10_000_000, 3: 50_000_000, 4: 100_000_000}[config]
+    cb = d["cpu_baseline"]
+    assert cb["gpu_matches_oracle_on_sample"] is True, cb
+    assert "200000 reads" in cb["sample"] and d["config"]["reads_corrected_frac"] > 0.2
 
 
 @pytest.mark.gpu
@@ -577,7 +606,8 @@ def test_quality_bits_give_the_same_results_as_quality_bytes(gpu_ctx_factory, or
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["se_k23", "pe_k23", "il_k23", "pe_var", "varlen", "edge", "k31_mc8", "long600_k31", "polya_k23"])
+@pytest.mark.parametrize("name", ["se_k23", "pe_k23", "il_k23", "pe_var", "varlen", "edge", "k31_mc8", "long600_k31", "polya_k23",
+                                  "se_151", "pe_151", "pe_160_k15", "tiers_se", "tiers_pe", "tiers_il"])
 def test_locality_order_does_not_change_results(oracle, name, monkeypatch):
     """Large batches are processed in min-hash order (overlapping reads next to each other, rc_table.hip):
     a pure reordering -- forced here on the small parity sets, ragged, paired and interleaved ones included,
@@ -678,6 +708,92 @@ def test_default_dispatch_at_a_size_that_selects_the_timed_path(oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["len151", "mixed"])
+def test_default_dispatch_on_151_base_reads_and_on_a_mixed_length_batch(oracle, shape):
+    """The fast path is not a property of the batch's longest read (the reference treats every read of up to 1 023 bases
+    alike, utils.h:7).  `len151`: 151-base pairs at k = 23 have 129 k-mers -- the nine-register instances of the fused probe
+    + threshold kernel and of k_single.  `mixed`: 90 % 150-base, 9 % 151-base, 1 % 250-base reads, mates drawn
+    independently: the short units stay on the fused kernel / k_single / the compiled-for-k k_correct, the units with a
+    250-base read take the list-driven probe kernel, the quarter-wave threshold kernel and k_correct<320> (rc_api.hip:
+    length tiers).  400 k paired reads over a table beyond 128 MB, no knob; the first 10 000 pairs against the oracle."""
+    import torch
+    import bench as B
+    dev = torch.device("cuda", 0)
+    mix = [(151, 1.0)] if shape == "len151" else [(150, 0.9), (151, 0.09), (250, 0.01)]
+    n, L, k = 400_000, max(m[0] for m in mix), 23
+    cnt_reads = 1_600_000
+    seq_u, qual_u = B.synth_reads_gpu(777003, cnt_reads, L, 4400, 1500, 0.8, 0.005, dev, paired=True)
+    seq_all, qual_all, off_all, _, lens_all = B.cut_reads(seq_u, qual_u, cnt_reads, L, mix, 777003, 0, dev)
+    del seq_u, qual_u
+    ctx = rcorrector_amd.Context(k=k, device=0)
+    ctx.count_reads_device(seq_all, seq_all.numel(), 2)
+    st = ctx.table_stats()
+    assert st["bytes"] > (128 << 20) and ctx.table_layout() == 1, st
+    rate = ctx.estimate_error_rate(0.95)
+    ctx.set_run_params(rate, b"H")
+    # mode 1 batch of n reads: first mates [0, n/2), second mates [n/2, n) -- cut out of the generator's halves
+    half_all, half = cnt_reads // 2, n // 2
+    o = off_all.long()
+
+    def piece(lo, m):
+        b0, b1 = int(o[lo].item()), int(o[lo + m].item())
+        return seq_all[b0:b1], qual_all[b0:b1], (o[lo:lo + m + 1] - b0)
+    s1, q1, o1 = piece(0, half)
+    s2, q2, o2 = piece(half_all, half)
+    seq = torch.cat([s1, s2]).contiguous()
+    qual = torch.cat([q1, q2]).contiguous()
+    off = torch.cat([o1, o2[1:] + o1[-1]]).to(torch.int32)
+    work = seq.clone()
+    res = [torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(4)]
+    ctx.profile(True)
+    ctx.profile_reset()
+    ctx.correct_device(1, n, work.numel(), L, work, qual, off, *res)
+    ctx.sync()
+    _, launches = ctx.profile_get(0)
+    _, thr_launches = ctx.profile_get(1)
+    _, single_launches = ctx.profile_get(3)
+    ctx.profile(False)
+    if shape == "len151":
+        assert launches == 1 and thr_launches == 0 and single_launches == 1, "151-base reads fell off the fused probe + threshold kernel"
+    else:   # fused kernel + the list-driven probe kernel of the long units; one threshold kernel for the 250-base tier
+        assert launches == 2 and thr_launches == 1 and single_launches == 1, (launches, thr_launches, single_launches)
+        assert int((lens_all[:half] > 160).sum().item()) > 1000
+    pairs = 10_000
+    codes, counts = ctx.table_export()
+    T = oracle.Table(k, len(codes))
+    T.put_many(codes, counts)
+    P = oracle.make_params(k, 4, rate, b"H")
+    b1, b2 = int(o1[pairs].item()), int(o2[pairs].item())
+    a1, qa1 = s1[:b1].cpu().numpy().copy(), q1[:b1].cpu().numpy().copy()
+    a2, qa2 = s2[:b2].cpu().numpy().copy(), q2[:b2].cpu().numpy().copy()
+    ho1, ho2 = o1[:pairs + 1].cpu().numpy().astype(np.uint32), o2[:pairs + 1].cpu().numpy().astype(np.uint32)
+    want = oracle.correct_batch(P, T, 1, a1, qa1, ho1, a2, qa2, ho2, threads=8)
+    for got, w in zip(res, want):
+        g = got.cpu().numpy()
+        assert np.array_equal(g[:pairs], w[:pairs]) and np.array_equal(g[half:half + pairs], w[pairs:])
+    base2 = int(o1[-1].item())
+    assert np.array_equal(work[:b1].cpu().numpy(), a1) and np.array_equal(work[base2:base2 + b2].cpu().numpy(), a2)
+    assert (want[0] > 0).sum() > 2000
+    # a pure re-arrangement: the batch's longest read deciding for every read (RC_NO_TIER=1) gives the same
+    os.environ["RC_NO_TIER"] = "1"
+    try:
+        ctx2 = rcorrector_amd.Context(k=k, device=0)
+        ctx2.table_build(codes, counts)
+        ctx2.set_run_params(rate, b"H")
+        work2 = seq.clone()
+        res2 = [torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(4)]
+        ctx2.correct_device(1, n, work2.numel(), L, work2, qual, off, *res2)
+        ctx2.sync()
+    finally:
+        del os.environ["RC_NO_TIER"]
+    for x, y in zip(res, res2):
+        assert torch.equal(x, y)
+    assert torch.equal(work, work2)
+    ctx2.close()
+    ctx.close()
+
+
+@pytest.mark.gpu
 def test_k31_maxcork8_on_a_packed_table_with_extension_bits(oracle):
     """BASELINE configs[4]'s code path at test size: k = 31, -maxcorK 8, 5 % substitutions over a table of
     >= 17 M entries, which the build lays out PACKED with remainder extension bits (ext > 0: the k = 31
@@ -759,12 +875,13 @@ KNOBS = [{"RC_TABLE_LAYOUT": "wide"}, {"RC_TABLE_LOAD": "0.85"}, {"RC_TABLE_LOAD
          {"RC_NO_FUSE": "1", "RC_LOCALITY": "force"}, {"RC_K2_WAVE_PER_READ": "1"}, {"RC_NO_CLASSIFY": "1"},
          {"RC_NO_ALT": "1"}, {"RC_K3_GENERIC": "1"}, {"RC_K3_GENERIC": "1", "RC_NO_ALT": "1", "RC_LOCALITY": "force"},
          {"RC_TABLE_FILTER": "force"}, {"RC_TABLE_FILTER": "force", "RC_LOCALITY": "force", "RC_TABLE_LOAD": "0.85"},
-         {"RC_NO_SINGLE": "1"}, {"RC_NO_SINGLE": "1", "RC_NO_ALT": "1"}, {"RC_NO_BS_EXT": "1"}]
+         {"RC_NO_SINGLE": "1"}, {"RC_NO_SINGLE": "1", "RC_NO_ALT": "1"}, {"RC_NO_BS_EXT": "1"}, {"RC_NO_TIER": "1"},
+         {"RC_NO_TIER": "1", "RC_LOCALITY": "force"}]
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("knobs", KNOBS, ids=lambda d: "+".join("%s=%s" % kv for kv in d.items()))
-@pytest.mark.parametrize("name", ["se_k23", "pe_var", "k31_mc8"])
+@pytest.mark.parametrize("name", ["se_k23", "pe_var", "k31_mc8", "tiers_pe"])
 def test_every_alternative_code_path_gives_the_oracles_results(oracle, name, knobs, monkeypatch):
     """tools/knob_matrix.sh as a test: the library's alternative code paths (slot layout, load factor, list-driven and
     unfused probe kernels on small batches, wave-per-read threshold kernel, no classification, no alternative chains

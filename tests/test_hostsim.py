@@ -6,7 +6,8 @@ import pytest
 import datasets
 
 
-@pytest.mark.parametrize("name", ["se_k23", "pe_k23", "il_k23", "k31_mc8", "skew", "nrich", "varlen", "k15", "k32", "pe_var", "edge", "long300", "long600_k31", "max1023", "k11", "polya_k23", "polya_k31", "polya_k15"])
+@pytest.mark.parametrize("name", ["se_k23", "pe_k23", "il_k23", "k31_mc8", "skew", "nrich", "varlen", "k15", "k32", "pe_var", "edge", "long300", "long600_k31", "max1023", "k11", "polya_k23", "polya_k31", "polya_k15",
+                                  "se_151", "pe_151", "pe_160_k15", "tiers_se", "tiers_pe", "tiers_il"])
 def test_core_control_flow_matches_oracle(oracle, hostsim, name):
     d = datasets.make(name)
     want = datasets.run_oracle(oracle, d)

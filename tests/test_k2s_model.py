@@ -24,7 +24,7 @@ def _reads(d, want, oracle):
 
 
 @pytest.mark.parametrize("double", [False, True], ids=["as_built", "with_class_D"])
-@pytest.mark.parametrize("name", ["se_k23", "pe_k23", "il_k23", "skew", "k11", "k32", "varlen", "polya_k23"])
+@pytest.mark.parametrize("name", ["se_k23", "pe_k23", "il_k23", "skew", "k11", "k32", "varlen", "polya_k23", "pe_151", "pe_160_k15"])
 def test_model_of_the_early_finish_agrees_with_the_oracle(oracle, name, double):
     d = datasets.make(name)
     k, mfk = d["k"], d["mfk"]
