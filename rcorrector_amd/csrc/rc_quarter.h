@@ -245,11 +245,14 @@ __device__ __forceinline__ int rcq_threshold_row(const rc_kernel_args &A, uint32
     // Class of the read.  Replay the first threshold iteration of ErrorCorrection (:793-842):
     // `s` = the strong threshold it starts with (its own, lowered to the pair's), `t0` = the weak
     // one ("trust").  If no k-mer of the read lies below t0 (v[0] >= t0 >= 2, which also means
-    // every window is in the table: no letter outside ACGT, no poly-A mask) and more than half of
-    // the k-mers reach s, the function's result is known without running it:
-    //  * more than ceil(kcnt/2) trusted k-mers cannot avoid two adjacent ones, so a real island
-    //    exists (:870-931), no boundary is moved (:934-965 needs a count < trust) and every
-    //    segment has its anchor k-mer inside the read (:1140-1154);
+    // every window is in the table: no letter outside ACGT, no poly-A mask) and two adjacent k-mers
+    // are trusted (count >= s, not poly-A at 2), the function's result is known without running it:
+    //  * two adjacent trusted k-mers are a real island (:870-931: a run of >= 2; no fall-back island, :1002-1007),
+    //    no boundary is moved (:934-965 needs a count < trust) and every segment has its anchor k-mer
+    //    inside the read (:1140-1154).  [Rounds 2-3 asked for "more than ceil(kcnt/2) k-mers reach s", which
+    //    implies the adjacency but fails for every read with an odd number of k-mers whose s is the median
+    //    of its counts without a tie -- 151-base reads at k = 23: 4.6 % of the reads of a batch went to
+    //    k_correct for nothing; the mask is the one the k_single candidates are found from anyway];
     //  * in every segment search the keep-base child is taken at every node, because its count is
     //    a count of the unchanged read, >= t0 >= the node's threshold (InferPosThreshold never
     //    returns more than the threshold handed down, :165-172); the zero-fix path ends first
@@ -288,7 +291,30 @@ __device__ __forceinline__ int rcq_threshold_row(const rc_kernel_args &A, uint32
         int n_below = 0;  // k-mers with count < s
 #pragma unroll
         for (int e = 0; e < E_CNT; ++e) n_below += __popc(row_bits(__ballot(x[e] < s), row));
-        const bool clean = !screened && v0 >= t0 && kcnt - n_below > (kcnt + 1) / 2;
+        // the trusted mask ErrorCorrection builds its islands from (:870-931): counts[g] >= s && !IsPolyA(g, 2), bit g % 16 of
+        // word g / 16; `adj` = it has two adjacent 1-bits, i.e. a real island (a run of >= 2 trusted k-mers) exists
+        constexpr int NTB = 4 * ((E_CNT + 3) / 4);
+        uint32_t tb[NTB];
+        int y[E_CNT];  // the real (unmasked, unsorted) counts
+        int rmin = 2147483647, rmax = 0;
+#pragma unroll
+        for (int e = 0; e < NTB; ++e) tb[e] = 0;
+        uint32_t adj_bits = 0;
+#pragma unroll
+        for (int e = 0; e < E_CNT; ++e) {
+            const int g = e * 16 + l;
+            const uint32_t shf = (uint32_t)((e & 1) * 16 + l);
+            const int na = __popc(__builtin_amdgcn_alignbit(ma[(e >> 1) + 1], ma[e >> 1], shf) & kmask);
+            const int nt = __popc(__builtin_amdgcn_alignbit(mt[(e >> 1) + 1], mt[e >> 1], shf) & kmask);
+            y[e] = g < kcnt ? count_at(g) : 2147483647;
+            rmin = y[e] < rmin ? y[e] : rmin;
+            rmax = g < kcnt && y[e] > rmax ? y[e] : rmax;
+            tb[e] = row_bits(__ballot(g < kcnt && y[e] >= s && na < k - 2 && nt < k - 2), row);
+            adj_bits |= tb[e] & (tb[e] >> 1);
+            if (e > 0) adj_bits |= (tb[e - 1] >> 15) & tb[e];
+        }
+        const bool adj = adj_bits != 0;
+        const bool clean = !screened && v0 >= t0 && adj;
         const int im = kcnt >> 1, ih = kcnt > 0 ? kcnt - 1 : 0;
         int sm = x[0], sh = x[0];
 #pragma unroll
@@ -302,26 +328,16 @@ __device__ __forceinline__ int rcq_threshold_row(const rc_kernel_args &A, uint32
         // The same on the REAL counts.  The sorted array hides the windows the threshold scan masks as poly-A (:1530-1541:
         // >= k - max(7, k/2) A's or T's -- one read in eight has such a window), so v0 < 0 for a read that is clean in every
         // other respect.  ErrorCorrection itself never looks at that mask (its own, :870-931, asks for >= k - 2): if every
-        // real count reaches t0 and more than half of the k-mers reach s even with the masked ones left out (n_below counts
-        // them as below), the argument above holds word for word.  l / m / h of the real counts: two row reductions and a
+        // real count reaches t0 and its own mask has two adjacent trusted k-mers, the argument above holds word for word.  l / m / h of the real counts: two row reductions and a
         // descent over the bits of the largest count for the element of rank kcnt / 2 (no second sort).
         bool clean2 = false;
         {
-            int y[E_CNT];
-            int rmin = 2147483647, rmax = 0;
-#pragma unroll
-            for (int e = 0; e < E_CNT; ++e) {
-                const int g = e * 16 + l;
-                y[e] = g < kcnt ? count_at(g) : 2147483647;
-                rmin = y[e] < rmin ? y[e] : rmin;
-                rmax = g < kcnt && y[e] > rmax ? y[e] : rmax;
-            }
             int q;
             q = row_xor<1>(rmin); rmin = q < rmin ? q : rmin;
             q = row_xor<2>(rmin); rmin = q < rmin ? q : rmin;
             q = row_xor<4>(rmin); rmin = q < rmin ? q : rmin;
             q = row_xor<8>(rmin); rmin = q < rmin ? q : rmin;
-            clean2 = !clean && !screened && kcnt > 0 && rmin >= t0 && kcnt - n_below > (kcnt + 1) / 2;
+            clean2 = !clean && !screened && kcnt > 0 && rmin >= t0 && adj;
             if (__ballot(clean2)) {  // (wave-uniform)
                 q = row_xor<1>(rmax); rmax = q > rmax ? q : rmax;
                 q = row_xor<2>(rmax); rmax = q > rmax ? q : rmax;
@@ -361,20 +377,10 @@ __device__ __forceinline__ int rcq_threshold_row(const rc_kernel_args &A, uint32
             int cand_runs = 1;  // 0-runs of a candidate = segments k_single will walk: its work list is grouped by that number
             if constexpr (E_CNT <= 12) {
                 constexpr int NW = (E_CNT + 3) / 4;  // 64-bit words of the mask
-                uint32_t other = 0, tb[4 * NW];
+                static_assert(4 * NW == NTB, "the trusted mask above");
+                uint32_t other = 0;
 #pragma unroll
                 for (int e = 0; e < E_BASE; ++e) other |= row_bits(__ballot(code[e] >= 4 && e * 16 + l < len), row);
-#pragma unroll
-                for (int e = 0; e < 4 * NW; ++e) tb[e] = 0;
-#pragma unroll
-                for (int e = 0; e < E_CNT; ++e) {
-                    const int g = e * 16 + l;
-                    const uint32_t shf = (uint32_t)((e & 1) * 16 + l);
-                    const int na = __popc(__builtin_amdgcn_alignbit(ma[(e >> 1) + 1], ma[e >> 1], shf) & kmask);
-                    const int nt = __popc(__builtin_amdgcn_alignbit(mt[(e >> 1) + 1], mt[e >> 1], shf) & kmask);
-                    const int cg = g < kcnt ? count_at(g) : 0;
-                    tb[e] = row_bits(__ballot(g < kcnt && cg >= s && na < k - 2 && nt < k - 2), row);
-                }
                 if (!clean && !clean2 && !screened && other == 0 && kcnt >= 5) {
                     // T = the trusted mask, Z = its zero bits inside [0, kcnt); shifts run over the NW-word number
                     uint64_t T[NW], Z[NW], S[NW], E[NW];

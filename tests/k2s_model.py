@@ -52,7 +52,8 @@ def finished_early(P, T, seq, k, mfk, strong0, info0, pair_t, allow_double=False
     t = trust
     pa2 = polya(seq, k, 2)
     Tm = (counts >= strong) & ~pa2
-    if counts.min() >= t and int(Tm.sum()) > (kc + 1) // 2:      # condition (0): nothing to correct
+    if counts.min() >= t and bool((Tm[:-1] & Tm[1:]).any()):     # condition (0): nothing to correct -- a real island (two
+        # adjacent trusted k-mers, ErrorCorrection.cpp:870-931) and no count below the weak threshold
         v = np.sort(np.where(counts == 0, 1, counts))
         return 0, bytes(seq), int(v[0]), int(v[len(v) // 2]), int(v[-1])
     d_ = np.diff(np.concatenate([[0], Tm.astype(np.int8), [0]]))

@@ -24,7 +24,7 @@ def _reads(d, want, oracle):
 
 
 @pytest.mark.parametrize("double", [False, True], ids=["as_built", "with_class_D"])
-@pytest.mark.parametrize("name", ["se_k23", "pe_k23", "il_k23", "skew", "k11", "k32", "varlen", "polya_k23", "pe_151", "pe_160_k15"])
+@pytest.mark.parametrize("name", ["se_k23", "pe_k23", "il_k23", "skew", "k11", "k32", "varlen", "polya_k23", "pe_151", "pe_160_k15", "se_151", "k31_mc8", "nrich", "pe_var", "k15"])
 def test_model_of_the_early_finish_agrees_with_the_oracle(oracle, name, double):
     d = datasets.make(name)
     k, mfk = d["k"], d["mfk"]
@@ -44,6 +44,7 @@ def test_model_of_the_early_finish_agrees_with_the_oracle(oracle, name, double):
         accepted += 1
         changed += r[0] > 0
         assert r == (int(ret[i]), out[i], int(l[i]), int(m[i]), int(h[i])), "read %d of %s" % (i, name)
-    assert accepted > 0.05 * len(seqs), (name, accepted)     # the model is not vacuous on any of these sets
+    if name not in ("k31_mc8", "nrich", "pe_var"):   # (5 % errors, N-rich, 3 % errors: few reads finish early there)
+        assert accepted > 0.05 * len(seqs), (name, accepted)     # the model is not vacuous on any of these sets
     if name in ("skew", "k11", "pe_k23"):
         assert changed > 0.02 * len(seqs), (name, changed)
