@@ -387,8 +387,16 @@ int rc_launch_threshold(rc_ctx *ctx, const rc_device_batch_args &a, bool classif
             ctx->cand_ready = true;
         }
     }
+    dim3 qgrid((a.n + 15) / 16), qblock(256);
+    if (quarter && a.tier_list && A.cls) {
+        // list-driven pass of a tier: only its reads are touched, so the classes of the other tiers' reads (the passes
+        // before this one left them there) are cleared first -- the compaction below reads the whole array
+        RC_CHECK_HIP(ctx, hipMemsetAsync(A.cls, 0, a.n, ctx->stream));
+        A.worklist = a.tier_list;
+        A.n_work = a.tier_n;
+        if (qgrid.x > (unsigned)ctx->n_cu * 64u) qgrid.x = (unsigned)ctx->n_cu * 64u;
+    }
     rc_timer_begin(ctx);
-    const dim3 qgrid((a.n + 15) / 16), qblock(256);
     if (quarter && ec == 8) {
         hipLaunchKernelGGL((k_threshold_q<8, 10>), qgrid, qblock, 0, ctx->stream, A);
     } else if (quarter && ec == 9) {

@@ -110,6 +110,8 @@ struct rc_ctx {
     rc_dbuf worklist; // RC_WORK_CLASSES sections of work_stride uint32 each: the reads with cls == 4, 3, 2, 1, ascending within a section
     rc_dbuf sel_tmp;  // rocPRIM scratch of the compaction
     rc_dbuf loc_a, loc_list;  // locality order of a batch (rc_launch_locality_order)
+    rc_dbuf tier_flag, tier_list;  // mixed-length batches: the reads of the middle / long tier in locality order (rc_launch_tier_lists)
+    size_t tier_stride = 0;        // uint32 entries between the two sections of tier_list
     bool env_no_fuse = false;  // RC_NO_FUSE=1 (dev): separate probe and threshold kernels in locality order too
     int env_force_ec = 0;      // RC_FORCE_EC=9|10 (dev / tests): at least this many count registers per lane in the 160-base instances
     bool env_no_tier = false;  // RC_NO_TIER=1 (dev / tests): no length tiers, the longest read of a batch decides every kernel
@@ -158,6 +160,9 @@ int rc_launch_last_base_variants(rc_ctx *ctx, const uint64_t *d_codes, size_t n,
 int rc_launch_digest(rc_ctx *ctx, unsigned long long *d_out);
 int rc_launch_locality_order(rc_ctx *ctx, const struct rc_device_batch_args &a, size_t nbytes);
 int rc_launch_probe_list(rc_ctx *ctx, const struct rc_device_batch_args &a, size_t nbytes, int32_t *d_counts, int skip_hi = -1);
+int rc_launch_tier_lists(rc_ctx *ctx, const struct rc_device_batch_args &a, int s_hi, int m_hi);
+// K1 over section `section` (0: middle tier, 1: long tier) of ctx->tier_list; a.max_len = the longest read of that tier
+int rc_launch_probe_tier(rc_ctx *ctx, const struct rc_device_batch_args &a, size_t nbytes, int32_t *d_counts, int section);
 int rc_launch_compact(rc_ctx *ctx, const uint8_t *d_cls, uint32_t n, uint32_t *d_list, size_t stride, uint32_t *d_count);
 int rc_launch_compact_flag(rc_ctx *ctx, const uint8_t *d_flag, uint32_t n, uint32_t *d_list, size_t stride, uint32_t *d_count);
 
@@ -177,6 +182,9 @@ struct rc_device_batch_args {
     int max_len;         // longest read in the batch (bases)
     int tier_lo = -1, tier_hi = RC_TIER_ALL;  // length tier of this pass (rc_kernel_args::tier_lo / tier_hi)
     int pair_override = -1;                   // rc_kernel_args::pair_override
+    // the tier's reads as a list in locality order and its length on the device (rc_launch_tier_lists), or nullptr: the
+    // threshold kernel of the pass then walks the whole batch and leaves the other tiers' reads out
+    const uint32_t *tier_list = nullptr, *tier_n = nullptr;
 };
 int rc_launch_threshold(rc_ctx *ctx, const rc_device_batch_args &a, bool classify);
 int rc_launch_correct(rc_ctx *ctx, const rc_device_batch_args &a);
@@ -193,6 +201,7 @@ int rc_launch_kmer_info(rc_ctx *ctx, const rc_device_batch_args &a);
 // then the lengths of the work-list sections, then the phase counters of PROF builds
 #define RC_WORK_BYTES 5120
 #define RC_WORK_NWORK_OFF 4096
-#define RC_WORK_NSINGLE_OFF 4160  // 4 x uint32: length of k_single's list, 0, 0, 0 (it reads it like the four section lengths)
+#define RC_WORK_NSINGLE_OFF 4160  // 4 x uint32: lengths of the three sections of k_single's list, 0 (it reads them like the four section lengths)
+#define RC_WORK_NTIER_OFF 4192    // 2 x uint32: reads of the middle / long length tier (rc_launch_tier_lists)
 #define RC_WORK_PHASE_OFF 4224
 #define RC_WORK_SUMMARY_OFF 4608  // 2 x uint64: reads, corrected bases (never reset)

@@ -457,6 +457,25 @@ template <int E_CNT, int E_BASE>
 __global__ __launch_bounds__(256) void k_threshold_q(rc_kernel_args A)
 {
     const int row = (threadIdx.x & 63) >> 4;
+    if (A.worklist) {
+        // the pass of a length tier over its list (rc_launch_tier_lists: the tier's reads in locality order, the mates of a
+        // pair adjacent -- rows 2j and 2j+1 again); the list's length lives on the device, a fixed grid walks it
+        const uint32_t n_list = *A.n_work;
+        for (uint32_t wv = (uint32_t)blockIdx.x * 4u + (threadIdx.x >> 6); wv * 4u < n_list; wv += gridDim.x * 4u) {
+            const uint32_t i = wv * 4u + (uint32_t)row;
+            const bool live = i < n_list;
+            const uint32_t r = live ? A.worklist[i] : 0u;
+            uint32_t o = 0;
+            int len = 0;
+            if (live) {
+                o = A.off[r];
+                len = (int)(A.off[r + 1] - o) - 1;
+            }
+            rcq_threshold_row<E_CNT, E_BASE>(
+                A, r, live, len, [&](int p) { return (uint32_t)A.seq[o + p]; }, [&](int g) { return A.counts[o + g]; });
+        }
+        return;
+    }
     // rows 2j and 2j+1 of a wave hold the two mates of a pair (paired: reads u and n/2 + u;
     // interleaved: reads 2u and 2u+1), so the pair threshold is one lane exchange away
     const uint32_t wv = (uint32_t)blockIdx.x * 4u + (threadIdx.x >> 6);

@@ -470,40 +470,105 @@ int rc_launch_selftest_bound(rc_ctx *ctx, const int32_t *d_c, size_t n, double e
     return RC_OK;
 }
 
-// section c (0 .. RC_WORK_CLASSES-1) of d_list, at d_list + c * stride = the indices i in [0, n) with
-// d_cls[i] == RC_WORK_CLASSES - c, ascending; d_count[c] = how many
-struct rc_cls_is {
-    uint8_t v;
-    __host__ __device__ bool operator()(uint8_t c) const { return c == v; }
-};
-int rc_launch_compact(rc_ctx *ctx, const uint8_t *d_cls, uint32_t n, uint32_t *d_list, size_t stride, uint32_t *d_count)
+// Work lists by flag value, in one pass: section c (0 .. NS-1) of d_list, at d_list + c * stride, receives the indices
+// i in [0, n) with d_flag[i] == first + c * step; d_count[c] = how many.  A 256-thread workgroup takes 4096 flags (16 per
+// thread, one 16-byte load), scans its per-section counts (four 16-bit fields of one 64-bit word) and claims its stretch
+// of every section with one atomic per section.  Within a section the indices ascend inside a workgroup's stretch; the
+// stretches themselves land in the order the workgroups got there -- nothing downstream depends on the order of a list
+// (a read's result depends on its unit alone), only on which section a read is in.  [Rounds 2-3 ran one rocprim::select
+// per section: 7 passes of ~0.24 ms over a batch's flags per step, each with its own lookback-scan initialisation.]
+// values != nullptr: the lists receive values[i] instead of i (the length-tier lists: i = a position of the locality order,
+// values[i] = the read there)
+template <int NS>
+__global__ __launch_bounds__(256) void k_compact_sections(const uint8_t *__restrict__ flag, uint32_t n, int first, int step,
+                                                          uint32_t *__restrict__ list, size_t stride, uint32_t *__restrict__ count,
+                                                          const uint32_t *__restrict__ values)
 {
-    rocprim::counting_iterator<uint32_t> ids(0);
-    for (int c = 0; c < RC_WORK_CLASSES; ++c) {
-        auto flags = rocprim::make_transform_iterator(d_cls, rc_cls_is{(uint8_t)(RC_WORK_CLASSES - c)});
-        size_t tmp = 0;
-        RC_CHECK_HIP(ctx, rocprim::select(nullptr, tmp, ids, flags, d_list + c * stride, d_count + c, (size_t)n, ctx->stream));
-        int rc = rc_dbuf_reserve(ctx, &ctx->sel_tmp, tmp);
-        if (rc) return rc;
-        RC_CHECK_HIP(ctx, rocprim::select(ctx->sel_tmp.p, tmp, ids, flags, d_list + c * stride, d_count + c, (size_t)n, ctx->stream));
+    static_assert(NS >= 1 && NS <= 4, "four 16-bit fields");
+    __shared__ uint64_t s_wave[4];
+    __shared__ uint32_t s_base[NS];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    for (uint32_t b0 = blockIdx.x * 4096u; b0 < n; b0 += gridDim.x * 4096u) {
+        const uint32_t i0 = b0 + t * 16u;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (i0 < n) v = *reinterpret_cast<const uint4 *>(flag + i0);  // (the flag arrays are reserved with 256 bytes of slack)
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        uint64_t mine = 0;  // field c = how many of this thread's flags belong to section c
+        if (i0 < n && (v.x | v.y | v.z | v.w)) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int f = (int)((w[q >> 2] >> (8 * (q & 3))) & 0xffu);
+                if (i0 + q < n && f) {
+#pragma unroll
+                    for (int c = 0; c < NS; ++c) mine += f == first + c * step ? (1ull << (16 * c)) : 0ull;
+                }
+            }
+        }
+        // exclusive scan over the workgroup
+        uint64_t inc = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint64_t y = __shfl_up(inc, o, 64);
+            inc += lane >= (uint32_t)o ? y : 0ull;
+        }
+        if (lane == 63) s_wave[wave] = inc;
+        __syncthreads();
+        uint64_t before = 0, total = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            before += (uint32_t)q < wave ? s_wave[q] : 0ull;
+            total += s_wave[q];
+        }
+        if (total) {  // (uniform)
+            if (t < (uint32_t)NS) {
+                const uint32_t c = (uint32_t)((total >> (16 * t)) & 0xffffu);
+                s_base[t] = c ? atomicAdd(count + t, c) : 0u;
+            }
+            __syncthreads();
+            if (mine) {
+                const uint64_t ex = before + inc - mine;
+                uint32_t pos[NS];
+#pragma unroll
+                for (int c = 0; c < NS; ++c) pos[c] = s_base[c] + (uint32_t)((ex >> (16 * c)) & 0xffffu);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int f = (int)((w[q >> 2] >> (8 * (q & 3))) & 0xffu);
+                    if (i0 + q < n && f) {
+#pragma unroll
+                        for (int c = 0; c < NS; ++c)
+                            if (f == first + c * step) list[(size_t)c * stride + pos[c]++] = values ? values[i0 + (uint32_t)q] : i0 + (uint32_t)q;
+                    }
+                }
+            }
+        }
+        __syncthreads();  // s_wave / s_base are rewritten by the next stretch
     }
+}
+
+template <int NS>
+static int rc_compact_sections(rc_ctx *ctx, const uint8_t *d_flag, uint32_t n, int first, int step, uint32_t *d_list, size_t stride, uint32_t *d_count,
+                               const uint32_t *d_values = nullptr)
+{
+    RC_CHECK_HIP(ctx, hipMemsetAsync(d_count, 0, NS * sizeof(uint32_t), ctx->stream));
+    if (n == 0) return RC_OK;
+    unsigned grid = (n + 4095u) / 4096u;
+    if (grid > (unsigned)ctx->n_cu * 32u) grid = (unsigned)ctx->n_cu * 32u;
+    hipLaunchKernelGGL(k_compact_sections<NS>, dim3(grid), dim3(256), 0, ctx->stream, d_flag, n, first, step, d_list, stride, d_count, d_values);
+    RC_CHECK_HIP(ctx, hipGetLastError());
     return RC_OK;
 }
 
-// section v - 1 (v = 1 .. 3) of d_list, at d_list + (v - 1) * stride = the indices i in [0, n) with d_flag[i] == v,
-// ascending; d_count[v - 1] = how many
+// section c (0 .. RC_WORK_CLASSES-1) of d_list = the reads with d_cls[i] == RC_WORK_CLASSES - c (k_correct's list: the
+// classes expected to be expensive first)
+int rc_launch_compact(rc_ctx *ctx, const uint8_t *d_cls, uint32_t n, uint32_t *d_list, size_t stride, uint32_t *d_count)
+{
+    return rc_compact_sections<RC_WORK_CLASSES>(ctx, d_cls, n, RC_WORK_CLASSES, -1, d_list, stride, d_count);
+}
+
+// section v - 1 (v = 1 .. 3) of d_list = the reads with d_flag[i] == v (k_single's list: by number of untrusted stretches)
 int rc_launch_compact_flag(rc_ctx *ctx, const uint8_t *d_flag, uint32_t n, uint32_t *d_list, size_t stride, uint32_t *d_count)
 {
-    rocprim::counting_iterator<uint32_t> ids(0);
-    for (int v = 1; v <= 3; ++v) {
-        auto flags = rocprim::make_transform_iterator(d_flag, rc_cls_is{(uint8_t)v});
-        size_t tmp = 0;
-        RC_CHECK_HIP(ctx, rocprim::select(nullptr, tmp, ids, flags, d_list + (v - 1) * stride, d_count + (v - 1), (size_t)n, ctx->stream));
-        int rc = rc_dbuf_reserve(ctx, &ctx->sel_tmp, tmp);
-        if (rc) return rc;
-        RC_CHECK_HIP(ctx, rocprim::select(ctx->sel_tmp.p, tmp, ids, flags, d_list + (v - 1) * stride, d_count + (v - 1), (size_t)n, ctx->stream));
-    }
-    return RC_OK;
+    return rc_compact_sections<3>(ctx, d_flag, n, 1, 1, d_list, stride, d_count);
 }
 
 // ---- locality order of a batch -------------------------------------------------------------------
@@ -601,6 +666,40 @@ int rc_launch_locality_order(rc_ctx *ctx, const rc_device_batch_args &a, size_t 
     return RC_OK;
 }
 
+// Length tiers of a mixed-length batch (rc_api.hip: correct_device_impl): flag of list position i = 0 if the unit of the read
+// there -- the read, or the pair it is a mate of -- belongs to the short tier (its longer read has at most s_hi bases), 1 for
+// the middle tier (at most m_hi), 2 for the long one.  Compacted, the positions of a tier give the reads of that tier in
+// locality order, mates still adjacent: what the list-driven probe and threshold kernels of the tier's pass walk.
+__global__ __launch_bounds__(256) void k_tier_flags(const uint32_t *__restrict__ off, const uint32_t *__restrict__ list, uint32_t n, int mode,
+                                                    int s_hi, int m_hi, uint8_t *__restrict__ flag)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t r = list[i];
+    int ml = (int)(off[r + 1] - off[r]) - 1;
+    if (mode != 0) {
+        const uint32_t half = n >> 1, mr = mode == 1 ? (r < half ? r + half : r - half) : (r ^ 1u);
+        const int m1 = (int)(off[mr + 1] - off[mr]) - 1;
+        ml = m1 > ml ? m1 : ml;
+    }
+    flag[i] = ml <= s_hi ? 0 : (ml <= m_hi ? 1 : 2);
+}
+
+// ctx->tier_list: two sections of `stride` entries (middle tier, long tier), their lengths at work + RC_WORK_NTIER_OFF
+int rc_launch_tier_lists(rc_ctx *ctx, const rc_device_batch_args &a, int s_hi, int m_hi)
+{
+    int rc;
+    const size_t stride = ((size_t)a.n + 63) & ~(size_t)63;
+    if ((rc = rc_dbuf_reserve(ctx, &ctx->tier_flag, (size_t)a.n + 256))) return rc;
+    if ((rc = rc_dbuf_reserve(ctx, &ctx->tier_list, stride * 2 * 4 + 256))) return rc;
+    ctx->tier_stride = stride;
+    hipLaunchKernelGGL(k_tier_flags, dim3((a.n + 255) / 256), dim3(256), 0, ctx->stream, a.off, (const uint32_t *)ctx->loc_list.p, a.n, a.mode, s_hi, m_hi,
+                       (uint8_t *)ctx->tier_flag.p);
+    RC_CHECK_HIP(ctx, hipGetLastError());
+    return rc_compact_sections<2>(ctx, (const uint8_t *)ctx->tier_flag.p, a.n, 1, 1, (uint32_t *)ctx->tier_list.p, stride,
+                                  (uint32_t *)((char *)ctx->work.p + RC_WORK_NTIER_OFF), (const uint32_t *)ctx->loc_list.p);
+}
+
 // ---- K1: probe kernel ----------------------------------------------------------------------
 // counts[a] = GetCount(k-mer starting at arena byte a) for every a whose k-window lies inside one
 // read (reads are NUL-terminated inside the arena, so "inside one read" == "no NUL in the
@@ -671,7 +770,7 @@ template <bool EXT>
 __global__ __launch_bounds__(RC_PROBE_THREADS) void k_probe_list(rc_table_view T, const uint8_t *__restrict__ seq, size_t nbytes,
                                                                  const uint32_t *__restrict__ off, const uint32_t *__restrict__ list,
                                                                  uint32_t n, uint32_t reads_per_block, int k, int32_t *__restrict__ counts,
-                                                                 int mode, int skip_hi)
+                                                                 int mode, int skip_hi, const uint32_t *__restrict__ n_list)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_raw[(RC_PROBE_TILE + 64) / 4];
     __shared__ uint32_t s_code[RC_PROBE_TILE / 16 + 4];
@@ -679,9 +778,11 @@ __global__ __launch_bounds__(RC_PROBE_THREADS) void k_probe_list(rc_table_view T
     __shared__ uint16_t s_nul[RC_PROBE_TILE / 16 + 4];
     __shared__ uint32_t s_lpos[RC_PLIST_MAX_READS + 1], s_gpos[RC_PLIST_MAX_READS], s_len1[RC_PLIST_MAX_READS];
     const int t = threadIdx.x;
-    const uint32_t i0 = blockIdx.x * reads_per_block;
-    const uint32_t nr = n - i0 < reads_per_block ? n - i0 : reads_per_block;
-    for (int c = t; c < (RC_PROBE_TILE + 64) / 4; c += RC_PROBE_THREADS) s_raw[c] = 0;
+    // n_list != nullptr: `list` is a tier's list whose length lives on the device (rc_launch_tier_lists); a fixed grid walks it
+    const uint32_t n_eff = n_list ? *n_list : n;
+    for (uint32_t i0 = blockIdx.x * reads_per_block; i0 < n_eff; i0 += gridDim.x * reads_per_block) {
+    const uint32_t nr = n_eff - i0 < reads_per_block ? n_eff - i0 : reads_per_block;
+    bool any_live = false;
     if ((uint32_t)t < nr) {
         const uint32_t r = list[i0 + t], g0 = off[r];
         uint32_t len1 = off[r + 1] - g0;  // bases + the NUL
@@ -696,8 +797,11 @@ __global__ __launch_bounds__(RC_PROBE_THREADS) void k_probe_list(rc_table_view T
         }
         s_gpos[t] = g0;
         s_len1[t] = len1;
+        any_live = len1 != 0;
     }
-    __syncthreads();
+    // (a mixed-length batch's short reads were probed by the fused kernel: most workgroups of this launch hold none)
+    if (!__syncthreads_or(any_live)) continue;
+    for (int c = t; c < (RC_PROBE_TILE + 64) / 4; c += RC_PROBE_THREADS) s_raw[c] = 0;
     if (t == 0) {  // local start of each read: same alignment modulo 4 as in memory, a NUL in front
         uint32_t lp = 4;
         for (uint32_t j = 0; j < nr; ++j) {
@@ -766,6 +870,8 @@ __global__ __launch_bounds__(RC_PROBE_THREADS) void k_probe_list(rc_table_view T
         }
         __builtin_nontemporal_store(cnt, &counts[s_gpos[lo] + (a - s_lpos[lo])]);
     }
+    __syncthreads();  // (the next stretch of the list rewrites the tile)
+    }
 }
 
 int rc_launch_probe_list(rc_ctx *ctx, const rc_device_batch_args &a, size_t nbytes, int32_t *d_counts, int skip_hi)
@@ -781,10 +887,32 @@ int rc_launch_probe_list(rc_ctx *ctx, const rc_device_batch_args &a, size_t nbyt
     rc_timer_begin(ctx);
     if (ctx->ext)
         hipLaunchKernelGGL(k_probe_list<true>, dim3((a.n + rpb - 1) / rpb), dim3(RC_PROBE_THREADS), 0, ctx->stream, rc_view(ctx), a.seq, nbytes, a.off,
-                           (const uint32_t *)ctx->loc_list.p, a.n, rpb, ctx->k, d_counts, a.mode, skip_hi);
+                           (const uint32_t *)ctx->loc_list.p, a.n, rpb, ctx->k, d_counts, a.mode, skip_hi, (const uint32_t *)nullptr);
     else
         hipLaunchKernelGGL(k_probe_list<false>, dim3((a.n + rpb - 1) / rpb), dim3(RC_PROBE_THREADS), 0, ctx->stream, rc_view(ctx), a.seq, nbytes, a.off,
-                           (const uint32_t *)ctx->loc_list.p, a.n, rpb, ctx->k, d_counts, a.mode, skip_hi);
+                           (const uint32_t *)ctx->loc_list.p, a.n, rpb, ctx->k, d_counts, a.mode, skip_hi, (const uint32_t *)nullptr);
+    rc_timer_end(ctx, RC_T_PROBE);
+    RC_CHECK_HIP(ctx, hipGetLastError());
+    return RC_OK;
+}
+
+int rc_launch_probe_tier(rc_ctx *ctx, const rc_device_batch_args &a, size_t nbytes, int32_t *d_counts, int section)
+{
+    if (a.n == 0) return RC_OK;
+    uint32_t rpb = (uint32_t)((RC_PROBE_TILE - 8) / (a.max_len + 8));
+    if (rpb > RC_PLIST_MAX_READS) rpb = RC_PLIST_MAX_READS;
+    if (rpb < 1) rpb = 1;
+    const uint32_t *list = (const uint32_t *)ctx->tier_list.p + (size_t)section * ctx->tier_stride;
+    const uint32_t *n_list = (const uint32_t *)((char *)ctx->work.p + RC_WORK_NTIER_OFF) + section;
+    unsigned grid = (a.n + rpb - 1) / rpb;  // (at most: the tier's share of the batch is not known here)
+    if (grid > (unsigned)ctx->n_cu * 16u) grid = (unsigned)ctx->n_cu * 16u;
+    rc_timer_begin(ctx);
+    if (ctx->ext)
+        hipLaunchKernelGGL(k_probe_list<true>, dim3(grid), dim3(RC_PROBE_THREADS), 0, ctx->stream, rc_view(ctx), a.seq, nbytes, a.off, list, a.n, rpb, ctx->k,
+                           d_counts, a.mode, -1, n_list);
+    else
+        hipLaunchKernelGGL(k_probe_list<false>, dim3(grid), dim3(RC_PROBE_THREADS), 0, ctx->stream, rc_view(ctx), a.seq, nbytes, a.off, list, a.n, rpb, ctx->k,
+                           d_counts, a.mode, -1, n_list);
     rc_timer_end(ctx, RC_T_PROBE);
     RC_CHECK_HIP(ctx, hipGetLastError());
     return RC_OK;
