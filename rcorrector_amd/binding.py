@@ -96,6 +96,8 @@ def load_library():
     L.rc_table_write_jfdump.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64)]
     L.rc_table_share.argtypes = [vp, vp]
     L.rc_table_replicate.argtypes = [vp, vp]
+    L.rc_table_replicate_async.argtypes = [vp, vp]
+    L.rc_device_numa_node.argtypes = [vp]
     L.rc_table_lookup.argtypes = [vp, vp, sz, vp]
     L.rc_table_export.argtypes = [vp, vp, vp, sz, C.POINTER(C.c_size_t)]
     L.rc_table_digest.argtypes = [vp, C.POINTER(C.c_uint64)]
@@ -244,6 +246,15 @@ class Context:
     def replicate_table_of(self, other):
         """An own copy of `other`'s table, device to device (rc_table_replicate)."""
         self._ck(self._L.rc_table_replicate(self._h, other._h))
+
+    def replicate_table_of_async(self, other):
+        """The same with the copy left in flight on this context's stream (sync() waits for it): queue the copies to all
+        GPUs of a node first, they travel at the same time (rc_table_replicate_async)."""
+        self._ck(self._L.rc_table_replicate_async(self._h, other._h))
+
+    def numa_node(self):
+        """NUMA node of the host this context's GPU hangs off, -1 if the system does not say (rc_device_numa_node)."""
+        return int(self._L.rc_device_numa_node(self._h))
 
     def lookup(self, codes):
         codes = np.ascontiguousarray(codes, dtype=np.uint64)

@@ -414,6 +414,78 @@ def test_bench_eight_ranks_on_one_gpu():
     assert d["n_gpus"] == 8 and d["scaling"] == "weak" and "x8" in d["config"]["parallelism"]
     assert abs(d["value"] - 8 * 100000 / (d["ms_per_step"] / 1e3)) / d["value"] < 1e-6
     assert d["config"]["table_replicas_identical"] is True and 0.2 < d["config"]["reads_corrected_frac"] < 0.9
+    mg = d["multi_gpu"]   # what the driver reads to see that the collectives saw eight ranks
+    assert mg["world_size_seen"] == 8 and mg["collective_backend"] == "gloo" and len(mg["ranks"]) == 8
+    assert [r["rank"] for r in mg["ranks"]] == list(range(8)) and all(r["device"] == 0 for r in mg["ranks"])
+    assert mg["ms_per_step_min"] <= mg["ms_per_step_max"] <= d["ms_per_step"] * 1.001
+
+
+def _bench_json(args, env=None, timeout=900, launcher=None):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable] + (launcher or []) + [os.path.join(root, "bench.py")] + args
+    p = subprocess.run(cmd, cwd=root, env=dict(os.environ, **(env or {})), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_in_process_contexts_replicate_the_table(tmp_path):
+    """`bench.py --in-process --gpus 3`: the `rcorrector -gpus N` shape -- one process, a context and a host thread per
+    GPU, the table counted once and replicated with all copies in flight (rc_table_replicate_async), digests compared.
+    Here all three contexts sit on GPU 0 (RC_BENCH_SHARED_GPU=1); the same single-GPU run must find the same reads to
+    correct in shard 0 (results do not depend on how many contexts share the work)."""
+    args = ["--steps", "2", "--warmup", "1", "--reads", "300000", "--n-tx", "1500"]
+    d = _bench_json(["--in-process", "--gpus", "3"] + args, env={"RC_BENCH_SHARED_GPU": "1"})
+    mg = d["multi_gpu"]
+    assert d["n_gpus"] == 3 and mg["world_size_seen"] == 3 and len(mg["ranks"]) == 3 and mg["table_replicas_identical"] is True
+    assert len(set(mg["table_digests"])) == 1 and mg["table_replicate_s"] > 0
+    assert abs(d["value"] - 3 * 300000 * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 1e-6
+    one = _bench_json(["--gpus", "1", "--no-extras"] + args)
+    assert one["config"]["table_digest"] == mg["table_digests"][0] and one["config"]["table_kmers"] == d["config"]["table_kmers"]
+    assert 0.2 < d["config"]["reads_corrected_frac"] < 0.9
+
+
+@pytest.mark.gpu
+def test_two_real_gpus_when_the_box_has_them(tmp_path):
+    """Only where torch sees more than one GPU (the driver's 8-GPU node; skipped on the one-GPU boxes): bench.py under
+    torch.distributed.run with the nccl (= RCCL) backend on two devices, the in-process mode with a peer-to-peer table copy,
+    and `rcorrector -gpus 2` WITHOUT RC_SHARED_GPU -- the code paths the one-GPU suite can only run with every context on
+    device 0 (distinct devices, peer access, NUMA binding per GPU)."""
+    import socket
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    args = ["--steps", "2", "--warmup", "1", "--reads", "2000000", "--n-tx", "3000", "--cpu-sample", "0", "--no-extras"]
+    d = _bench_json(["--gpus", "2"] + args, launcher=["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                                                      "127.0.0.1", "--master-port", str(port)])
+    mg = d["multi_gpu"]
+    assert d["n_gpus"] == 2 and mg["collective_backend"] == "nccl" and mg["world_size_seen"] == 2
+    assert sorted(r["device"] for r in mg["ranks"]) == [0, 1] and d["config"]["table_replicas_identical"] is True
+    ip = _bench_json(["--in-process", "--gpus", "2"] + args)
+    assert sorted(r["device"] for r in ip["multi_gpu"]["ranks"]) == [0, 1] and len(set(ip["multi_gpu"]["table_digests"])) == 1
+    assert ip["config"]["table_kmers"] == d["config"]["table_kmers"]
+    # the CLI on two devices equals the CLI on one
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fx = os.path.join(root, "tests", "golden", "fx_pe_k23")
+    cli_args = open(os.path.join(fx, "cmd.txt")).read().split()
+    outs = []
+    for g in ("1", "2"):
+        od = tmp_path / ("g" + g)
+        p = subprocess.run([os.path.join(root, "rcorrector_amd", "rcorrector")] + cli_args + ["-od", str(od), "-gpus", g, "-batch", "64"], cwd=fx,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert p.returncode == 0, p.stderr.decode()[-2000:]
+        outs.append({f: open(os.path.join(od, f), "rb").read() for f in sorted(os.listdir(od))})
+    assert outs[0] == outs[1] and len(outs[0]) == 2
 
 
 @pytest.mark.gpu
