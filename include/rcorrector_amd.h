@@ -184,6 +184,47 @@ int rc_host_free(rc_ctx *ctx, void *p);
 int rc_host_register(void *p, size_t bytes);
 int rc_host_unregister(void *p);
 
+/* The packed boundary: what SURVEY.md section 3 gives as the device boundary of a batch -- "only packed reads go down
+ * and (fix list, ret, l, m, h) come back" -- for callers bound by the PCIe link (the byte path above moves 306 bytes up
+ * and 167 down per 150-base read, this one about 61 and 20).  The reads of a batch are described as ONE arena of
+ * `nbytes` bytes, read i the NUL-terminated string at off[i] (mode 1: the n first mates, then the n second mates;
+ * off has total + 1 entries, total = n reads of mode 0 / 2 or 2 n of mode 1); the arena itself stays with the caller:
+ *   bases     2 bits per arena byte, 16 per word: byte p at bits 30 - 2 (p & 15) of word p >> 4, A0 C1 G2 T3
+ *             (KmerCode.h:7-89's code); NULs and letters outside ACGT are 0.  (nbytes + 15) / 16 words.
+ *   exc_pos / exc_chr   the n_exc letters outside ACGT: arena position (ascending) and the letter
+ *   qual_bits one bit per arena byte as rc_pack_quality_bits() makes them, or NULL: no qualities (FASTA input,
+ *             Reads.h:224-266: the reference then sees qual[0] == 0)
+ * rc_pack_bases() makes bases / exc_* from a byte arena (callers with several threads pack ranges that start at multiples
+ * of 16 bytes side by side: range [begin, end) writes words [begin / 16, (end + 15) / 16) and its own exception list,
+ * whose positions are arena positions).  rc_submit_packed() starts the batch, rc_wait_packed() completes it: ret / l / m / h
+ * as for rc_batch, and the substitutions the correction made (ErrorCorrection.cpp:1468-1479) as n_fix pairs
+ * (fix_pos[j] = arena position, fix_chr[j] = the new letter), in no particular order -- positions are distinct, so the
+ * caller may apply them from several threads (rc_apply_fixes() is the loop).  fix_cap = room in the caller's arrays;
+ * more fixes than that is an error (a batch of N bases never has more than N).  All arrays of the descriptor should be
+ * page-locked (rc_host_alloc); others are staged through the slot's own pinned memory.
+ * The results equal rc_submit()'s on the same reads: ret / l / m / h identical, arena + fixes = the corrected arena. */
+typedef struct {
+    int mode;
+    size_t n;               /* reads per arena as in rc_batch (mode 1: pairs) */
+    uint64_t nbytes;        /* bytes of the arena (mode 1: both mates' arenas together) */
+    const uint32_t *off;    /* [total + 1] */
+    const uint32_t *bases;  /* [(nbytes + 15) / 16] */
+    const uint8_t *qual_bits; /* [(nbytes + 7) / 8] or NULL */
+    const uint32_t *exc_pos;
+    const uint8_t *exc_chr;
+    size_t n_exc;
+    int32_t *ret, *l, *m, *h; /* [total] */
+    uint32_t *fix_pos;      /* [fix_cap] */
+    uint8_t *fix_chr;       /* [fix_cap] */
+    size_t fix_cap;
+    size_t n_fix;           /* out, valid after rc_wait_packed */
+} rc_packed_batch;
+/* returns the number of exceptions found in [begin, end) (all of them are counted, the first exc_cap are stored) */
+size_t rc_pack_bases(const char *seq, size_t begin, size_t end, uint32_t *bases, uint32_t *exc_pos, uint8_t *exc_chr, size_t exc_cap);
+int rc_submit_packed(rc_ctx *ctx, rc_packed_batch *b, int slot);
+int rc_wait_packed(rc_ctx *ctx, int slot);
+void rc_apply_fixes(char *seq, const uint32_t *fix_pos, const uint8_t *fix_chr, size_t n_fix);
+
 /* rc_correct_batch plus everything the reference prints per read under -verbose (VERBOSE,
  * ErrorCorrection.cpp:15,686-689,759-770,856-857,1088-1094,1590-1597), as data; the caller formats
  * it (rc_main.cpp does, byte for byte).  Reads are indexed like ret/l/m/h (mode 1: arena 2's reads

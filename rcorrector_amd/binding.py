@@ -17,6 +17,7 @@ ABI_SYMBOLS = [
     "rc_estimate_error_rate", "rc_bad_quality_from_hist", "rc_set_run_params", "rc_set_quality_bits", "rc_pack_quality_bits",
     "rc_correct_batch", "rc_submit", "rc_wait", "rc_host_alloc", "rc_host_free", "rc_host_register", "rc_host_unregister", "rc_correct_batch_traced", "rc_correct_device", "rc_strong_threshold_device", "rc_probe_device", "rc_sync",
     "rc_strong_threshold_read", "rc_correct_read", "rc_kmer_info_read",
+    "rc_pack_bases", "rc_submit_packed", "rc_wait_packed", "rc_apply_fixes",
     "rc_profile_enable", "rc_profile_get", "rc_profile_reset", "rc_profile_correct_counters", "rc_selftest_get_bound", "rc_summary",
 ]
 
@@ -46,6 +47,14 @@ class _Batch(C.Structure):
                 ("seq", C.c_void_p), ("qual", C.c_void_p), ("off", C.c_void_p),
                 ("seq2", C.c_void_p), ("qual2", C.c_void_p), ("off2", C.c_void_p),
                 ("ret", C.c_void_p), ("l", C.c_void_p), ("m", C.c_void_p), ("h", C.c_void_p)]
+
+
+class _PackedBatch(C.Structure):
+    _fields_ = [("mode", C.c_int), ("n", C.c_size_t), ("nbytes", C.c_uint64),
+                ("off", C.c_void_p), ("bases", C.c_void_p), ("qual_bits", C.c_void_p),
+                ("exc_pos", C.c_void_p), ("exc_chr", C.c_void_p), ("n_exc", C.c_size_t),
+                ("ret", C.c_void_p), ("l", C.c_void_p), ("m", C.c_void_p), ("h", C.c_void_p),
+                ("fix_pos", C.c_void_p), ("fix_chr", C.c_void_p), ("fix_cap", C.c_size_t), ("n_fix", C.c_size_t)]
 
 
 class _DeviceBatch(C.Structure):
@@ -122,6 +131,12 @@ def load_library():
     L.rc_strong_threshold_read.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int32)]
     L.rc_correct_read.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_int32, C.POINTER(C.c_int32)]
     L.rc_kmer_info_read.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.rc_pack_bases.restype = sz
+    L.rc_pack_bases.argtypes = [vp, sz, sz, vp, vp, vp, sz]
+    L.rc_submit_packed.argtypes = [vp, C.POINTER(_PackedBatch), C.c_int]
+    L.rc_wait_packed.argtypes = [vp, C.c_int]
+    L.rc_apply_fixes.restype = None
+    L.rc_apply_fixes.argtypes = [vp, vp, vp, sz]
     L.rc_profile_enable.argtypes = [vp, C.c_int]
     L.rc_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.rc_profile_reset.argtypes = [vp]
@@ -366,6 +381,57 @@ class Context:
         self._ck(self._L.rc_wait(self._h, slot))
         res, _keep, _arr = self._inflight.pop(slot)
         return tuple(res)
+
+    # ---- the packed boundary (rc_packed_batch) ----
+    def pack_bases(self, arena, bases=None, exc_pos=None, exc_chr=None):
+        """2-bit codes + the letters outside ACGT of a byte arena (rc_pack_bases).  Returns (bases, exc_pos, exc_chr):
+        the given arrays (e.g. page-locked ones) or new ones, the exception arrays cut to their length."""
+        arena = self._arena(arena, "arena")
+        nw = (arena.size + 15) // 16
+        if bases is None:
+            bases = np.zeros(nw, dtype=np.uint32)
+        cap = 0 if exc_pos is None else len(exc_pos)
+        n = self._L.rc_pack_bases(arena.ctypes.data, 0, arena.size, bases.ctypes.data, exc_pos.ctypes.data if cap else None,
+                                  exc_chr.ctypes.data if cap else None, cap)
+        if n > cap:   # (first call without room, or too little of it)
+            exc_pos, exc_chr = np.zeros(n, dtype=np.uint32), np.zeros(n, dtype=np.uint8)
+            self._L.rc_pack_bases(arena.ctypes.data, 0, arena.size, bases.ctypes.data, exc_pos.ctypes.data, exc_chr.ctypes.data, n)
+        if exc_pos is None:
+            exc_pos, exc_chr = np.zeros(0, dtype=np.uint32), np.zeros(0, dtype=np.uint8)
+        return bases, exc_pos[:n], exc_chr[:n]
+
+    def submit_packed(self, slot, mode, nbytes, off, bases, qual_bits, exc_pos, exc_chr, res=None, fix_pos=None, fix_chr=None, fix_cap=None):
+        """rc_submit_packed: off over the whole arena (mode 1: first mates then second mates, 2 n + 1 entries).
+        wait_packed(slot) returns (ret, l, m, h, fix_pos, fix_chr)."""
+        off = np.ascontiguousarray(off, dtype=np.uint32)
+        total = len(off) - 1
+        if res is None:
+            res = [np.zeros(total, dtype=np.int32) for _ in range(4)]
+        if fix_pos is None:
+            fix_cap = int(nbytes) if fix_cap is None else fix_cap
+            fix_pos, fix_chr = np.zeros(fix_cap, dtype=np.uint32), np.zeros(fix_cap, dtype=np.uint8)
+        b = _PackedBatch()
+        b.mode, b.n, b.nbytes = mode, (total // 2 if mode == 1 else total), int(nbytes)
+        b.off, b.bases = off.ctypes.data, bases.ctypes.data
+        b.qual_bits = None if qual_bits is None else qual_bits.ctypes.data
+        b.n_exc = len(exc_pos)
+        b.exc_pos, b.exc_chr = (exc_pos.ctypes.data, exc_chr.ctypes.data) if len(exc_pos) else (None, None)
+        b.ret, b.l, b.m, b.h = (r.ctypes.data for r in res)
+        b.fix_pos, b.fix_chr, b.fix_cap = fix_pos.ctypes.data, fix_chr.ctypes.data, len(fix_pos)
+        self._ck(self._L.rc_submit_packed(self._h, C.byref(b), slot))
+        if not hasattr(self, "_inflight_packed"):
+            self._inflight_packed = {}
+        self._inflight_packed[slot] = (b, res, fix_pos, fix_chr, (off, bases, qual_bits, exc_pos, exc_chr))
+
+    def wait_packed(self, slot):
+        self._ck(self._L.rc_wait_packed(self._h, slot))
+        b, res, fix_pos, fix_chr, _keep = self._inflight_packed.pop(slot)
+        return tuple(res) + (fix_pos[:b.n_fix], fix_chr[:b.n_fix])
+
+    def apply_fixes(self, arena, fix_pos, fix_chr):
+        arena = self._arena(arena, "arena")
+        fp, fc = np.ascontiguousarray(fix_pos, dtype=np.uint32), np.ascontiguousarray(fix_chr, dtype=np.uint8)
+        self._L.rc_apply_fixes(arena.ctypes.data, fp.ctypes.data, fc.ctypes.data, len(fp))
 
     def host_array(self, n, dtype=np.uint8):
         """A page-locked numpy array (rc_host_alloc): rc_submit DMAs straight from / into it.

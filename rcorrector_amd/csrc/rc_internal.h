@@ -193,6 +193,12 @@ int rc_launch_probe_threshold_list(rc_ctx *ctx, const rc_device_batch_args &a, s
 int rc_launch_summary(rc_ctx *ctx, const int32_t *d_ret, uint32_t n);
 int rc_launch_kmer_info(rc_ctx *ctx, const rc_device_batch_args &a);
 
+// rc_transport.hip: the packed boundary (include/rcorrector_amd.h: rc_packed_batch)
+int rc_launch_unpack(rc_ctx *ctx, const uint32_t *d_packed, size_t nbytes, const uint32_t *d_off, uint32_t n_reads, const uint32_t *d_exc_pos,
+                     const uint8_t *d_exc_chr, uint32_t n_exc, uint8_t *d_seq);
+int rc_launch_fix_list(rc_ctx *ctx, const uint32_t *d_packed, size_t nbytes, const uint8_t *d_seq, const uint32_t *d_exc_pos, uint32_t n_exc,
+                       uint32_t *d_n_fix, uint32_t cap, uint32_t *d_fix_pos, uint8_t *d_fix_chr);
+
 // k_correct's work list comes in RC_WORK_CLASSES sections, taken in order: the reads expected to be
 // the most expensive first, so that the last waves of a launch are not left alone with them
 // (cls value of a read = 1 + its section counted from the back; cls 0 = finished by the threshold kernel)

@@ -97,3 +97,42 @@ def test_bad_quality_from_hist_equals_oracle(built, oracle):
         a = L.rc_bad_quality_from_hist(fh.ctypes.data, lh.ctypes.data, total)
         b = O.rco_bad_quality_from_hist(fh.ctypes.data, lh.ctypes.data, total)
         assert a == b, (it, a, b)
+
+
+def test_pack_bases_and_apply_fixes_are_plain_host_code(built):
+    """rc_pack_bases (the packed boundary's host half): 2 bits per base at bits 30 - 2 (p & 15) of word p >> 4, NULs and
+    the letters outside ACGT as code 0 with the latter listed -- against a numpy restatement on a random arena, whole and
+    in ranges that start at multiples of 16 bytes (how several threads pack one arena); rc_apply_fixes is the loop."""
+    import ctypes as C
+    import numpy as np
+    L = built.load_library()
+    rng = np.random.default_rng(3)
+    n = 100_003
+    a = rng.choice(np.frombuffer(b"ACGTACGTACGTACGTNRYKM\0\0", np.uint8), size=n).astype(np.uint8)
+    code = np.zeros(256, np.uint32)
+    code[ord("C")], code[ord("G")], code[ord("T")] = 1, 2, 3
+    pad = np.zeros((n + 15) // 16 * 16, np.uint8)
+    pad[:n] = a
+    want = (code[pad].reshape(-1, 16) << (30 - 2 * np.arange(16, dtype=np.uint32))).sum(axis=1).astype(np.uint32)
+    exc = np.nonzero((a != 0) & ~np.isin(a, np.frombuffer(b"ACGT", np.uint8)))[0]
+    bases = np.full((n + 15) // 16, 0xDEADBEEF, np.uint32)
+    ep, ec = np.zeros(len(exc) + 4, np.uint32), np.zeros(len(exc) + 4, np.uint8)
+    got = L.rc_pack_bases(a.ctypes.data, 0, n, bases.ctypes.data, ep.ctypes.data, ec.ctypes.data, len(ep))
+    assert got == len(exc) and np.array_equal(ep[:got], exc) and np.array_equal(ec[:got], a[exc]) and np.array_equal(bases, want)
+    assert L.rc_pack_bases(a.ctypes.data, 0, n, bases.ctypes.data, None, None, 0) == len(exc)   # counting only
+    bases2 = np.zeros_like(bases)
+    cuts = [0, 16 * 100, 16 * 2500, 16 * 2501, n]
+    tot = 0
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        e2p, e2c = np.zeros(len(exc), np.uint32), np.zeros(len(exc), np.uint8)
+        k = L.rc_pack_bases(a.ctypes.data, lo, hi, bases2.ctypes.data, e2p.ctypes.data, e2c.ctypes.data, len(e2p))
+        assert np.array_equal(e2p[:k], exc[(exc >= lo) & (exc < hi)])
+        tot += k
+    assert tot == len(exc) and np.array_equal(bases2, want)
+    b = a.copy()
+    fp = rng.choice(n, size=500, replace=False).astype(np.uint32)
+    fc = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=500).astype(np.uint8)
+    L.rc_apply_fixes(b.ctypes.data, fp.ctypes.data, fc.ctypes.data, 500)
+    w = a.copy()
+    w[fp] = fc
+    assert np.array_equal(b, w)

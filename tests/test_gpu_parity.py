@@ -677,6 +677,94 @@ def test_quality_bits_give_the_same_results_as_quality_bytes(gpu_ctx_factory, or
     assert np.array_equal(got[0], want[0])
 
 
+def _packed_inputs(ctx, oracle, d, fasta=False):
+    """One arena (mode 1: first mates, then second mates) and its packed form, all in page-locked arrays."""
+    a, off = oracle.pack_reads(d["seqs1"])
+    qa, _ = oracle.pack_reads(d["quals1"])
+    if d["mode"] == 1:
+        a2, off2 = oracle.pack_reads(d["seqs2"])
+        qa2, _ = oracle.pack_reads(d["quals2"])
+        off = np.concatenate([off, (off2[1:].astype(np.int64) + a.size).astype(np.uint32)])
+        a, qa = np.concatenate([a, a2]), np.concatenate([qa, qa2])
+    arena = ctx.host_array(a.size)
+    arena[:] = a
+    bases, exc_pos, exc_chr = ctx.pack_bases(arena, bases=ctx.host_array((a.size + 15) // 16, np.uint32))
+    qb = None
+    if not fasta:
+        qb = ctx.host_array((a.size + 7) // 8)
+        ctx.pack_quality_bits(qa, b"H", out=qb)
+    return arena, off, bases, exc_pos, exc_chr, qb
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["se_k23", "pe_k23", "il_k23", "pe_var", "nrich", "edge", "varlen", "k31_mc8", "tiers_pe", "long600_k31"])
+def test_packed_boundary_gives_the_oracles_results(gpu_ctx_factory, oracle, name):
+    """rc_submit_packed / rc_wait_packed (packed reads down, fix list up): 2 bits per base + the
+    letters outside ACGT as a list + a quality bit per base go down, ret / l / m / h and the substitutions come back.
+    ret / l / m / h must be the oracle's, and the caller's arena with the fixes applied must be the oracle's corrected
+    arena -- on N-rich and adversarial reads (IUPAC letters, N replaced by A: the one substitution the packed codes
+    cannot show), ragged pairs, interleaved pairs, long reads; the fix count equals the bases the oracle changed."""
+    d = datasets.make(name)
+    want = datasets.run_oracle(oracle, d)
+    ctx = _table(gpu_ctx_factory, d)
+    arena, off, bases, exc_pos, exc_chr, qb = _packed_inputs(ctx, oracle, d)
+    before = arena.copy()
+    assert len(exc_pos) == int(((before != 0) & ~np.isin(before, np.frombuffer(b"ACGT", np.uint8))).sum())
+    ctx.submit_packed(0, d["mode"], arena.size, off, bases, qb, exc_pos, exc_chr)
+    ret, l, m, h, fix_pos, fix_chr = ctx.wait_packed(0)
+    for w, g, what in zip(want[:4], (ret, l, m, h), ["ret", "l", "m", "h"]):
+        assert np.array_equal(w, g), "%s differs on %s through the packed boundary" % (what, name)
+    assert np.array_equal(arena, before)       # the caller's arena is not touched ...
+    ctx.apply_fixes(arena, fix_pos, fix_chr)   # ... until the caller applies the fixes
+    want_arena = np.concatenate(want[4:])
+    assert np.array_equal(arena, want_arena), "corrected bases differ on %s through the packed boundary" % name
+    assert len(fix_pos) == int((before != want_arena).sum()) and len(np.unique(fix_pos)) == len(fix_pos)
+    assert len(fix_pos) == int(want[0][want[0] > 0].sum())   # ErrorCorrection's return value counts exactly these (:1468-1479)
+
+
+@pytest.mark.gpu
+def test_packed_boundary_slots_fasta_and_errors(gpu_ctx_factory, oracle):
+    """Three packed batches in flight give what three synchronous byte batches give; no quality array = FASTA input
+    (qual[0] == 0, Reads.h:224-266) = the byte path with zeroed quality arenas; too little room for the fixes and a
+    byte-path wait on a packed slot are errors, and the context works on after them."""
+    d = datasets.make("pe_var")
+    ctx = _table(gpu_ctx_factory, d)
+    n1 = len(d["seqs1"])
+    parts = []
+    for j in range(3):
+        lo, hi = j * n1 // 3, (j + 1) * n1 // 3
+        sub = dict(d, seqs1=d["seqs1"][lo:hi], quals1=d["quals1"][lo:hi], seqs2=d["seqs2"][lo:hi], quals2=d["quals2"][lo:hi])
+        parts.append((sub, _packed_inputs(ctx, oracle, sub)))
+    for j, (sub, (arena, off, bases, exc_pos, exc_chr, qb)) in enumerate(parts):
+        ctx.submit_packed(j, 1, arena.size, off, bases, qb, exc_pos, exc_chr)
+    for j, (sub, (arena, off, bases, exc_pos, exc_chr, qb)) in enumerate(parts):
+        ret, l, m, h, fix_pos, fix_chr = ctx.wait_packed(j)
+        want = datasets.run_oracle(oracle, sub)
+        ctx.apply_fixes(arena, fix_pos, fix_chr)
+        assert np.array_equal(ret, want[0]) and np.array_equal(m, want[2]) and np.array_equal(arena, np.concatenate(want[4:]))
+    # FASTA: no qualities
+    sub, (arena, off, bases, exc_pos, exc_chr, _qb) = parts[0][0], _packed_inputs(ctx, oracle, parts[0][0], fasta=True)
+    ctx.submit_packed(1, 1, arena.size, off, bases, None, exc_pos, exc_chr)
+    ret, l, m, h, fix_pos, fix_chr = ctx.wait_packed(1)
+    a1, o1 = oracle.pack_reads(sub["seqs1"])
+    a2, o2 = oracle.pack_reads(sub["seqs2"])
+    got = ctx.correct_batch(1, a1, np.zeros_like(a1), o1, a2, np.zeros_like(a2), o2)
+    ctx.apply_fixes(arena, fix_pos, fix_chr)
+    assert np.array_equal(ret, got[0]) and np.array_equal(h, got[3]) and np.array_equal(arena, np.concatenate([a1, a2]))
+    # errors
+    arena, off, bases, exc_pos, exc_chr, qb = _packed_inputs(ctx, oracle, sub)
+    ctx.submit_packed(2, 1, arena.size, off, bases, qb, exc_pos, exc_chr, fix_cap=1)
+    with pytest.raises(rcorrector_amd.RcorrectorError, match="room for 1"):
+        ctx.wait_packed(2)
+    ctx.submit_packed(0, 1, arena.size, off, bases, qb, exc_pos, exc_chr)
+    with pytest.raises(rcorrector_amd.RcorrectorError, match="packed"):
+        ctx._ck(ctx._L.rc_wait(ctx._h, 0))
+    ret2 = ctx.wait_packed(0)[0]
+    assert np.array_equal(ret2, datasets.run_oracle(oracle, sub)[0])
+    with pytest.raises(rcorrector_amd.RcorrectorError):
+        ctx.submit_packed(0, 1, arena.size + 1, off, bases, qb, exc_pos, exc_chr)   # off[total] is not the arena's size
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["se_k23", "pe_k23", "il_k23", "pe_var", "varlen", "edge", "k31_mc8", "long600_k31", "polya_k23",
                                   "se_151", "pe_151", "pe_160_k15", "tiers_se", "tiers_pe", "tiers_il"])
