@@ -196,7 +196,8 @@ int rc_host_unregister(void *p);
  *             Reads.h:224-266: the reference then sees qual[0] == 0)
  * rc_pack_bases() makes bases / exc_* from a byte arena (callers with several threads pack ranges that start at multiples
  * of 16 bytes side by side: range [begin, end) writes words [begin / 16, (end + 15) / 16) and its own exception list,
- * whose positions are arena positions).  rc_submit_packed() starts the batch, rc_wait_packed() completes it: ret / l / m / h
+ * whose positions are arena positions; a range that starts inside a word keeps the bits of the positions in front of it,
+ * so the second arena of a pair is packed behind the first one: seq = arena2 - bytes1, begin = bytes1).  rc_submit_packed() starts the batch, rc_wait_packed() completes it: ret / l / m / h
  * as for rc_batch, and the substitutions the correction made (ErrorCorrection.cpp:1468-1479) as n_fix pairs
  * (fix_pos[j] = arena position, fix_chr[j] = the new letter), in no particular order -- positions are distinct, so the
  * caller may apply them from several threads (rc_apply_fixes() is the loop).  fix_cap = room in the caller's arrays;

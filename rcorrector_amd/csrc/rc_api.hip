@@ -1659,6 +1659,8 @@ size_t rc_pack_bases(const char *seq, size_t begin, size_t end, uint32_t *bases,
                 ++n_exc;
             }
         }
+        // a range that starts inside a word keeps the bits of the positions in front of it (the caller packed them first)
+        if (lo > p0) word |= bases[w] & ~(0xFFFFFFFFu >> (2 * (lo - p0)));
         bases[w] = word;
     }
     return n_exc;

@@ -52,6 +52,7 @@ static bool g_verbose = false;   // -verbose: the reference's per-read transcrip
 static int g_trace_iter = 64;    // threshold iterations recorded per read under -verbose
 static bool g_timing = false;  // RC_TIMING=1: phase timings on stderr (off by default: stderr is part of the contract)
 static int g_threads = 8;
+static bool g_packed = false;  // -packed / RC_TRANSPORT=packed: batches cross PCIe through rc_submit_packed (2-bit bases, quality bits, fix list)
 
 static double g_w_reader = 0, g_w_writer = 0, g_w_worker = 0;  // RC_TIMING: time blocked on the neighbouring stage
 static double g_t_read = 0, g_t_pack = 0, g_t_gpu = 0, g_t_format = 0, g_t_write = 0;  // RC_TIMING stage totals (thread-seconds)
@@ -609,6 +610,9 @@ struct Job {
     Arena a, b;
     std::vector<int32_t> ret, l, m, h;
     std::vector<int32_t> tr_before, tr_after, tr_flags, tr_niter, tr_iter;  // -verbose only
+    // -packed: the batch as rc_packed_batch wants it (one offset array over both arenas, 2-bit codes, quality bits, the
+    // letters outside ACGT) and the room for the fix list
+    PinBuf pk_off, pk_bases, pk_qbits, pk_exc_pos, pk_exc_chr, pk_fix_pos, pk_fix_chr;
     std::vector<std::vector<char>> o1, o2;  // the formatted (and, for .gz, deflated) output records, in slices
     bool done = false;
     int rc = 0;
@@ -931,6 +935,8 @@ int main(int argc, char **argv)
             inflight = atoi(argv[++i]);
         else if (!strcmp("-write-dump", argv[i]))
             write_dump = argv[++i];
+        else if (!strcmp("-packed", argv[i]))
+            g_packed = true;
         else if (!strcmp("-h", argv[i])) {
             print_help();
             return 0;
@@ -958,6 +964,8 @@ int main(int argc, char **argv)
         if (g_threads < 1) g_threads = 1;
     }
     g_timing = getenv("RC_TIMING") != nullptr;
+    if (const char *e = getenv("RC_TRANSPORT")) g_packed = g_packed || !strcmp(e, "packed");
+    if (verbose) g_packed = false;  // (the transcript needs the traced entry point)
     // batches recycle buffers of hundreds of MB: keep freed memory in the heap instead of handing it
     // back to the kernel and faulting it in again page by page (with dozens of threads every
     // mmap/munmap/page fault also serialises on the process's memory-map lock)
@@ -1276,6 +1284,125 @@ int main(int argc, char **argv)
                     tr.iter = j->tr_iter.data();
                     std::lock_guard<std::mutex> lk(submit_mu[(size_t)g]);
                     rc = rc_correct_batch_traced(ctx[g], &rb, &tr);
+                } else if (g_packed && [&]() {
+                               // One bit per quality cannot say "this read has no quality string" (qual[0] == 0: an empty
+                               // quality line in a FASTQ file; ErrorCorrection.cpp:1316 asks): such a batch takes the bytes
+                               if (!j->fastq) return true;
+                               for (int sd = 0; sd < (j->mode == 1 ? 2 : 1); ++sd) {
+                                   const Arena &A = sd ? j->b : j->a;
+                                   for (size_t r = 0; r < A.n(); ++r)
+                                       if (A.off[r + 1] - A.off[r] > 1 && A.qual.data()[A.off[r]] == 0) return false;
+                               }
+                               return true;
+                           }()) {
+                    // the packed boundary: the arenas stay here; 2-bit codes, quality bits and the letters outside ACGT go
+                    // down, the substitutions come back as a list and are applied to the arenas in front of the formatter
+                    Job &J = *j;
+                    const size_t bytes1 = J.a.off[n], bytes2 = J.mode == 1 ? J.b.off[n] : 0, nbytes = bytes1 + bytes2;
+                    const size_t n_words = (nbytes + 15) / 16, cap = nbytes / 4 + 64;
+                    J.pk_off.need((total + 1) * 4);
+                    J.pk_bases.need(n_words * 4 + 64);
+                    J.pk_qbits.need((nbytes + 7) / 8 + 64);
+                    J.pk_fix_pos.need(cap * 4);
+                    J.pk_fix_chr.need(cap);
+                    uint32_t *off = (uint32_t *)J.pk_off.data();
+                    memcpy(off, J.a.off.data(), (n + 1) * 4);
+                    if (J.mode == 1)
+                        for (size_t r = 0; r <= n; ++r) off[n + r] = (uint32_t)bytes1 + J.b.off[r];
+                    // bases: 16-byte-aligned pieces of the combined arena side by side, the exceptions of each piece after it
+                    const size_t P = std::max<size_t>(1, std::min<size_t>((size_t)g_threads, n_words / 4096 + 1));
+                    std::vector<std::vector<uint32_t>> ep(P);
+                    std::vector<std::vector<uint8_t>> ec(P);
+                    auto piece = [&](size_t t) {
+                        const size_t w0 = n_words * t / P, w1 = n_words * (t + 1) / P;
+                        size_t lo = w0 * 16, hi = std::min(w1 * 16, nbytes);
+                        uint32_t *bases = (uint32_t *)J.pk_bases.data();
+                        for (int pass = 0; pass < 2; ++pass) {  // (first pass counts the exceptions, second stores them)
+                            size_t cnt = 0;
+                            uint32_t *pp = pass ? ep[t].data() : nullptr;
+                            uint8_t *pc = pass ? ec[t].data() : nullptr;
+                            const size_t room = pass ? ep[t].size() : 0;
+                            size_t got = 0;
+                            if (lo < bytes1) cnt += (got = rc_pack_bases(J.a.seq.data(), lo, std::min(hi, bytes1), bases, pp, pc, room));
+                            if (hi > bytes1) {
+                                const size_t b0 = std::max(lo, bytes1);
+                                cnt += rc_pack_bases(J.b.seq.data() - bytes1, b0, hi, bases, pp ? pp + std::min(got, room) : nullptr,
+                                                     pc ? pc + std::min(got, room) : nullptr, room > got ? room - got : 0);
+                            }
+                            if (pass == 0) {
+                                if (cnt == 0) break;
+                                ep[t].resize(cnt);
+                                ec[t].resize(cnt);
+                            }
+                        }
+                    };
+                    g_pool.run(P, piece);
+                    size_t n_exc = 0;
+                    for (size_t t = 0; t < P; ++t) n_exc += ep[t].size();
+                    J.pk_exc_pos.need(n_exc * 4 + 64);
+                    J.pk_exc_chr.need(n_exc + 64);
+                    {
+                        size_t at = 0;
+                        for (size_t t = 0; t < P; ++t) {
+                            if (ep[t].empty()) continue;
+                            memcpy(J.pk_exc_pos.data() + at * 4, ep[t].data(), ep[t].size() * 4);
+                            memcpy(J.pk_exc_chr.data() + at, ec[t].data(), ec[t].size());
+                            at += ep[t].size();
+                        }
+                    }
+                    // quality bits (FASTQ) over the combined arena; byte-aligned pieces
+                    const bool fq = J.fastq;
+                    if (fq) {
+                        uint8_t *qb = (uint8_t *)J.pk_qbits.data();
+                        const size_t Q = std::max<size_t>(1, std::min<size_t>((size_t)g_threads, nbytes / 65536 + 1));
+                        // (arena 2's bits start at bit bytes1 of the same array: pack the two arenas' bytes through one view)
+                        g_pool.run(Q, [&](size_t t) {
+                            const size_t lo = (nbytes * t / Q) & ~(size_t)7, hi = t + 1 == Q ? nbytes : ((nbytes * (t + 1) / Q) & ~(size_t)7);
+                            for (size_t p8 = lo; p8 < hi; p8 += 8) {
+                                unsigned v = 0;
+                                for (size_t q = p8; q < std::min(p8 + 8, hi); ++q) {
+                                    const signed char c = q < bytes1 ? (signed char)J.a.qual.data()[q] : (signed char)J.b.qual.data()[q - bytes1];
+                                    v |= (unsigned)(c > (signed char)bad_q) << (q - p8);
+                                }
+                                qb[p8 >> 3] = (uint8_t)v;
+                            }
+                        });
+                    }
+                    rc_packed_batch pb;
+                    memset(&pb, 0, sizeof pb);
+                    pb.mode = J.mode;
+                    pb.n = n;
+                    pb.nbytes = nbytes;
+                    pb.off = off;
+                    pb.bases = (const uint32_t *)J.pk_bases.data();
+                    pb.qual_bits = fq ? (const uint8_t *)J.pk_qbits.data() : nullptr;
+                    pb.exc_pos = n_exc ? (const uint32_t *)J.pk_exc_pos.data() : nullptr;
+                    pb.exc_chr = n_exc ? (const uint8_t *)J.pk_exc_chr.data() : nullptr;
+                    pb.n_exc = n_exc;
+                    pb.ret = J.ret.data();
+                    pb.l = J.l.data();
+                    pb.m = J.m.data();
+                    pb.h = J.h.data();
+                    pb.fix_pos = (uint32_t *)J.pk_fix_pos.data();
+                    pb.fix_chr = (uint8_t *)J.pk_fix_chr.data();
+                    pb.fix_cap = cap;
+                    {
+                        std::lock_guard<std::mutex> lk(submit_mu[(size_t)g]);
+                        rc = rc_submit_packed(ctx[g], &pb, slot);
+                    }
+                    if (!rc) rc = rc_wait_packed(ctx[g], slot);
+                    if (!rc && pb.n_fix) {  // positions are distinct: any number of threads
+                        const size_t F = std::max<size_t>(1, std::min<size_t>((size_t)g_threads, pb.n_fix / 16384 + 1));
+                        g_pool.run(F, [&](size_t t) {
+                            for (size_t q = pb.n_fix * t / F; q < pb.n_fix * (t + 1) / F; ++q) {
+                                const size_t pos = pb.fix_pos[q];
+                                if (pos < bytes1)
+                                    J.a.seq.data()[pos] = (char)pb.fix_chr[q];
+                                else
+                                    J.b.seq.data()[pos - bytes1] = (char)pb.fix_chr[q];
+                            }
+                        });
+                    }
                 } else {
                     {   // upload + kernels + download are queued here; the wait below overlaps with the other
                         // workers' packing, submitting and formatting

@@ -19,6 +19,17 @@ def test_cli_reproduces_reference_outputs(name, tmp_path):
     gu.assert_same_as_reference(name, tmp_path, p.stderr)
 
 
+@pytest.mark.parametrize("name", gu.FIXTURES + ["fa_se_k23"])
+@pytest.mark.parametrize("extra", [[], ["-batch", "50"]], ids=["one_batch", "batch50"])
+def test_cli_packed_transport_reproduces_reference_outputs(name, extra, tmp_path):
+    """`-packed` (or RC_TRANSPORT=packed): the batches cross PCIe through rc_submit_packed -- 2-bit bases, quality bits,
+    the letters outside ACGT as a list down, ret / l / m / h and the substitutions as a fix list up, applied to the arenas in
+    front of the formatter -- and every golden fixture, the FASTA one included (no quality array), comes out as the reference
+    wrote it; a FASTQ batch with an empty quality line takes the byte path (fx_io_quirks)."""
+    p = gu.run_fixture(CLI, name, tmp_path, extra=["-packed"] + extra)
+    gu.assert_same_as_reference(name, tmp_path, p.stderr)
+
+
 @pytest.mark.parametrize("name", ["fx_se_k23", "fx_pe_k23", "fx_il_k23", "fx_edge"])
 def test_cli_small_batches_and_thread_flag(name, tmp_path):
     # output must not depend on the batch size (the reference's is 512*T, main.cpp:441)

@@ -108,6 +108,14 @@ def test_cli_equals_oracle_cli_on_random_inputs(oracle, seed, tmp_path):
         assert outs["gpu"][1][f] == outs["cpu"][1][f], "%s differs (seed %d, args %s)" % (f, seed, args)
     assert outs["gpu"][0] == outs["cpu"][0], "stderr differs (seed %d)" % seed
     assert outs["gpu"][2] == outs["cpu"][2], "-verbose transcript differs (seed %d)" % seed
+    # the same through the packed boundary (rc_submit_packed: N-rich reads, IUPAC letters, ragged pairs, empty tables)
+    od = os.path.join(d, "packed")
+    os.makedirs(od)
+    p = subprocess.run([CLI] + args + ["-od", od, "-packed"] + (["-batch", "32"] if seed % 2 else []), cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr.decode()
+    assert p.stderr == outs["cpu"][0], "stderr differs through the packed boundary (seed %d)" % seed
+    for f in outs["cpu"][1]:
+        assert _content(os.path.join(od, f)) == outs["cpu"][1][f], "%s differs through the packed boundary (seed %d, args %s)" % (f, seed, args)
 
 
 @pytest.mark.gpu
@@ -128,3 +136,10 @@ def test_cli_equals_oracle_cli_on_io_quirks(oracle, seed, tmp_path):
     assert res[0][0] == 0
     for j, what in enumerate(("exit status", "stderr", "output files", "-verbose transcript")):
         assert res[0][j] == res[1][j], "%s differs (seed %d)" % (what, seed)
+    # through the packed boundary (a batch with an empty quality line falls back to the bytes: one bit per quality cannot
+    # say "no quality string")
+    od = os.path.join(d, "packed")
+    os.makedirs(od)
+    p = subprocess.run([CLI] + args + ["-od", od, "-packed"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert (p.returncode, p.stderr) == (res[1][0], res[1][1])
+    assert {f: _content(os.path.join(od, f)) for f in sorted(os.listdir(od))} == res[1][2], "output differs through the packed boundary (seed %d)" % seed
