@@ -71,6 +71,13 @@ int rc_table_count_begin(rc_ctx *ctx);
 int rc_table_count_add(rc_ctx *ctx, const char *seq, size_t nbytes);
 int rc_table_count_add_device(rc_ctx *ctx, const uint8_t *d_seq, size_t nbytes);
 int rc_table_count_finish(rc_ctx *ctx, int min_count, int64_t *n_kmers);
+/* on != 0: rc_table_count_finish leaves the arenas it was given in HBM (in the order of the non-empty count_add calls)
+ * instead of releasing them, for rc_submit_resident below: a data set whose k-mers were counted on this GPU is corrected
+ * where it lies and crosses PCIe once.  rc_table_count_arenas reports how many there are (and the bytes of the first
+ * `cap`); they are released by the next rc_table_count_begin, by rc_table_count_release, or with the context. */
+int rc_table_count_keep(rc_ctx *ctx, int on);
+int rc_table_count_arenas(const rc_ctx *ctx, size_t *n_arenas, uint64_t *bytes, size_t cap);
+int rc_table_count_release(rc_ctx *ctx);
 /* begin + add_device + finish for one arena */
 int rc_table_count_reads_device(rc_ctx *ctx, const uint8_t *d_seq, size_t nbytes, int min_count,
                                 int64_t *n_kmers);
@@ -225,6 +232,30 @@ size_t rc_pack_bases(const char *seq, size_t begin, size_t end, uint32_t *bases,
 int rc_submit_packed(rc_ctx *ctx, rc_packed_batch *b, int slot);
 int rc_wait_packed(rc_ctx *ctx, int slot);
 void rc_apply_fixes(char *seq, const uint32_t *fix_pos, const uint8_t *fix_chr, size_t n_fix);
+
+/* The packed boundary for reads that are already in HBM -- the arenas the k-mer counter kept (rc_table_count_keep; without
+ * a jellyfish dump the reads have been uploaded once to be counted, run_rcorrector.pl:262-281 reads them a second time
+ * for stage 3): nothing but the offsets and the quality bits goes down, the same results come back.  A batch is a byte
+ * range of one kept arena (mode 0 / 2), or of two (mode 1: first mates from arena_a, second mates from arena_b); the ranges
+ * hold whole NUL-terminated reads.  off / qual_bits / ret .. fix_* / n_fix as in rc_packed_batch, over the batch's own
+ * arena of bytes_a + bytes_b bytes (range a, then range b); the kept arenas themselves are never modified, so a batch
+ * may be submitted again. */
+typedef struct {
+    int mode;
+    size_t n;                  /* reads per arena as in rc_batch (mode 1: pairs) */
+    int arena_a, arena_b;      /* indices of kept arenas (arena_b: mode 1 only) */
+    uint64_t begin_a, bytes_a; /* the batch's byte range of arena_a */
+    uint64_t begin_b, bytes_b; /* ... of arena_b (mode 1), else 0 */
+    const uint32_t *off;       /* [total + 1], off[total] = bytes_a + bytes_b */
+    const uint8_t *qual_bits;  /* [(bytes_a + bytes_b + 7) / 8] or NULL (FASTA) */
+    int32_t *ret, *l, *m, *h;  /* [total] */
+    uint32_t *fix_pos;         /* [fix_cap] positions in the batch's arena */
+    uint8_t *fix_chr;          /* [fix_cap] */
+    size_t fix_cap;
+    size_t n_fix;              /* out, valid after rc_wait_resident */
+} rc_resident_batch;
+int rc_submit_resident(rc_ctx *ctx, rc_resident_batch *b, int slot);
+int rc_wait_resident(rc_ctx *ctx, int slot);
 
 /* rc_correct_batch plus everything the reference prints per read under -verbose (VERBOSE,
  * ErrorCorrection.cpp:15,686-689,759-770,856-857,1088-1094,1590-1597), as data; the caller formats

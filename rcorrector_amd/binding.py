@@ -13,6 +13,7 @@ ABI_SYMBOLS = [
     "rc_create", "rc_destroy", "rc_last_error", "rc_device_numa_node",
     "rc_table_build", "rc_table_build_device", "rc_table_load_jfdump",
     "rc_table_count_begin", "rc_table_count_add", "rc_table_count_add_device", "rc_table_count_finish",
+    "rc_table_count_keep", "rc_table_count_arenas", "rc_table_count_release", "rc_submit_resident", "rc_wait_resident",
     "rc_table_count_reads_device", "rc_table_write_jfdump", "rc_table_share", "rc_table_replicate", "rc_table_replicate_async", "rc_table_lookup", "rc_table_export", "rc_table_digest", "rc_table_layout", "rc_table_stats",
     "rc_estimate_error_rate", "rc_bad_quality_from_hist", "rc_set_run_params", "rc_set_quality_bits", "rc_pack_quality_bits",
     "rc_correct_batch", "rc_submit", "rc_wait", "rc_host_alloc", "rc_host_free", "rc_host_register", "rc_host_unregister", "rc_correct_batch_traced", "rc_correct_device", "rc_strong_threshold_device", "rc_probe_device", "rc_sync",
@@ -53,6 +54,14 @@ class _PackedBatch(C.Structure):
     _fields_ = [("mode", C.c_int), ("n", C.c_size_t), ("nbytes", C.c_uint64),
                 ("off", C.c_void_p), ("bases", C.c_void_p), ("qual_bits", C.c_void_p),
                 ("exc_pos", C.c_void_p), ("exc_chr", C.c_void_p), ("n_exc", C.c_size_t),
+                ("ret", C.c_void_p), ("l", C.c_void_p), ("m", C.c_void_p), ("h", C.c_void_p),
+                ("fix_pos", C.c_void_p), ("fix_chr", C.c_void_p), ("fix_cap", C.c_size_t), ("n_fix", C.c_size_t)]
+
+
+class _ResidentBatch(C.Structure):
+    _fields_ = [("mode", C.c_int), ("n", C.c_size_t), ("arena_a", C.c_int), ("arena_b", C.c_int),
+                ("begin_a", C.c_uint64), ("bytes_a", C.c_uint64), ("begin_b", C.c_uint64), ("bytes_b", C.c_uint64),
+                ("off", C.c_void_p), ("qual_bits", C.c_void_p),
                 ("ret", C.c_void_p), ("l", C.c_void_p), ("m", C.c_void_p), ("h", C.c_void_p),
                 ("fix_pos", C.c_void_p), ("fix_chr", C.c_void_p), ("fix_cap", C.c_size_t), ("n_fix", C.c_size_t)]
 
@@ -102,6 +111,11 @@ def load_library():
     L.rc_table_count_add.argtypes = [vp, vp, sz]
     L.rc_table_count_add_device.argtypes = [vp, vp, sz]
     L.rc_table_count_finish.argtypes = [vp, C.c_int, C.POINTER(C.c_int64)]
+    L.rc_table_count_keep.argtypes = [vp, C.c_int]
+    L.rc_table_count_arenas.argtypes = [vp, C.POINTER(C.c_size_t), vp, sz]
+    L.rc_table_count_release.argtypes = [vp]
+    L.rc_submit_resident.argtypes = [vp, C.POINTER(_ResidentBatch), C.c_int]
+    L.rc_wait_resident.argtypes = [vp, C.c_int]
     L.rc_table_write_jfdump.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64)]
     L.rc_table_share.argtypes = [vp, vp]
     L.rc_table_replicate.argtypes = [vp, vp]
@@ -426,6 +440,50 @@ class Context:
     def wait_packed(self, slot):
         self._ck(self._L.rc_wait_packed(self._h, slot))
         b, res, fix_pos, fix_chr, _keep = self._inflight_packed.pop(slot)
+        return tuple(res) + (fix_pos[:b.n_fix], fix_chr[:b.n_fix])
+
+    # ---- reads the k-mer counter kept in HBM (rc_resident_batch) ----
+    def count_keep(self, on=True):
+        self._ck(self._L.rc_table_count_keep(self._h, 1 if on else 0))
+
+    def count_arenas(self):
+        """bytes of the arenas the counter kept, in the order they were added"""
+        n = C.c_size_t(0)
+        self._ck(self._L.rc_table_count_arenas(self._h, C.byref(n), None, 0))
+        b = np.zeros(max(1, n.value), dtype=np.uint64)
+        self._ck(self._L.rc_table_count_arenas(self._h, C.byref(n), b.ctypes.data, len(b)))
+        return b[:n.value]
+
+    def count_release(self):
+        self._ck(self._L.rc_table_count_release(self._h))
+
+    def submit_resident(self, slot, mode, off, qual_bits, arena_a, begin_a, bytes_a, arena_b=0, begin_b=0, bytes_b=0, res=None, fix_pos=None,
+                        fix_chr=None, fix_cap=None):
+        """rc_submit_resident: the batch is a byte range of kept arena `arena_a` (mode 1: + one of `arena_b`); off over the
+        batch's own arena (bytes_a + bytes_b bytes).  wait_resident(slot) returns (ret, l, m, h, fix_pos, fix_chr)."""
+        off = np.ascontiguousarray(off, dtype=np.uint32)
+        total = len(off) - 1
+        if res is None:
+            res = [np.zeros(total, dtype=np.int32) for _ in range(4)]
+        if fix_pos is None:
+            fix_cap = int(bytes_a + bytes_b) if fix_cap is None else fix_cap
+            fix_pos, fix_chr = np.zeros(fix_cap, dtype=np.uint32), np.zeros(fix_cap, dtype=np.uint8)
+        b = _ResidentBatch()
+        b.mode, b.n = mode, (total // 2 if mode == 1 else total)
+        b.arena_a, b.begin_a, b.bytes_a = int(arena_a), int(begin_a), int(bytes_a)
+        b.arena_b, b.begin_b, b.bytes_b = int(arena_b), int(begin_b), int(bytes_b)
+        b.off = off.ctypes.data
+        b.qual_bits = None if qual_bits is None else qual_bits.ctypes.data
+        b.ret, b.l, b.m, b.h = (r.ctypes.data for r in res)
+        b.fix_pos, b.fix_chr, b.fix_cap = fix_pos.ctypes.data, fix_chr.ctypes.data, len(fix_pos)
+        self._ck(self._L.rc_submit_resident(self._h, C.byref(b), slot))
+        if not hasattr(self, "_inflight_resident"):
+            self._inflight_resident = {}
+        self._inflight_resident[slot] = (b, res, fix_pos, fix_chr, (off, qual_bits))
+
+    def wait_resident(self, slot):
+        self._ck(self._L.rc_wait_resident(self._h, slot))
+        b, res, fix_pos, fix_chr, _keep = self._inflight_resident.pop(slot)
         return tuple(res) + (fix_pos[:b.n_fix], fix_chr[:b.n_fix])
 
     def apply_fixes(self, arena, fix_pos, fix_chr):

@@ -50,6 +50,7 @@ struct rc_slot {
     // the packed boundary (rc_submit_packed): the caller's descriptor, the packed arena / exceptions / fix list in HBM,
     // pinned staging for descriptor arrays that are not page-locked, and the fix count's landing place
     rc_packed_batch *pb = nullptr;
+    rc_resident_batch *rb = nullptr;  // rc_submit_resident: same slot state, the arena copied from the counter's kept arenas
     rc_dbuf d_packed, d_exc, d_fix;
     rc_hbuf p_in, p_fix, p_nfix;
     uint32_t fix_room = 0;
@@ -212,6 +213,7 @@ void rc_destroy(rc_ctx *c)
     if (ctx->s_d2h) (void)hipStreamDestroy(ctx->s_d2h);
     for (auto &a : ctx->cnt_arenas)
         if (a.p) (void)hipFree(a.p);
+    rc_kept_release(ctx);
     rc_table_release(ctx);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -654,6 +656,30 @@ int rc_table_count_begin(rc_ctx *ctx)
     return rc_count_begin(ctx);
 }
 
+int rc_table_count_keep(rc_ctx *ctx, int on)
+{
+    if (!ctx) return RC_ERR_ARG;
+    ctx->cnt_keep = on != 0;
+    return RC_OK;
+}
+
+int rc_table_count_arenas(const rc_ctx *ctx, size_t *n_arenas, uint64_t *bytes, size_t cap)
+{
+    if (!ctx || !n_arenas) return RC_ERR_ARG;
+    *n_arenas = ctx->kept_arenas.size();
+    for (size_t i = 0; bytes && i < cap && i < ctx->kept_arenas.size(); ++i) bytes[i] = ctx->kept_arenas[i].bytes;
+    return RC_OK;
+}
+
+int rc_table_count_release(rc_ctx *ctx)
+{
+    if (!ctx) return RC_ERR_ARG;
+    RC_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (a batch still reading them)
+    rc_kept_release(ctx);
+    return RC_OK;
+}
+
 int rc_table_count_add_device(rc_ctx *ctx, const uint8_t *d_seq, size_t nbytes)
 {
     if (!ctx || (nbytes && !d_seq)) return RC_ERR_ARG;
@@ -843,52 +869,57 @@ int rc_estimate_error_rate(rc_ctx *c, double wk, double *rate_out)
         return RC_ERR_STATE;
     }
     RC_CHECK_HIP(ctx, hipSetDevice(ctx->device));
-    if (!ctx->dump.valid) {
-        // no dump file was read (the table was counted here or handed over as arrays): scan the
-        // entries in the order rc_table_write_jfdump would write them -- what the reference would
-        // see if it were given that dump
-        ctx->dump.codes.assign(1, std::vector<uint64_t>());
-        int rc = rc_table_entries_in_dump_order(ctx, &ctx->dump.codes[0], nullptr);
-        if (rc) return rc;
-        ctx->dump.n = ctx->dump.codes[0].size();
-        ctx->dump.inv_mid.assign(1, std::vector<int8_t>(ctx->dump.n, 0));
-        ctx->dump.load_state_invalid = 0;
-        ctx->dump.valid = true;
-    }
-    const rc_dump_cache &D = ctx->dump;
-    const size_t n = D.n;
-    std::vector<int32_t> mx2(2 * n);
-    if (n) {
-        rc_dev_tmp b_codes, b_out;
-        RC_CHECK_HIP(ctx, b_codes.alloc(n * 8));
-        RC_CHECK_HIP(ctx, b_out.alloc(n * 8));
-        size_t at = 0;
-        for (const auto &ch : D.codes) {
-            if (!ch.empty()) RC_CHECK_HIP(ctx, hipMemcpyAsync(b_codes.as<uint64_t>() + at, ch.data(), ch.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-            at += ch.size();
-        }
-        int rc = rc_launch_last_base_variants(ctx, b_codes.as<uint64_t>(), n, b_out.as<int32_t>());
-        if (rc) return rc;
-        RC_CHECK_HIP(ctx, hipMemcpyAsync(mx2.data(), b_out.p, n * 8, hipMemcpyDeviceToHost, ctx->stream));
-        RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    }
+    // The scan keeps an entry when the largest count among its four last-base variants reaches 1000 and stops after
+    // 100 000 of them (main.cpp:329-347): the probes, the test and the selection run on the device over the whole dump
+    // (k_error_rate_candidates), the first 100 000 kept entries in dump order come back -- a few hundred KB instead of
+    // 16 bytes per entry of the dump each way.
     const int rate_size = 100000;
+    std::vector<uint64_t> vals;
+    if (!ctx->dump.valid) {
+        // no dump file was read (the table was counted here or handed over as arrays): the entries in the order
+        // rc_table_write_jfdump would write them -- what the reference would see if it were given that dump
+        uint64_t *d_codes = nullptr;
+        size_t n = 0;
+        int rc = rc_table_codes_device(ctx, &d_codes, &n);
+        if (rc) return rc;
+        rc = rc_error_rate_candidates(ctx, d_codes, n, true, (size_t)rate_size, &vals);
+        (void)hipFree(d_codes);
+        if (rc) return rc;
+    } else {
+        const rc_dump_cache &D = ctx->dump;
+        // an entry that leaves an invalid KmerCode behind ends the scan (the IsValid() test at main.cpp:323)
+        size_t n = 0;
+        bool cut = D.load_state_invalid != 0;
+        for (size_t c = 0; c < D.inv_mid.size() && !cut; ++c) {
+            const std::vector<int8_t> &inv = D.inv_mid[c];
+            const void *hit = inv.empty() ? nullptr : memchr(inv.data(), 1, inv.size());
+            if (hit) {
+                n += (size_t)((const int8_t *)hit - inv.data());
+                cut = true;
+            } else {
+                n += inv.size();
+            }
+        }
+        if (n) {
+            rc_dev_tmp b_codes;
+            RC_CHECK_HIP(ctx, b_codes.alloc(n * 8));
+            size_t at = 0;
+            for (const auto &ch : D.codes) {
+                if (at >= n) break;
+                const size_t take = std::min(ch.size(), n - at);
+                if (take) RC_CHECK_HIP(ctx, hipMemcpyAsync(b_codes.as<uint64_t>() + at, ch.data(), take * 8, hipMemcpyHostToDevice, ctx->stream));
+                at += take;
+            }
+            int rc = rc_error_rate_candidates(ctx, b_codes.as<uint64_t>(), n, false, (size_t)rate_size, &vals);
+            if (rc) return rc;
+        }
+    }
     std::vector<double> store((size_t)rate_size + 2, 0.0);
     double *r = store.data() + 1;  // r[-1] readable, as in the reference when k == 0
     int cnt = 0;
-    bool state_invalid = D.load_state_invalid != 0;  // the IsValid() test at main.cpp:323
-    size_t i = 0;
-    for (size_t c = 0; c < D.inv_mid.size() && cnt < rate_size && !state_invalid; ++c) {
-        const std::vector<int8_t> &inv = D.inv_mid[c];
-        for (size_t j = 0; j < inv.size() && cnt < rate_size; ++j, ++i) {
-            if (inv[j]) {  // this entry leaves an invalid KmerCode behind: everything after is skipped
-                state_invalid = true;
-                break;
-            }
-            const int mx = mx2[2 * i], second = mx2[2 * i + 1];
-            if (mx < 1000) continue;
-            r[cnt++] = (double)second / (double)mx;
-        }
+    for (size_t i = 0; i < vals.size() && cnt < rate_size; ++i) {
+        const int mx = (int)(uint32_t)(vals[i] >> 32), second = (int)(uint32_t)vals[i];
+        r[cnt++] = (double)second / (double)mx;
     }
     qsort(r, (size_t)cnt, sizeof(double), cmp_double);
     r[cnt] = r[cnt - 1];
@@ -1470,6 +1501,7 @@ int rc_submit(rc_ctx *c, const rc_batch *b, int slot)
     }
     sl.b = *b;
     sl.pb = nullptr;
+    sl.rb = nullptr;
     const size_t n1 = b->n;
     sl.total_reads = b->mode == 1 ? 2 * n1 : n1;
     sl.bytes1 = n1 ? b->off[n1] : 0;
@@ -1603,8 +1635,8 @@ int rc_wait(rc_ctx *c, int slot)
         return RC_ERR_STATE;
     }
     rc_slot &sl = ctx->slots[slot];
-    if (sl.pb) {
-        rc_set_error(ctx, "wait: slot %d holds a packed batch (rc_wait_packed)", slot);
+    if (sl.pb || sl.rb) {
+        rc_set_error(ctx, "wait: slot %d holds a packed batch (rc_wait_packed / rc_wait_resident)", slot);
         return RC_ERR_STATE;
     }
     sl.busy = false;
@@ -1691,6 +1723,7 @@ int rc_submit_packed(rc_ctx *c, rc_packed_batch *b, int slot)
     const size_t total = b->mode == 1 ? 2 * b->n : b->n, nbytes = (size_t)b->nbytes;
     b->n_fix = 0;
     sl.pb = b;
+    sl.rb = nullptr;
     sl.b.n = b->n;
     sl.total_reads = total;
     if (total == 0) {
@@ -1861,6 +1894,181 @@ int rc_wait_packed(rc_ctx *c, int slot)
     if (!sl.fix_pinned && n_fix) {
         memcpy(b->fix_pos, o_pos, (size_t)n_fix * 4);
         memcpy(b->fix_chr, o_chr, n_fix);
+    }
+    b->n_fix = n_fix;
+    return RC_OK;
+}
+
+int rc_submit_resident(rc_ctx *c, rc_resident_batch *b, int slot)
+{
+    if (!c || !b || slot < 0 || slot >= RC_MAX_SLOTS) return RC_ERR_ARG;
+    rc_ctx_full *ctx = static_cast<rc_ctx_full *>(c);
+    if (b->mode < 0 || b->mode > 2 || (b->n && (!b->off || !b->ret || !b->l || !b->m || !b->h)) || (b->fix_cap && (!b->fix_pos || !b->fix_chr))) {
+        rc_set_error(ctx, "submit_resident: bad batch descriptor");
+        return RC_ERR_ARG;
+    }
+    RC_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = slots_init(ctx);
+    if (rc) return rc;
+    rc_slot &sl = ctx->slots[slot];
+    if (sl.busy) {
+        rc_set_error(ctx, "submit_resident: slot %d still holds a batch (wait for it first)", slot);
+        return RC_ERR_STATE;
+    }
+    const size_t total = b->mode == 1 ? 2 * b->n : b->n;
+    const uint64_t bytes_b = b->mode == 1 ? b->bytes_b : 0;
+    const size_t nbytes = (size_t)(b->bytes_a + bytes_b);
+    b->n_fix = 0;
+    sl.pb = nullptr;
+    sl.rb = b;
+    sl.b.n = b->n;
+    sl.total_reads = total;
+    if (total == 0) {
+        sl.busy = true;
+        return RC_OK;
+    }
+    if (b->bytes_a + bytes_b >= (1ull << 32) || total >= (1ull << 32) || b->fix_cap >= (1ull << 32)) {
+        rc_set_error(ctx, "submit_resident: batch too large (split it)");
+        return RC_ERR_ARG;
+    }
+    if (b->mode != 0 && (total & 1)) {
+        rc_set_error(ctx, "submit_resident: %s mode needs an even number of reads", b->mode == 1 ? "paired" : "interleaved");
+        return RC_ERR_ARG;
+    }
+    const size_t n_kept = ctx->kept_arenas.size();
+    auto in_range = [&](int idx, uint64_t begin, uint64_t bytes) {
+        return idx >= 0 && (size_t)idx < n_kept && begin <= ctx->kept_arenas[(size_t)idx].bytes && bytes <= ctx->kept_arenas[(size_t)idx].bytes - begin;
+    };
+    if (!in_range(b->arena_a, b->begin_a, b->bytes_a) || (b->mode == 1 && !in_range(b->arena_b, b->begin_b, b->bytes_b))) {
+        rc_set_error(ctx, "submit_resident: no such range of a kept arena (%zu kept; rc_table_count_keep before counting)", n_kept);
+        return RC_ERR_ARG;
+    }
+    if (b->off[total] != nbytes || (b->mode == 1 && b->off[b->n] != b->bytes_a)) {
+        rc_set_error(ctx, "submit_resident: the offsets do not describe the ranges (off[%zu] = %u, %zu bytes)", total, b->off[total], nbytes);
+        return RC_ERR_ARG;
+    }
+    if (!ctx->d_buckets) {
+        rc_set_error(ctx, "correct: no k-mer table loaded");
+        return RC_ERR_STATE;
+    }
+    int max_len = 0;
+    for (size_t i = 0; i < total; ++i) max_len = std::max(max_len, (int)(b->off[i + 1] - b->off[i]) - 1);
+    const size_t qb = (nbytes + 7) / 8;
+    const uint32_t cap = (uint32_t)b->fix_cap;
+    if ((rc = rc_dbuf_reserve(ctx, &sl.d_seq, ((nbytes + 15) & ~(size_t)15) + 64))) return rc;
+    if ((rc = rc_dbuf_reserve(ctx, &sl.d_qual, (b->qual_bits ? qb : nbytes) + 64))) return rc;
+    if ((rc = rc_dbuf_reserve(ctx, &sl.d_off, (total + 1) * 4))) return rc;
+    if ((rc = rc_dbuf_reserve(ctx, &sl.d_res, total * 16))) return rc;
+    if ((rc = rc_dbuf_reserve(ctx, &sl.d_fix, 64))) return rc;
+    if ((rc = hbuf_reserve(ctx, &sl.p_nfix, 64))) return rc;
+    const bool in_pinned = is_pinned(b->off, (total + 1) * 4) && (!b->qual_bits || is_pinned(b->qual_bits, qb));
+    const uint32_t *h_off = b->off;
+    const uint8_t *h_qb = b->qual_bits;
+    if (!in_pinned) {
+        const size_t o_qb = ((total + 1) * 4 + 63) & ~(size_t)63;
+        if ((rc = hbuf_reserve(ctx, &sl.p_in, o_qb + qb + 64))) return rc;
+        char *s = (char *)sl.p_in.p;
+        memcpy(s, b->off, (total + 1) * 4);
+        if (b->qual_bits) memcpy(s + o_qb, b->qual_bits, qb);
+        h_off = (const uint32_t *)s;
+        h_qb = b->qual_bits ? (const uint8_t *)(s + o_qb) : nullptr;
+    }
+    sl.res_pinned = is_pinned(b->ret, total * 4) && is_pinned(b->l, total * 4) && is_pinned(b->m, total * 4) && is_pinned(b->h, total * 4);
+    sl.fix_pinned = !cap || (is_pinned(b->fix_pos, (size_t)cap * 4) && is_pinned(b->fix_chr, cap));
+    sl.fix_room = cap;
+    if (!sl.res_pinned && (rc = hbuf_reserve(ctx, &sl.p_res, total * 16))) return rc;
+    if (!sl.fix_pinned && (rc = hbuf_reserve(ctx, &sl.p_fix, (size_t)cap * 5 + 64))) return rc;
+    struct drain_on_error {
+        rc_ctx *c;
+        bool armed = true;
+        ~drain_on_error()
+        {
+            if (!armed) return;
+            (void)hipStreamSynchronize(c->s_h2d);
+            (void)hipStreamSynchronize(c->stream);
+            (void)hipStreamSynchronize(c->s_d2h);
+        }
+    } guard{ctx};
+    if (h_qb) RC_CHECK_HIP(ctx, hipMemcpyAsync(sl.d_qual.p, h_qb, qb, hipMemcpyHostToDevice, ctx->s_h2d));
+    RC_CHECK_HIP(ctx, hipMemcpyAsync(sl.d_off.p, h_off, (total + 1) * 4, hipMemcpyHostToDevice, ctx->s_h2d));
+    RC_CHECK_HIP(ctx, hipEventRecord(sl.e_h2d, ctx->s_h2d));
+    RC_CHECK_HIP(ctx, hipStreamWaitEvent(ctx->stream, sl.e_h2d, 0));
+    // the batch's own arena: its ranges of the kept arenas, side by side
+    uint8_t *d_seq = (uint8_t *)sl.d_seq.p;
+    const uint8_t *orig_a = (const uint8_t *)ctx->kept_arenas[(size_t)b->arena_a].p + b->begin_a;
+    const uint8_t *orig_b = bytes_b ? (const uint8_t *)ctx->kept_arenas[(size_t)b->arena_b].p + b->begin_b : nullptr;
+    if (b->bytes_a) RC_CHECK_HIP(ctx, hipMemcpyAsync(d_seq, orig_a, b->bytes_a, hipMemcpyDeviceToDevice, ctx->stream));
+    if (bytes_b) RC_CHECK_HIP(ctx, hipMemcpyAsync(d_seq + b->bytes_a, orig_b, bytes_b, hipMemcpyDeviceToDevice, ctx->stream));
+    if (!h_qb) RC_CHECK_HIP(ctx, hipMemsetAsync(sl.d_qual.p, 0, nbytes, ctx->stream));  // FASTA: qual[0] == 0 (Reads.h:224-266)
+    int32_t *d_res = (int32_t *)sl.d_res.p;
+    rc_device_batch db;
+    db.mode = b->mode;
+    db.n_reads = (uint32_t)total;
+    db.nbytes = nbytes;
+    db.max_read_len = max_len;
+    db.d_seq = d_seq;
+    db.d_qual = (const uint8_t *)sl.d_qual.p;
+    db.d_off = (const uint32_t *)sl.d_off.p;
+    db.d_ret = d_res;
+    db.d_l = d_res + total;
+    db.d_m = d_res + 2 * total;
+    db.d_h = d_res + 3 * total;
+    if ((rc = correct_device_impl(ctx, &db, 0xFFFFFFFFu, 0, h_qb ? 1 : 0))) return rc;
+    void *dp = nullptr, *dc = nullptr;  // (the fix list goes straight into page-locked host memory, as in rc_submit_packed)
+    if (cap) {
+        RC_CHECK_HIP(ctx, hipHostGetDevicePointer(&dp, sl.fix_pinned ? (void *)b->fix_pos : sl.p_fix.p, 0));
+        RC_CHECK_HIP(ctx, hipHostGetDevicePointer(&dc, sl.fix_pinned ? (void *)b->fix_chr : (void *)((char *)sl.p_fix.p + (size_t)cap * 4), 0));
+    }
+    uint32_t *d_nfix = (uint32_t *)sl.d_fix.p;
+    if ((rc = rc_launch_fix_list_bytes(ctx, orig_a, (size_t)b->bytes_a, orig_b, (size_t)bytes_b, d_seq, d_nfix, cap, (uint32_t *)dp, (uint8_t *)dc))) return rc;
+    RC_CHECK_HIP(ctx, hipEventRecord(sl.e_k, ctx->stream));
+    RC_CHECK_HIP(ctx, hipStreamWaitEvent(ctx->s_d2h, sl.e_k, 0));
+    RC_CHECK_HIP(ctx, hipMemcpyAsync(sl.p_nfix.p, d_nfix, 4, hipMemcpyDeviceToHost, ctx->s_d2h));
+    if (sl.res_pinned) {
+        RC_CHECK_HIP(ctx, hipMemcpyAsync(b->ret, db.d_ret, total * 4, hipMemcpyDeviceToHost, ctx->s_d2h));
+        RC_CHECK_HIP(ctx, hipMemcpyAsync(b->l, db.d_l, total * 4, hipMemcpyDeviceToHost, ctx->s_d2h));
+        RC_CHECK_HIP(ctx, hipMemcpyAsync(b->m, db.d_m, total * 4, hipMemcpyDeviceToHost, ctx->s_d2h));
+        RC_CHECK_HIP(ctx, hipMemcpyAsync(b->h, db.d_h, total * 4, hipMemcpyDeviceToHost, ctx->s_d2h));
+    } else {
+        RC_CHECK_HIP(ctx, hipMemcpyAsync(sl.p_res.p, d_res, total * 16, hipMemcpyDeviceToHost, ctx->s_d2h));
+    }
+    RC_CHECK_HIP(ctx, hipEventRecord(sl.e_done, ctx->s_d2h));
+    guard.armed = false;
+    sl.busy = true;
+    return RC_OK;
+}
+
+int rc_wait_resident(rc_ctx *c, int slot)
+{
+    if (!c || slot < 0 || slot >= RC_MAX_SLOTS) return RC_ERR_ARG;
+    rc_ctx_full *ctx = static_cast<rc_ctx_full *>(c);
+    if (!ctx->slots || !ctx->slots[slot].busy || !ctx->slots[slot].rb) {
+        rc_set_error(ctx, "wait_resident: slot %d holds no resident batch", slot);
+        return RC_ERR_STATE;
+    }
+    rc_slot &sl = ctx->slots[slot];
+    rc_resident_batch *b = sl.rb;
+    sl.busy = false;
+    sl.rb = nullptr;
+    const size_t total = sl.total_reads;
+    if (total == 0) return RC_OK;
+    RC_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    RC_CHECK_HIP(ctx, hipEventSynchronize(sl.e_done));
+    const uint32_t n_fix = *(const volatile uint32_t *)sl.p_nfix.p, cap = sl.fix_room;
+    if (n_fix > cap) {
+        rc_set_error(ctx, "wait_resident: %u substitutions, room for %u (fix_cap)", n_fix, cap);
+        return RC_ERR_ARG;
+    }
+    if (!sl.res_pinned) {
+        const int32_t *r = (const int32_t *)sl.p_res.p;
+        memcpy(b->ret, r, total * 4);
+        memcpy(b->l, r + total, total * 4);
+        memcpy(b->m, r + 2 * total, total * 4);
+        memcpy(b->h, r + 3 * total, total * 4);
+    }
+    if (!sl.fix_pinned && n_fix) {
+        memcpy(b->fix_pos, sl.p_fix.p, (size_t)n_fix * 4);
+        memcpy(b->fix_chr, (const uint8_t *)sl.p_fix.p + (size_t)cap * 4, n_fix);
     }
     b->n_fix = n_fix;
     return RC_OK;

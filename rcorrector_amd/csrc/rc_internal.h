@@ -95,6 +95,10 @@ struct rc_ctx {
     std::vector<rc_dbuf> cnt_arenas;
     size_t cnt_total = 0;  // bytes
     bool cnt_active = false;
+    // rc_table_count_keep(on): finish() leaves the arenas here instead of releasing them -- the reads of a data set
+    // that was counted on this GPU are corrected where they lie (rc_submit_resident)
+    bool cnt_keep = false;
+    std::vector<rc_dbuf> kept_arenas;
 
     // batch scratch
     rc_dbuf counts;   // int32 per arena byte
@@ -150,12 +154,15 @@ int rc_launch_canonicalize(rc_ctx *ctx, uint64_t *d_codes, size_t n);
 int rc_launch_lookup(rc_ctx *ctx, const uint64_t *d_codes, size_t n, int32_t *d_out);
 int rc_launch_probe(rc_ctx *ctx, const uint8_t *d_seq, size_t nbytes, int32_t *d_counts);
 int rc_count_begin(rc_ctx *ctx);
+void rc_kept_release(rc_ctx *ctx);
 int rc_count_add(rc_ctx *ctx, const uint8_t *seq, size_t nbytes, bool from_device);
 int rc_count_finish(rc_ctx *ctx, int min_count, int64_t *n_kmers);
 int rc_count_reads(rc_ctx *ctx, const uint8_t *d_seq, size_t nbytes, int min_count, int64_t *n_kmers);
 int rc_launch_selftest_bound(rc_ctx *ctx, const int32_t *d_c, size_t n, double e, int32_t *d_oi, double *d_od);
 int rc_launch_export(rc_ctx *ctx, uint64_t *d_codes, int32_t *d_counts, unsigned long long *d_n, size_t cap);
 int rc_table_entries_in_dump_order(rc_ctx *ctx, std::vector<uint64_t> *codes, std::vector<int32_t> *counts);
+int rc_error_rate_candidates(rc_ctx *ctx, const uint64_t *d_codes, size_t n, bool by_hash, size_t want, std::vector<uint64_t> *vals);
+int rc_table_codes_device(rc_ctx *ctx, uint64_t **d_codes, size_t *n);
 int rc_launch_last_base_variants(rc_ctx *ctx, const uint64_t *d_codes, size_t n, int32_t *d_max2);
 int rc_launch_digest(rc_ctx *ctx, unsigned long long *d_out);
 int rc_launch_locality_order(rc_ctx *ctx, const struct rc_device_batch_args &a, size_t nbytes);
@@ -196,6 +203,8 @@ int rc_launch_kmer_info(rc_ctx *ctx, const rc_device_batch_args &a);
 // rc_transport.hip: the packed boundary (include/rcorrector_amd.h: rc_packed_batch)
 int rc_launch_unpack(rc_ctx *ctx, const uint32_t *d_packed, size_t nbytes, const uint32_t *d_off, uint32_t n_reads, const uint32_t *d_exc_pos,
                      const uint8_t *d_exc_chr, uint32_t n_exc, uint8_t *d_seq);
+int rc_launch_fix_list_bytes(rc_ctx *ctx, const uint8_t *d_orig_a, size_t bytes_a, const uint8_t *d_orig_b, size_t bytes_b, const uint8_t *d_seq,
+                              uint32_t *d_n_fix, uint32_t cap, uint32_t *d_fix_pos, uint8_t *d_fix_chr);
 int rc_launch_fix_list(rc_ctx *ctx, const uint32_t *d_packed, size_t nbytes, const uint8_t *d_seq, const uint32_t *d_exc_pos, uint32_t n_exc,
                        uint32_t *d_n_fix, uint32_t cap, uint32_t *d_fix_pos, uint8_t *d_fix_chr);
 

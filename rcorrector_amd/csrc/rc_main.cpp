@@ -27,9 +27,11 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
+#include <emmintrin.h>
 
 #include <algorithm>
 #include <chrono>
@@ -70,6 +72,16 @@ static void timing_add(double &acc, double dt)
 static double now_s()
 {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// RC_TIMING with RC_T0=<seconds since the epoch at which the caller started this process>: where the process is on the
+// caller's clock (process start, HIP initialisation and the exit are outside the phases the other lines time)
+static void stamp(const char *what)
+{
+    static const char *e = getenv("RC_T0");
+    if (!g_timing || !e) return;
+    const double t = std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count();
+    fprintf(stderr, "[rc timing] +%.3f s %s\n", t - atof(e), what);
 }
 
 static void die(const char *fmt, ...)
@@ -202,26 +214,84 @@ static void parallel_for(size_t n, F fn)
     g_pool.run(T, [&](size_t t) { fn(n * t / T, n * (t + 1) / T); });
 }
 
+// Buffers of megabytes come straight from mmap with transparent huge pages asked for (the host's THP mode is "madvise"):
+// a run touches tens of GB of fresh memory -- the text of every batch, arenas, output slices -- and with 4 KB pages the
+// page faults of the threads that fill them and the unmapping at the end (0.3 s per 10 GB after _exit) are a visible share
+// of a run that takes two seconds.
+static const size_t BIG = (size_t)4 << 20;
+static void *big_alloc(size_t n, size_t *cap)
+{
+    const size_t c = (n + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+    void *p = mmap(nullptr, c, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (p == MAP_FAILED) {
+        fprintf(stderr, "rcorrector: out of memory (%zu bytes)\n", c);
+        exit(1);
+    }
+    (void)madvise(p, c, MADV_HUGEPAGE);
+    *cap = c;
+    return p;
+}
+
 // growable byte buffer without value-initialisation (a std::vector<char> zero-fills on resize,
 // which at GB/s rates is a pass over memory of its own); contents survive growth
 struct Buf {
     char *p = nullptr;
     size_t cap = 0;
+    bool big = false;
     Buf() = default;
     Buf(const Buf &) = delete;
     Buf &operator=(const Buf &) = delete;
-    Buf(Buf &&o) noexcept : p(o.p), cap(o.cap)
+    Buf(Buf &&o) noexcept : p(o.p), cap(o.cap), big(o.big)
     {
         o.p = nullptr;
         o.cap = 0;
+        o.big = false;
     }
-    ~Buf() { free(p); }
+    ~Buf() { release(); }
+    void release()
+    {
+        if (big)
+            munmap(p, cap);
+        else
+            free(p);
+        p = nullptr;
+        cap = 0;
+        big = false;
+    }
+    void swap(Buf &o)
+    {
+        std::swap(p, o.p);
+        std::swap(cap, o.cap);
+        std::swap(big, o.big);
+    }
     char *data() { return p; }
     const char *data() const { return p; }
     void need(size_t n)
     {
         if (n <= cap) return;
         const size_t nc = std::max(n, cap + cap / 2);
+        if (nc >= BIG) {
+            if (big) {  // (moves page tables, not bytes)
+                const size_t c = (nc + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+                void *q = mremap(p, cap, c, MREMAP_MAYMOVE);
+                if (q == MAP_FAILED) {
+                    fprintf(stderr, "rcorrector: out of memory (%zu bytes)\n", c);
+                    exit(1);
+                }
+                (void)madvise(q, c, MADV_HUGEPAGE);
+                p = (char *)q;
+                cap = c;
+                return;
+            }
+            size_t c = 0;
+            char *q = (char *)big_alloc(nc, &c);
+            if (cap) memcpy(q, p, cap);
+            free(p);
+            p = q;
+            cap = c;
+            big = true;
+            return;
+        }
         p = (char *)realloc(p, nc);
         if (!p) {
             fprintf(stderr, "rcorrector: out of memory (%zu bytes)\n", nc);
@@ -231,37 +301,47 @@ struct Buf {
     }
 };
 
-// A batch arena the DMA engines read and write directly: ordinary heap memory, page-locked through
+// A batch arena the DMA engines read and write directly: ordinary memory, page-locked through
 // the library (rc_host_register) whenever it is (re)allocated.  Jobs are recycled through a pool,
 // so the registration is paid a handful of times per run.
 struct PinBuf {
     char *p = nullptr;
     size_t cap = 0;
-    bool pinned = false;
+    bool pinned = false, big = false;
     PinBuf() = default;
     PinBuf(const PinBuf &) = delete;
     PinBuf &operator=(const PinBuf &) = delete;
-    ~PinBuf()
+    ~PinBuf() { release(); }
+    void release()
     {
         if (pinned) rc_host_unregister(p);
-        free(p);
+        if (big)
+            munmap(p, cap);
+        else
+            free(p);
+        p = nullptr;
+        cap = 0;
+        pinned = big = false;
     }
     char *data() { return p; }
     const char *data() const { return p; }
     void need(size_t n)
     {
         if (n <= cap) return;
-        if (pinned) rc_host_unregister(p);
-        pinned = false;
-        free(p);  // (the old content is never needed: an arena is packed from scratch)
-        const size_t nc = std::max(n + (n >> 3) + (1u << 16), cap + cap / 2);
-        p = (char *)aligned_alloc(4096, (nc + 4095) & ~(size_t)4095);
-        if (!p) {
-            fprintf(stderr, "rcorrector: out of memory (%zu bytes)\n", nc);
-            exit(1);
+        const size_t want = std::max(n + (n >> 3) + (1u << 16), cap + cap / 2);
+        release();  // (the old content is never needed: an arena is packed from scratch)
+        if (want >= BIG) {
+            p = (char *)big_alloc(want, &cap);
+            big = true;
+        } else {
+            cap = (want + 4095) & ~(size_t)4095;
+            p = (char *)aligned_alloc(4096, cap);
+            if (!p) {
+                fprintf(stderr, "rcorrector: out of memory (%zu bytes)\n", cap);
+                exit(1);
+            }
         }
-        cap = nc;
-        pinned = rc_host_register(p, (nc + 4095) & ~(size_t)4095) == 0;  // not pinned: the library stages the copy
+        pinned = rc_host_register(p, cap) == 0;  // not pinned: the library stages the copy
     }
 };
 
@@ -275,6 +355,7 @@ struct Source {
     size_t left_len = 0;
     off_t pos = 0;  // file offset of the next unread byte (seekable files)
     bool eof = false;
+    double per_line = 0;  // bytes per line of the last block: sizes the next block's buffer in one go
 
     void open(const std::string &p)
     {
@@ -363,6 +444,13 @@ struct Block {
     std::vector<uint32_t> line;  // line i = text[line[i] .. line[i+1]-1), without its '\n'
     size_t records = 0;
     bool unterminated_last = false;  // the file ended without a newline: the last line got one here
+    void swap(Block &o)
+    {
+        text.swap(o.text);
+        line.swap(o.line);
+        std::swap(records, o.records);
+        std::swap(unterminated_last, o.unterminated_last);
+    }
 };
 
 // positions of the '\n' bytes of p[lo, hi), appended to nl in ascending order
@@ -418,6 +506,9 @@ static void take_records(Source &s, size_t max_records, int lines_per_record, Bl
         if (s.eof) break;
         if (have >= (1ull << 31)) die("ERROR: %s: a batch exceeds 2 GiB of text; lower -batch\n", s.path.c_str());
         size_t want = (size_t)32 << 20;
+        if (nl.size() < 64 && s.per_line > 0 && want_lines > nl.size()) {
+            want = (size_t)(s.per_line * (double)(want_lines - nl.size()) * 1.01 + 65536.0);
+        }
         if (nl.size() >= 64) {  // bytes per line so far -> what the missing lines should need, plus 2 %
             const double per_line = (double)have / (double)nl.size();
             want = (size_t)(per_line * (double)(want_lines - nl.size()) * 1.02) + (1u << 16);
@@ -452,6 +543,7 @@ static void take_records(Source &s, size_t max_records, int lines_per_record, Bl
         }
     }
     b.records = n_lines / (size_t)lines_per_record;
+    if (n_lines >= 64) s.per_line = (double)end / (double)n_lines;
     if (have > end) {  // the tail behind the block waits in the source for the next call
         s.left.need(have - end);
         memcpy(s.left.p, b.text.p + end, have - end);
@@ -594,7 +686,11 @@ struct Arena {  // one file's share of a batch
     int lpr = 4;  // lines per record
     PinBuf seq, qual;
     std::vector<uint32_t> off;
+    // resident batches (the reads are in HBM since they were counted): there is no byte arena here, the fixes are applied
+    // to the sequence lines of the text itself
+    bool seq_in_text = false;
     size_t n() const { return blk.records; }
+    const char *sequence(size_t r) const { return seq_in_text ? blk.text.data() + blk.line[r * (size_t)lpr + 1] : seq.data() + off[r]; }
     const char *line(size_t rec, int which, uint32_t *len) const
     {
         const size_t li = rec * (size_t)lpr + (size_t)which;
@@ -610,6 +706,8 @@ struct Job {
     Arena a, b;
     std::vector<int32_t> ret, l, m, h;
     std::vector<int32_t> tr_before, tr_after, tr_flags, tr_niter, tr_iter;  // -verbose only
+    bool resident = false;        // the batch's reads are arenas the k-mer counter kept in HBM (rc_submit_resident)
+    int arena_a = 0, arena_b = 0;
     // -packed: the batch as rc_packed_batch wants it (one offset array over both arenas, 2-bit codes, quality bits, the
     // letters outside ACGT) and the room for the fix list
     PinBuf pk_off, pk_bases, pk_qbits, pk_exc_pos, pk_exc_chr, pk_fix_pos, pk_fix_chr;
@@ -621,7 +719,7 @@ struct Job {
 
 // Reads.h:224-266 for a whole block: sequence -> NUL-terminated arena, quality cut / padded to the
 // sequence length for the kernels (the output prints the quality line verbatim, see put_record)
-static void pack_arena(Arena &A, const std::string &path)
+static uint64_t index_arena(Arena &A, const std::string &path)
 {
     const size_t n = A.n();
     A.off.resize(n + 1);
@@ -638,6 +736,28 @@ static void pack_arena(Arena &A, const std::string &path)
         A.off[r + 1] = (uint32_t)total;
     }
     if (total >= (1ull << 32)) die("ERROR: batch too large; lower -batch\n");
+    return total;
+}
+
+// the sequences alone, NUL-terminated, at dst (A.off must be set): what the k-mer counter is given
+static void pack_sequences(const Arena &A, char *dst)
+{
+    parallel_for(A.n(), [&](size_t lo, size_t hi) {
+        for (size_t r = lo; r < hi; ++r) {
+            uint32_t sl;
+            const char *s = A.line(r, 1, &sl);
+            char *d = dst + A.off[r];
+            memcpy(d, s, sl);
+            d[sl] = 0;
+        }
+    });
+}
+
+static void pack_arena(Arena &A, const std::string &path)
+{
+    const size_t n = A.n();
+    const uint64_t total = index_arena(A, path);
+    A.seq_in_text = false;
     A.seq.need(total);
     A.qual.need(total);
     parallel_for(n, [&](size_t lo, size_t hi) {
@@ -657,6 +777,93 @@ static void pack_arena(Arena &A, const std::string &path)
             memset(dq + qc, 0, sl + 1 - qc);
         }
     });
+}
+
+// Quality bits of a resident batch straight from the text: bit p of the batch's arena (arena 1's bytes, then arena 2's)
+// = the quality character of that base is above the threshold; positions without one (the NUL behind a read, a
+// quality line shorter than its sequence: pack_arena pads with 0) compare as 0.  [lo, hi) is a range of arena positions
+// that starts and ends at multiples of 8 (or at the arena's end): ranges are packed side by side by different threads.
+// Returns false if a read with bases has no first quality character (qual[0] == 0 asks for the byte path,
+// ErrorCorrection.cpp:1316).
+struct QualView {
+    const Arena *A[2];
+    size_t bytes1;
+    size_t nbytes;
+};
+static bool pack_quality_bits_from_text(const QualView &V, char bad_q, size_t lo, size_t hi, uint8_t *bits)
+{
+    bool ok = true;
+    uint64_t acc = 0;
+    int nacc = 0;
+    uint8_t *out = bits + (lo >> 3);
+    auto put = [&](uint64_t v, int nb) {  // nb <= 16 bits at a time
+        acc |= v << nacc;
+        nacc += nb;
+        while (nacc >= 8) {
+            *out++ = (uint8_t)acc;
+            acc >>= 8;
+            nacc -= 8;
+        }
+    };
+    const __m128i thr = _mm_set1_epi8(bad_q);
+    const bool zero_above = (signed char)0 > (signed char)bad_q;  // (a negative threshold: the padding compares as "good")
+    size_t pos = lo;
+    while (pos < hi) {
+        const int sd = pos >= V.bytes1 ? 1 : 0;
+        const Arena &A = *V.A[sd];
+        const size_t base = sd ? V.bytes1 : 0, p = pos - base;
+        const size_t r = (size_t)(std::upper_bound(A.off.begin(), A.off.begin() + (ptrdiff_t)A.n() + 1, (uint32_t)p) - A.off.begin()) - 1;
+        const size_t end_side = std::min(hi, sd ? V.nbytes : V.bytes1);
+        for (size_t rr = r; rr < A.n() && base + A.off[rr] < end_side; ++rr) {
+            const uint32_t sl = A.off[rr + 1] - A.off[rr] - 1;
+            uint32_t ql = 0;
+            const char *q = A.line(rr, 3, &ql);
+            const uint32_t qc = std::min(ql, sl);
+            if (sl && (qc == 0 || q[0] == 0)) ok = false;
+            // this read's positions inside [lo, hi): characters j0 .. j1 - 1 of its sl + 1 bytes
+            const size_t r0 = base + A.off[rr];
+            const uint32_t j0 = r0 < pos ? (uint32_t)(pos - r0) : 0;
+            const uint32_t j1 = (uint32_t)std::min<size_t>(sl + 1, end_side - r0);
+            uint32_t j = j0;
+            while (j < j1) {
+                const uint32_t nb = std::min<uint32_t>(16, j1 - j);
+                uint32_t m = 0;
+                if (j < qc) {  // (the text buffer carries 64 bytes of slack behind its last line)
+                    m = (uint32_t)_mm_movemask_epi8(_mm_cmpgt_epi8(_mm_loadu_si128((const __m128i *)(q + j)), thr));
+                    if (qc - j < 16) {
+                        const uint32_t keep = (1u << (qc - j)) - 1u;
+                        m = (m & keep) | (zero_above ? (0xffffu & ~keep) : 0u);
+                    }
+                } else if (zero_above) {
+                    m = 0xffffu;
+                }
+                put(m & ((1u << nb) - 1u), (int)nb);
+                j += nb;
+            }
+            pos = r0 + j1;
+        }
+        if (pos < end_side) pos = end_side;  // (cannot happen: the reads tile the arena)
+    }
+    if (nacc) *out = (uint8_t)acc;
+    return ok;
+}
+
+// the substitutions of a resident batch, applied to the sequence lines of the text
+static void apply_fixes_to_text(Arena &A1, Arena *A2, size_t bytes1, const uint32_t *fix_pos, const uint8_t *fix_chr, size_t lo, size_t hi)
+{
+    for (size_t q = lo; q < hi; ++q) {
+        size_t p = fix_pos[q];
+        Arena &A = (A2 && p >= bytes1) ? *A2 : A1;
+        if (&A == A2) p -= bytes1;
+        const size_t n = A.n();
+        size_t r;
+        const uint32_t stride = A.off[1];
+        if ((uint64_t)stride * n == A.off[n] && A.off[p / stride] == (p / stride) * (size_t)stride && A.off[p / stride + 1] == (p / stride + 1) * (size_t)stride)
+            r = p / stride;  // reads of one length
+        else
+            r = (size_t)(std::upper_bound(A.off.begin(), A.off.begin() + (ptrdiff_t)n + 1, (uint32_t)p) - A.off.begin()) - 1;
+        A.blk.text.p[A.blk.line[r * (size_t)A.lpr + 1] + (p - A.off[r])] = (char)fix_chr[q];
+    }
 }
 
 static inline char *put_int(char *p, int v)
@@ -679,7 +886,7 @@ static inline void put_record(std::vector<char> &out, const Arena &A, size_t r, 
 {
     uint32_t il, ql = 0;
     const char *id = A.line(r, 0, &il);
-    const char *seq = A.seq.data() + A.off[r];
+    const char *seq = A.sequence(r);
     const uint32_t sl = A.off[r + 1] - A.off[r] - 1;
     const char *q = fastq ? A.line(r, 3, &ql) : nullptr;
     const size_t need = (size_t)il + sl + ql + 96;
@@ -855,6 +1062,127 @@ static void count_inputs(rc_ctx *ctx, const std::vector<std::pair<std::string, b
     if (rc_table_count_finish(ctx, 2, stored)) die("rcorrector: %s\n", rc_last_error(ctx));
 }
 
+// ---- one pass over the input (no -c, plain files that fit): what the counting pass read stays ------------------
+// The reference's pipeline reads every file twice -- jellyfish counts the k-mers (run_rcorrector.pl:262-281), stage 3
+// corrects -- and so does the counting pass above followed by the correction loop.  When the inputs are plain files that
+// fit (text in host memory, bases in HBM), the counting pass cuts them into the correction loop's batches right away:
+// the text and its line index stay here, the sequence arenas stay in HBM with the counter (rc_table_count_keep), and the
+// loop corrects them where they lie (rc_submit_resident): files are read, parsed and uploaded once.
+struct Retained {
+    int file = 0, mode = 0;
+    bool fastq = true;
+    int lpr_a = 4, lpr_b = 4;
+    Block a, b;
+    std::vector<uint32_t> off_a, off_b;
+    int arena_a = 0, arena_b = 0;
+};
+
+static void ingest_resident(rc_ctx *ctx, std::vector<ReadFile> &files, std::vector<ReadFile> &mates, size_t batch_reads,
+                            std::vector<std::unique_ptr<Retained>> &kept, int64_t *stored)
+{
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::unique_ptr<Retained>> q;
+    bool done = false;
+    std::thread reader([&]() {
+        for (size_t fi = 0; fi < files.size(); ++fi) {
+            ReadFile &f = files[fi];
+            for (;;) {
+                std::unique_ptr<Retained> R(new Retained);
+                R->file = (int)fi;
+                R->mode = f.paired ? 1 : (f.interleaved ? 2 : 0);
+                R->fastq = f.fastq;
+                R->lpr_a = f.fastq ? 4 : 2;
+                R->lpr_b = f.paired ? (mates[fi].fastq ? 4 : 2) : R->lpr_a;
+                const double tr0 = now_s();
+                if (f.paired) {
+                    std::thread mate([&]() { take_records(mates[fi].src, batch_reads, R->lpr_b, R->b); });
+                    take_records(f.src, batch_reads, R->lpr_a, R->a);
+                    mate.join();
+                    if (R->b.records != R->a.records) die("ERROR: The files are not paired!\n");
+                } else {
+                    take_records(f.src, batch_reads, R->lpr_a, R->a);
+                }
+                if (R->a.records == 0) break;
+                if (R->mode == 2 && (R->a.records & 1)) die("ERROR: interleaved file %s holds an odd number of reads\n", f.path.c_str());
+                g_t_read += now_s() - tr0;
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return q.size() < 3; });
+                q.emplace_back(std::move(R));
+                cv.notify_all();
+            }
+        }
+        std::lock_guard<std::mutex> lk(mu);
+        done = true;
+        cv.notify_all();
+    });
+    if (rc_table_count_keep(ctx, 1) || rc_table_count_begin(ctx)) die("rcorrector: %s\n", rc_last_error(ctx));
+    PinBuf stage;  // the sequences of one file's share of a batch on their way to HBM
+    int next_arena = 0;
+    for (;;) {
+        std::unique_ptr<Retained> R;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return done || !q.empty(); });
+            if (q.empty()) break;
+            R = std::move(q.front());
+            q.pop_front();
+            cv.notify_all();
+        }
+        const double tp0 = now_s();
+        for (int sd = 0; sd < (R->mode == 1 ? 2 : 1); ++sd) {
+            Arena A;  // (a view for index_arena / pack_sequences: the block is swapped in and out)
+            A.lpr = sd ? R->lpr_b : R->lpr_a;
+            A.blk.swap(sd ? R->b : R->a);
+            const uint64_t total = index_arena(A, sd ? mates[(size_t)R->file].path : files[(size_t)R->file].path);
+            stage.need(total + 64);
+            pack_sequences(A, stage.data());
+            // (an arena without a byte is not kept: cannot happen, every record has at least its NUL)
+            if (rc_table_count_add(ctx, stage.data(), total)) die("rcorrector: %s\n", rc_last_error(ctx));
+            (sd ? R->arena_b : R->arena_a) = next_arena++;
+            (sd ? R->off_b : R->off_a).swap(A.off);
+            A.blk.swap(sd ? R->b : R->a);
+        }
+        g_t_pack += now_s() - tp0;
+        kept.emplace_back(std::move(R));
+    }
+    reader.join();
+    stamp("inputs read, indexed and uploaded");
+    if (rc_table_count_finish(ctx, 2, stored)) die("rcorrector: %s\n", rc_last_error(ctx));
+    stamp("k-mers counted, table built");
+}
+
+// GetBadQuality's two histograms over the records of one block (main.cpp:88-128), at most `room` of them
+static void quality_histograms(const Block &b, int lpr, size_t room, std::vector<int32_t> &fh, std::vector<int32_t> &lh, int *total)
+{
+    static char qbuf[MAX_READ_LENGTH];  // Reads::qual, reused from record to record
+    for (size_t r = 0; r < b.records && r < room; ++r) {
+        const uint32_t *L = b.line.data() + r * (size_t)lpr;
+        const uint32_t sl = L[2] - L[1] - 1, ql = lpr == 4 ? L[4] - L[3] - 1 : 0;
+        ++*total;
+        if (lpr != 4) continue;
+        const char *q = b.text.data() + L[3];
+        // qual[strlen(seq)-1] and qual[0] as GetBadQuality sees them: Reads::Next reads every
+        // quality line into ONE reused buffer (bytes behind a short line keep what earlier
+        // records left there) and strips a newline only at index strlen(seq)
+        // (Reads.h:204-219); qual[-1], for an empty sequence, is the last byte of the
+        // sequence buffer in front of it, 0.
+        const uint32_t qn = std::min<uint32_t>(ql, MAX_READ_LENGTH - 1);
+        memcpy(qbuf, q, qn);
+        if (qn + 1 < MAX_READ_LENGTH) {
+            qbuf[qn] = '\n';
+            qbuf[qn + 1] = 0;
+        } else {
+            qbuf[qn] = 0;
+        }
+        if (sl < MAX_READ_LENGTH && qbuf[sl] == '\n') qbuf[sl] = 0;
+        const unsigned char lastq = sl ? (unsigned char)qbuf[sl - 1] : 0;
+        const unsigned char firstq = (unsigned char)qbuf[0];
+        ++lh[lastq];
+        ++fh[firstq];
+    }
+}
+
 static void print_help()
 {
     fprintf(stderr,
@@ -898,6 +1226,8 @@ int main(int argc, char **argv)
         print_help();
         return 0;
     }
+    g_timing = getenv("RC_TIMING") != nullptr;
+    stamp("main() entered");
     for (i = 1; i < argc; ++i) {  // main.cpp:165-247
         if (!strcmp("-r", argv[i]) || !strcmp("-i", argv[i]))
             ++i;
@@ -1020,25 +1350,61 @@ int main(int argc, char **argv)
         if (node >= 0 && bind_to_numa_node(node) && g_timing) fprintf(stderr, "[rc timing] host threads bound to NUMA node %d\n", node);
     }
     g_pool.start((size_t)g_threads * 2);  // (the reader, the mate's reader and the workers call it side by side)
+    stamp("contexts created (HIP initialised, scratch allocated)");
     const double t_start = now_s();
     // While the table loads: the batch buffers of the pipeline -- text blocks, page-locked arenas, output slices --
     // are allocated, sized from the head of the first input, touched and registered with the GPU runtime here, so
     // that the first batches do not pay for a few GB of page faults and hipHostRegister calls one after the other
     const size_t max_in_flight = (size_t)(nworkers + 2);
+    // One pass (see ingest_resident): no dump, one GPU, plain regular files whose text fits a third of the memory that is
+    // available and whose bases fit the counter's share of HBM.  RC_RESIDENT=0 keeps the two passes, =1 skips the size test.
+    bool resident = false;
+    std::vector<std::unique_ptr<Retained>> kept;
+    if (!dump && !verbose && gpus == 1 && !files.empty()) {
+        uint64_t text_bytes = 0;
+        bool plain = true;
+        for (size_t fi = 0; fi < files.size(); ++fi)
+            for (const ReadFile *f : {(const ReadFile *)&files[fi], files[fi].paired ? (const ReadFile *)&mates[fi] : (const ReadFile *)nullptr}) {
+                if (!f) continue;
+                struct stat st;
+                if (f->src.is_gz || !f->src.seekable || fstat(f->src.fd, &st) != 0) {
+                    plain = false;
+                    continue;
+                }
+                text_bytes += (uint64_t)st.st_size;
+            }
+        uint64_t avail = 0;
+        if (FILE *mi = fopen("/proc/meminfo", "r")) {
+            char ln[256];
+            while (fgets(ln, sizeof ln, mi))
+                if (!strncmp(ln, "MemAvailable:", 13)) avail = (uint64_t)atoll(ln + 13) << 10;
+            fclose(mi);
+        }
+        const char *e = getenv("RC_RESIDENT");
+        resident = plain && (e ? atoi(e) != 0 : (text_bytes <= avail / 3 && text_bytes / 2 <= ((uint64_t)96 << 30)));
+        if (e && atoi(e) > 1) batch_reads = std::max<size_t>(2, (size_t)atoi(e)) & ~(size_t)1;  // (tests: RC_RESIDENT=<batch size>)
+    }
     std::vector<std::shared_ptr<Job>> warm_jobs;
+    // (the head of the first file is looked at here, not in the thread: the one-pass reader takes it out of the source)
+    size_t head_nl = 0, head_last = 0, head_seq_len = 0;
+    if (!files.empty() && !verbose && !files[0].src.is_gz && files[0].src.seekable) {
+        const ReadFile &f = files[0];
+        const int lpr = f.fastq ? 4 : 2;
+        const char *h = f.src.left.p;
+        size_t l1 = 0;
+        for (size_t i = 0; i < f.src.left_len; ++i)
+            if (h[i] == '\n') {
+                ++head_nl;
+                if (head_nl == 1) l1 = i;
+                if (head_nl == 2) head_seq_len = i - l1 - 1;
+                if (head_nl % (size_t)lpr == 0) head_last = i + 1;
+            }
+    }
     std::thread warm([&]() {
         if (files.empty() || verbose || files[0].src.is_gz || !files[0].src.seekable) return;
         const ReadFile &f = files[0];
         const int lpr = f.fastq ? 4 : 2;
-        const char *h = f.src.left.p;
-        size_t nl = 0, last = 0, seq_len = 0, l1 = 0;
-        for (size_t i = 0; i < f.src.left_len; ++i)
-            if (h[i] == '\n') {
-                ++nl;
-                if (nl == 1) l1 = i;
-                if (nl == 2) seq_len = i - l1 - 1;
-                if (nl % (size_t)lpr == 0) last = i + 1;
-            }
+        const size_t nl = head_nl, last = head_last, seq_len = head_seq_len;
         if (last == 0 || seq_len == 0) return;
         const double rec_bytes = (double)last / (double)(nl / (size_t)lpr);
         struct stat st;
@@ -1058,11 +1424,13 @@ int main(int argc, char **argv)
             const int sides = f.paired ? 2 : 1;
             for (int sd = 0; sd < sides; ++sd) {
                 Arena &A = sd ? j->b : j->a;
-                A.blk.text.need(text_bytes);
-                A.blk.line.reserve(recs * (size_t)lpr + 8);
-                A.off.reserve(recs + 1);
-                A.seq.need(arena_bytes);   // (page-locked here: rc_host_register)
-                A.qual.need(arena_bytes);
+                if (!resident) {
+                    A.blk.text.need(text_bytes);
+                    A.blk.line.reserve(recs * (size_t)lpr + 8);
+                    A.off.reserve(recs + 1);
+                    A.seq.need(arena_bytes);   // (page-locked here: rc_host_register)
+                    A.qual.need(arena_bytes);
+                }
                 std::vector<std::vector<char>> &o = sd ? j->o2 : j->o1;
                 o.resize(S);
                 for (auto &v : o) v.reserve(out_slice);
@@ -1072,7 +1440,7 @@ int main(int argc, char **argv)
                 for (int sd = 0; sd < sides; ++sd) {
                     Arena &A = sd ? j->b : j->a;
                     const size_t lo = text_bytes * t / 16, hi = text_bytes * (t + 1) / 16;
-                    memset(A.blk.text.p + lo, 0, hi - lo);
+                    if (!resident) memset(A.blk.text.p + lo, 0, hi - lo);
                     std::vector<std::vector<char>> &o = sd ? j->o2 : j->o1;
                     for (size_t s2 = t; s2 < S; s2 += 16) {
                         o[s2].resize(out_slice);
@@ -1081,6 +1449,13 @@ int main(int argc, char **argv)
                 }
             });
             const size_t total = (size_t)sides * recs;
+            if (resident) {  // what a resident batch sends and receives (page-locked)
+                const size_t nb = (size_t)sides * arena_bytes;
+                j->pk_off.need((total + 1) * 4);
+                j->pk_qbits.need((nb + 7) / 8 + 64);
+                j->pk_fix_pos.need((nb / 4 + 64) * 4);
+                j->pk_fix_chr.need(nb / 4 + 64);
+            }
             j->ret.reserve(total);
             j->l.reserve(total);
             j->m.reserve(total);
@@ -1099,8 +1474,13 @@ int main(int argc, char **argv)
             inputs.emplace_back(files[fi].path, files[fi].fastq);
             if (files[fi].paired) inputs.emplace_back(mates[fi].path, mates[fi].fastq);
         }
-        count_inputs(ctx[0], inputs, &stored);
-        if (g_timing) fprintf(stderr, "[rc timing] k-mer counting pass over %zu file(s): %.2f s\n", inputs.size(), now_s() - t_start);
+        if (resident)
+            ingest_resident(ctx[0], files, mates, batch_reads, kept, &stored);
+        else
+            count_inputs(ctx[0], inputs, &stored);
+        if (g_timing)
+            fprintf(stderr, "[rc timing] k-mer counting pass over %zu file(s): %.2f s%s\n", inputs.size(), now_s() - t_start,
+                    resident ? " (one pass: the text stays in host memory, the bases in HBM)" : "");
     }
     if (gpus > 1) {  // replicate the bucket array device to device (xGMI) and make sure the replicas agree
         uint64_t d0 = 0;
@@ -1124,49 +1504,33 @@ int main(int argc, char **argv)
     if (!files.empty() && files[0].fastq) {
         std::vector<int32_t> fh(300, 0), lh(300, 0);
         int total = 0;
-        static char qbuf[MAX_READ_LENGTH];  // Reads::qual, reused from record to record
-        for (size_t fi = 0; fi < files.size() && total < 1000000; ++fi) {
-            Source s;
-            s.open(files[fi].path);
-            Block b;
-            const int lpr = files[fi].fastq ? 4 : 2;
-            while (total < 1000000) {
-                take_records(s, std::min<size_t>((size_t)(1000000 - total), (size_t)1 << 18), lpr, b);
-                if (b.records == 0) break;
-                for (size_t r = 0; r < b.records; ++r) {
-                    const uint32_t *L = b.line.data() + r * (size_t)lpr;
-                    const uint32_t sl = L[2] - L[1] - 1, ql = lpr == 4 ? L[4] - L[3] - 1 : 0;
-                    ++total;
-                    if (lpr != 4) continue;
-                    const char *q = b.text.data() + L[3];
-                    // qual[strlen(seq)-1] and qual[0] as GetBadQuality sees them: Reads::Next reads every
-                    // quality line into ONE reused buffer (bytes behind a short line keep what earlier
-                    // records left there) and strips a newline only at index strlen(seq)
-                    // (Reads.h:204-219); qual[-1], for an empty sequence, is the last byte of the
-                    // sequence buffer in front of it, 0.
-                    const uint32_t qn = std::min<uint32_t>(ql, MAX_READ_LENGTH - 1);
-                    memcpy(qbuf, q, qn);
-                    if (qn + 1 < MAX_READ_LENGTH) {
-                        qbuf[qn] = '\n';
-                        qbuf[qn + 1] = 0;
-                    } else {
-                        qbuf[qn] = 0;
-                    }
-                    if (sl < MAX_READ_LENGTH && qbuf[sl] == '\n') qbuf[sl] = 0;
-                    const unsigned char lastq = sl ? (unsigned char)qbuf[sl - 1] : 0;
-                    const unsigned char firstq = (unsigned char)qbuf[0];
-                    ++lh[lastq];
-                    ++fh[firstq];
-                }
+        if (resident) {  // the same records, from the blocks the counting pass kept (primary files, in order)
+            for (const auto &R : kept) {
+                if (total >= 1000000) break;
+                quality_histograms(R->a, R->lpr_a, (size_t)(1000000 - total), fh, lh, &total);
             }
-            s.close();
+        } else {
+            for (size_t fi = 0; fi < files.size() && total < 1000000; ++fi) {
+                Source s;
+                s.open(files[fi].path);
+                Block b;
+                const int lpr = files[fi].fastq ? 4 : 2;
+                while (total < 1000000) {
+                    take_records(s, std::min<size_t>((size_t)(1000000 - total), (size_t)1 << 18), lpr, b);
+                    if (b.records == 0) break;
+                    quality_histograms(b, lpr, b.records, fh, lh, &total);
+                }
+                s.close();
+            }
         }
         bad_q = rc_bad_quality_from_hist(fh.data(), lh.data(), total);
     }
     fprintf(stderr, "Bad quality threshold is '%c'\n", bad_q);
+    stamp("ERROR_RATE and bad quality known");
     for (int c = 0; c < nctx; ++c)
         if (rc_set_run_params(ctx[c], rate, bad_q)) die("rcorrector: %s\n", rc_last_error(ctx[c]));
     const double t_setup = now_s();
+    stamp("start-up done");
 
     // pipeline: reader (this thread) -> one worker per GPU -> writer thread (input order)
     std::mutex mu;
@@ -1176,6 +1540,7 @@ int main(int argc, char **argv)
     std::deque<std::shared_ptr<Job>> q;  // one queue for all workers: whichever context is free takes the next batch
     bool closing = false, reader_done = false;
     warm.join();
+    stamp("batch buffers ready");
     pool = warm_jobs;
 
     // the output records of a finished batch, formatted (and deflated for .gz outputs) in slices by
@@ -1241,15 +1606,78 @@ int main(int argc, char **argv)
                     q.pop_front();
                 }
                 const double tp0 = now_s();
-                pack_arena(j->a, files[(size_t)j->file].path);
-                if (j->mode == 1) pack_arena(j->b, mates[(size_t)j->file].path);
-                const double tp1 = now_s();
                 const size_t n = j->a.n();
                 const size_t total = j->mode == 1 ? 2 * n : n;
                 j->ret.assign(total, 0);
                 j->l.assign(total, 0);
                 j->m.assign(total, 0);
                 j->h.assign(total, 0);
+                bool resident_done = false;
+                int rrc = 0;
+                double tq1 = tp0;
+                if (j->resident) {
+                    // the reads are in HBM since they were counted: offsets and quality bits go down, the results and the
+                    // substitutions come back and are applied to the sequence lines of the text
+                    Job &J = *j;
+                    const size_t bytes1 = J.a.off[n], bytes2 = J.mode == 1 ? J.b.off[n] : 0, nbytes = bytes1 + bytes2;
+                    const size_t cap = nbytes / 4 + 64;
+                    J.pk_off.need((total + 1) * 4);
+                    J.pk_qbits.need((nbytes + 7) / 8 + 64);
+                    J.pk_fix_pos.need(cap * 4);
+                    J.pk_fix_chr.need(cap);
+                    uint32_t *off = (uint32_t *)J.pk_off.data();
+                    memcpy(off, J.a.off.data(), (n + 1) * 4);
+                    if (J.mode == 1)
+                        for (size_t r = 0; r <= n; ++r) off[n + r] = (uint32_t)bytes1 + J.b.off[r];
+                    bool bits_ok = true;
+                    if (J.fastq) {
+                        QualView V{{&J.a, J.mode == 1 ? &J.b : &J.a}, J.mode == 1 ? bytes1 : nbytes, nbytes};
+                        const size_t Q = std::max<size_t>(1, std::min<size_t>((size_t)g_threads, nbytes / 65536 + 1));
+                        std::vector<char> okv(Q, 1);
+                        g_pool.run(Q, [&](size_t t) {
+                            const size_t lo = (nbytes * t / Q) & ~(size_t)7, hi = t + 1 == Q ? nbytes : ((nbytes * (t + 1) / Q) & ~(size_t)7);
+                            if (lo < hi) okv[t] = pack_quality_bits_from_text(V, bad_q, lo, hi, (uint8_t *)J.pk_qbits.data()) ? 1 : 0;
+                        });
+                        for (char c : okv) bits_ok = bits_ok && c;
+                    }
+                    tq1 = now_s();
+                    if (bits_ok) {
+                        rc_resident_batch rb;
+                        memset(&rb, 0, sizeof rb);
+                        rb.mode = J.mode;
+                        rb.n = n;
+                        rb.arena_a = J.arena_a;
+                        rb.bytes_a = bytes1;
+                        rb.arena_b = J.arena_b;
+                        rb.bytes_b = bytes2;
+                        rb.off = off;
+                        rb.qual_bits = J.fastq ? (const uint8_t *)J.pk_qbits.data() : nullptr;
+                        rb.ret = J.ret.data();
+                        rb.l = J.l.data();
+                        rb.m = J.m.data();
+                        rb.h = J.h.data();
+                        rb.fix_pos = (uint32_t *)J.pk_fix_pos.data();
+                        rb.fix_chr = (uint8_t *)J.pk_fix_chr.data();
+                        rb.fix_cap = cap;
+                        {
+                            std::lock_guard<std::mutex> lk(submit_mu[(size_t)g]);
+                            rrc = rc_submit_resident(ctx[g], &rb, slot);
+                        }
+                        if (!rrc) rrc = rc_wait_resident(ctx[g], slot);
+                        if (!rrc && rb.n_fix) {  // positions are distinct: any number of threads
+                            const size_t F = std::max<size_t>(1, std::min<size_t>((size_t)g_threads, rb.n_fix / 16384 + 1));
+                            g_pool.run(F, [&](size_t t) {
+                                apply_fixes_to_text(J.a, J.mode == 1 ? &J.b : nullptr, bytes1, rb.fix_pos, rb.fix_chr, rb.n_fix * t / F, rb.n_fix * (t + 1) / F);
+                            });
+                        }
+                        resident_done = true;
+                    }
+                }
+                if (!resident_done) {
+                    pack_arena(j->a, files[(size_t)j->file].path);
+                    if (j->mode == 1) pack_arena(j->b, mates[(size_t)j->file].path);
+                }
+                const double tp1 = resident_done ? tq1 : now_s();
                 rc_batch rb;
                 memset(&rb, 0, sizeof rb);
                 rb.mode = j->mode;
@@ -1267,8 +1695,10 @@ int main(int argc, char **argv)
                 rb.m = j->m.data();
                 rb.h = j->h.data();
                 int rc;
-                const double tg0 = now_s();
-                if (g_verbose) {
+                const double tg0 = resident_done ? tq1 : now_s();
+                if (resident_done) {
+                    rc = rrc;
+                } else if (g_verbose) {
                     const size_t nbytes = (size_t)j->a.off[n] + (j->mode == 1 ? (size_t)j->b.off[n] : 0);
                     j->tr_before.assign(nbytes, 0);
                     j->tr_after.assign(nbytes, 0);
@@ -1491,7 +1921,45 @@ int main(int argc, char **argv)
     });
 
     // reader
-    {
+    if (resident) {  // the batches are here already: a pooled job takes over the next one's text, line index and offsets
+        for (auto &R : kept) {
+            std::shared_ptr<Job> j;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                const double tw = now_s();
+                cv.wait(lk, [&] { return order.size() < max_in_flight; });
+                g_w_reader += now_s() - tw;
+                if (!pool.empty()) {
+                    j = pool.back();
+                    pool.pop_back();
+                }
+            }
+            if (!j) j = std::make_shared<Job>();
+            j->file = R->file;
+            j->mode = R->mode;
+            j->fastq = R->fastq;
+            j->resident = true;
+            j->arena_a = R->arena_a;
+            j->arena_b = R->arena_b;
+            j->a.lpr = R->lpr_a;
+            j->b.lpr = R->lpr_b;
+            j->a.blk.swap(R->a);
+            j->a.off.swap(R->off_a);
+            j->a.seq_in_text = true;
+            if (R->mode == 1) {
+                j->b.blk.swap(R->b);
+                j->b.off.swap(R->off_b);
+                j->b.seq_in_text = true;
+            }
+            R.reset();  // (the text of the batch this job carried before: written, no longer needed)
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                order.push_back(j);
+                q.push_back(j);
+            }
+            cv.notify_all();
+        }
+    } else {
         int ramp = 0;
         for (size_t fi = 0; fi < files.size(); ++fi) {
             ReadFile &f = files[fi];
@@ -1547,6 +2015,7 @@ int main(int argc, char **argv)
     cv.notify_all();
     writer.join();
     const double t_loop_end = now_s();
+    stamp("last batch written");
     {
         std::lock_guard<std::mutex> lk(mu);
         closing = true;
@@ -1581,6 +2050,16 @@ int main(int argc, char **argv)
     if (g_timing)
         fprintf(stderr, "[rc timing] blocked: reader %.2f s (no free slot), workers %.2f s (no batch), writer %.2f s (next batch not done)\n", g_w_reader, g_w_worker, g_w_writer);
     fprintf(stderr, "Processed %llu reads\n\tCorrected %llu bases.\n", (unsigned long long)total_reads, (unsigned long long)total_cor);
+    stamp("outputs closed, leaving");
+    if (getenv("RC_TEARDOWN")) {  // dev: where the time between _exit and the parent's wait goes
+        pool.clear();
+        warm_jobs.clear();
+        order.clear();
+        q.clear();
+        stamp("teardown: job buffers unregistered and freed");
+        for (rc_ctx *c : ctx) rc_destroy(c);
+        stamp("teardown: contexts destroyed");
+    }
     fflush(NULL);
     _exit(0);  // every output is closed: skip unmapping gigabytes of buffers one by one
 }

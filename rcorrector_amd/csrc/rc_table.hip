@@ -350,6 +350,109 @@ int rc_launch_last_base_variants(rc_ctx *ctx, const uint64_t *d_codes, size_t n,
     return RC_OK;
 }
 
+// The entries the ERROR_RATE scan keeps (main.cpp:329-347: max >= 1000), picked on the device: of n dump entries only these
+// few matter, and only the first 100 000 of them in dump order.  out_key = the entry's place in that order (its index in
+// the file, or rc_dump_order_key of its code for a table that was counted here), out_val = max << 32 | second.  n_out
+// counts every kept entry, the arrays hold the first `cap` in no particular order (the caller sorts by key).
+__global__ __launch_bounds__(256) void k_error_rate_candidates(rc_table_view T, const uint64_t *__restrict__ codes, size_t n, int k, int by_hash,
+                                                               uint64_t *__restrict__ out_key, uint64_t *__restrict__ out_val,
+                                                               unsigned long long *__restrict__ n_out, size_t cap)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int mx = 0, second = 0;
+    uint64_t code = 0;
+    if (i < n) {
+        code = codes[i];
+        const uint64_t base = code & ~3ull;
+        for (int c = 0; c < 4; ++c) {
+            int cnt = rc_table_lookup(T, rc_canonical(base | (uint64_t)c, k));
+            if (cnt > mx) {
+                second = mx;
+                mx = cnt;
+            } else if (cnt > second)
+                second = cnt;
+        }
+    }
+    const bool keep = i < n && mx >= 1000;
+    const unsigned long long m = __ballot(keep);
+    if (!m) return;
+    const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+    unsigned long long base_at = 0;
+    if (lane == leader) base_at = atomicAdd(n_out, (unsigned long long)__popcll(m));
+    base_at = __shfl(base_at, leader, 64);
+    if (keep) {
+        const unsigned long long at = base_at + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
+        if (at < cap) {
+            out_key[at] = by_hash ? rc_dump_order_key(code) : (uint64_t)i;
+            out_val[at] = ((uint64_t)(uint32_t)mx << 32) | (uint32_t)second;
+        }
+    }
+}
+
+// the (max, second) pairs of the first `want` kept entries in dump order
+int rc_error_rate_candidates(rc_ctx *ctx, const uint64_t *d_codes, size_t n, bool by_hash, size_t want, std::vector<uint64_t> *vals)
+{
+    vals->clear();
+    if (n == 0) return RC_OK;
+    rc_dev_tmp b_key, b_val, b_key_s, b_val_s, b_n, b_tmp;
+    RC_CHECK_HIP(ctx, b_n.alloc(8));
+    size_t cap = std::min<size_t>(n, (size_t)4 << 20);
+    unsigned long long found = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        RC_CHECK_HIP(ctx, b_key.alloc(cap * 8));
+        RC_CHECK_HIP(ctx, b_val.alloc(cap * 8));
+        RC_CHECK_HIP(ctx, hipMemsetAsync(b_n.p, 0, 8, ctx->stream));
+        hipLaunchKernelGGL(k_error_rate_candidates, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, rc_view(ctx), d_codes, n, ctx->k, by_hash ? 1 : 0,
+                           b_key.as<uint64_t>(), b_val.as<uint64_t>(), b_n.as<unsigned long long>(), cap);
+        RC_CHECK_HIP(ctx, hipGetLastError());
+        RC_CHECK_HIP(ctx, hipMemcpyAsync(&found, b_n.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+        RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (found <= cap) break;
+        cap = (size_t)found;  // (a data set with millions of k-mers beyond 1000: once more with room for all of them)
+    }
+    const size_t m = (size_t)found;
+    if (m == 0) return RC_OK;
+    RC_CHECK_HIP(ctx, b_key_s.alloc(m * 8));
+    RC_CHECK_HIP(ctx, b_val_s.alloc(m * 8));
+    size_t t1 = 0;
+    RC_CHECK_HIP(ctx, rocprim::radix_sort_pairs(nullptr, t1, b_key.as<uint64_t>(), b_key_s.as<uint64_t>(), b_val.as<uint64_t>(), b_val_s.as<uint64_t>(), m, 0, 64, ctx->stream));
+    RC_CHECK_HIP(ctx, b_tmp.alloc(t1));
+    RC_CHECK_HIP(ctx, rocprim::radix_sort_pairs(b_tmp.p, t1, b_key.as<uint64_t>(), b_key_s.as<uint64_t>(), b_val.as<uint64_t>(), b_val_s.as<uint64_t>(), m, 0, 64, ctx->stream));
+    vals->resize(std::min(m, want));
+    RC_CHECK_HIP(ctx, hipMemcpyAsync(vals->data(), b_val_s.p, vals->size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RC_OK;
+}
+
+// the table's canonical codes in HBM, unspecified order: *d_codes is allocated here (hipFree it), *n = their number
+int rc_table_codes_device(rc_ctx *ctx, uint64_t **d_codes, size_t *n)
+{
+    *d_codes = nullptr;
+    *n = 0;
+    const size_t cap = (size_t)ctx->n_entries;
+    if (cap == 0) return RC_OK;
+    rc_dev_tmp b_counts, b_n;
+    uint64_t *codes = nullptr;
+    RC_CHECK_HIP(ctx, hipMalloc((void **)&codes, cap * 8));
+    unsigned long long n64 = 0;
+    hipError_t e = b_counts.alloc(cap * 4);
+    if (e == hipSuccess) e = b_n.alloc(8);
+    if (e == hipSuccess) e = hipMemsetAsync(b_n.p, 0, 8, ctx->stream);
+    int rc = RC_OK;
+    if (e == hipSuccess) rc = rc_launch_export(ctx, codes, b_counts.as<int32_t>(), b_n.as<unsigned long long>(), cap);
+    if (e == hipSuccess && rc == RC_OK) e = hipMemcpyAsync(&n64, b_n.p, 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && rc == RC_OK) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess || rc != RC_OK || n64 > cap) {
+        (void)hipFree(codes);
+        if (e != hipSuccess) rc_set_error(ctx, "table export: %s", hipGetErrorString(e));
+        else if (rc == RC_OK) rc_set_error(ctx, "table export: %llu entries found, at most %zu expected", n64, cap);
+        return e != hipSuccess ? RC_ERR_HIP : (rc != RC_OK ? rc : RC_ERR_STATE);
+    }
+    *d_codes = codes;
+    *n = (size_t)n64;
+    return RC_OK;
+}
+
 // every stored (canonical code, count) pair, in unspecified order (jf_dump writer / test support)
 __global__ void k_export(rc_table_view T, size_t nslots, uint64_t *__restrict__ codes,
                          int32_t *__restrict__ counts, unsigned long long *__restrict__ n_out, size_t cap)
@@ -1059,9 +1162,17 @@ static void rc_count_release(rc_ctx *ctx)
     ctx->cnt_total = 0;
 }
 
+void rc_kept_release(rc_ctx *ctx)
+{
+    for (auto &a : ctx->kept_arenas)
+        if (a.p) (void)hipFree(a.p);
+    ctx->kept_arenas.clear();
+}
+
 int rc_count_begin(rc_ctx *ctx)
 {
     rc_count_release(ctx);
+    rc_kept_release(ctx);
     ctx->cnt_active = true;
     return RC_OK;
 }
@@ -1109,7 +1220,7 @@ int rc_count_finish(rc_ctx *ctx, int min_count, int64_t *n_kmers)
     ctx->cnt_active = false;
     struct release_on_exit {
         rc_ctx *c;
-        ~release_on_exit() { rc_count_release(c); }
+        ~release_on_exit() { rc_count_release(c); }  // (an error leaves nothing behind; success with cnt_keep has moved the arenas out)
     } guard{ctx};
     const int k = ctx->k;
     // passes: a pass holds, per k-mer occurrence of its slice, the key (8 B), its sorted copy (8 B), the sort's scratch
@@ -1208,6 +1319,10 @@ int rc_count_finish(rc_ctx *ctx, int min_count, int64_t *n_kmers)
         }
         RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
+    if (ctx->cnt_keep) {  // the reads stay where they are for rc_submit_resident
+        ctx->kept_arenas.swap(ctx->cnt_arenas);
+        ctx->cnt_total = 0;
+    }
     rc_count_release(ctx);  // the reads are no longer needed: their memory goes to the table build
     rc_dev_tmp b_allk, b_allc;
     RC_CHECK_HIP(ctx, b_allk.alloc((total_kept + 1) * 8));
@@ -1225,6 +1340,7 @@ int rc_count_finish(rc_ctx *ctx, int min_count, int64_t *n_kmers)
     }
     outs.clear();
     int rc = rc_build_table_from_device_pairs(ctx, b_allk.as<uint64_t>(), b_allc.as<int32_t>(), total_kept);
+    if (rc != RC_OK) rc_kept_release(ctx);
     if (n_kmers) *n_kmers = (int64_t)total_kept;
     return rc;
 }

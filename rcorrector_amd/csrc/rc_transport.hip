@@ -8,6 +8,9 @@
 //       150-base read.
 // Down: ret / l / m / h and the substitutions the correction made as (arena position, letter) pairs -- about 0.75 per
 //       read at 0.5 % errors: 20 bytes instead of 167.
+// Reads that are in HBM already -- the arenas the k-mer counter kept (rc_table_count_keep) -- do not travel at all
+// (rc_submit_resident): the batch's ranges are copied device to device into the byte arena the kernels correct in place,
+// and the fix list is the byte difference between that arena and the kept one (k_fix_list_bytes).
 // On the device the packed arena is expanded into the byte arena the kernels read (k_unpack_bases: 1 byte written
 // per base, ~1 ms for 25 M reads -- the kernels themselves are unchanged) and the fix list is the difference between
 // the corrected arena and the packed one (k_fix_list).
@@ -147,6 +150,124 @@ __global__ __launch_bounds__(256) void k_fix_list(const uint32_t *__restrict__ p
     }
 }
 
+// 16 bytes from any address as two aligned 16-byte loads and a byte funnel (the compiler turns a 16-byte copy from an
+// address it cannot prove aligned into sixteen byte loads).  Reads up to 31 bytes past p & ~15: the kept arenas carry
+// 64 bytes of slack.  The shift is the same for every thread of a launch, so the switch is a uniform branch.
+__device__ __forceinline__ uint4 rc_load16_any(const uint8_t *p)
+{
+    const uintptr_t a = (uintptr_t)p;
+    const uint4 *q = reinterpret_cast<const uint4 *>(a & ~(uintptr_t)15);
+    const uint32_t sh = (uint32_t)(a & 15u);
+    const uint4 lo = q[0];
+    if (sh == 0) return lo;
+    const uint4 hi = q[1];
+    const uint32_t r = sh & 3u;
+    switch (sh >> 2) {
+    case 0:
+        return make_uint4(__builtin_amdgcn_alignbyte(lo.y, lo.x, r), __builtin_amdgcn_alignbyte(lo.z, lo.y, r), __builtin_amdgcn_alignbyte(lo.w, lo.z, r),
+                          __builtin_amdgcn_alignbyte(hi.x, lo.w, r));
+    case 1:
+        return make_uint4(__builtin_amdgcn_alignbyte(lo.z, lo.y, r), __builtin_amdgcn_alignbyte(lo.w, lo.z, r), __builtin_amdgcn_alignbyte(hi.x, lo.w, r),
+                          __builtin_amdgcn_alignbyte(hi.y, hi.x, r));
+    case 2:
+        return make_uint4(__builtin_amdgcn_alignbyte(lo.w, lo.z, r), __builtin_amdgcn_alignbyte(hi.x, lo.w, r), __builtin_amdgcn_alignbyte(hi.y, hi.x, r),
+                          __builtin_amdgcn_alignbyte(hi.z, hi.y, r));
+    default:
+        return make_uint4(__builtin_amdgcn_alignbyte(hi.x, lo.w, r), __builtin_amdgcn_alignbyte(hi.y, hi.x, r), __builtin_amdgcn_alignbyte(hi.z, hi.y, r),
+                          __builtin_amdgcn_alignbyte(hi.w, hi.z, r));
+    }
+}
+
+// The same against the uncorrected bytes themselves: the corrected arena `seq` of na + nb bytes was copied from orig_a
+// (its first na bytes) and orig_b (the rest, the second mates of a paired batch; nb may be 0).  A correction only ever
+// writes one of ACGT over a different byte (ErrorCorrection.cpp:1468-1479), so every byte that differs is a fix.  16 bytes
+// of `seq` per thread and step; the bytes they were copied from sit at any alignment (rc_load16_any).
+__global__ __launch_bounds__(256) void k_fix_list_bytes(const uint8_t *__restrict__ orig_a, size_t na, const uint8_t *__restrict__ orig_b, size_t nb,
+                                                        const uint8_t *__restrict__ seq, uint32_t *__restrict__ n_fix, uint32_t cap,
+                                                        uint32_t *__restrict__ fix_pos, uint8_t *__restrict__ fix_chr)
+{
+    __shared__ uint32_t s_wave[4], s_base;
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const size_t nbytes = na + nb, n_words = (nbytes + 15) / 16;
+    for (size_t w0 = (size_t)blockIdx.x * RC_FIX_WORDS; w0 < n_words; w0 += (size_t)gridDim.x * RC_FIX_WORDS) {
+        uint32_t diff[RC_FIX_WPT];
+        uint4 now[RC_FIX_WPT];
+        uint32_t mine = 0;
+#pragma unroll
+        for (int q = 0; q < RC_FIX_WPT; ++q) {
+            const size_t w = w0 + (size_t)q * 256u + t, p = 16 * w;
+            uint4 sv = make_uint4(0, 0, 0, 0), ov = make_uint4(0, 0, 0, 0);
+            if (p + 16 <= nbytes) {
+                sv = *reinterpret_cast<const uint4 *>(seq + p);
+                if (p + 16 <= na) {
+                    ov = rc_load16_any(orig_a + p);
+                } else if (p >= na) {
+                    ov = rc_load16_any(orig_b + (p - na));
+                } else {
+                    uint8_t o[16];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) o[j] = p + j < na ? orig_a[p + j] : orig_b[p + j - na];
+                    __builtin_memcpy(&ov, o, 16);
+                }
+            } else if (p < nbytes) {  // the arena's last, partial word
+                uint8_t o[16], c[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const size_t a = p + j;
+                    c[j] = a < nbytes ? seq[a] : (uint8_t)0;
+                    o[j] = a < nbytes ? (a < na ? orig_a[a] : orig_b[a - na]) : (uint8_t)0;
+                }
+                __builtin_memcpy(&sv, c, 16);
+                __builtin_memcpy(&ov, o, 16);
+            }
+            const uint32_t sw[4] = {sv.x, sv.y, sv.z, sv.w}, ow[4] = {ov.x, ov.y, ov.z, ov.w};
+            uint32_t d = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) d |= ((((sw[j >> 2] ^ ow[j >> 2]) >> (8 * (j & 3))) & 0xffu) ? 1u : 0u) << j;
+            diff[q] = d;
+            now[q] = sv;
+            mine += (uint32_t)__popc(d);
+        }
+        uint32_t inc = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(inc, o, 64);
+            inc += lane >= (uint32_t)o ? y : 0u;
+        }
+        if (lane == 63) s_wave[wave] = inc;
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            before += (uint32_t)q < wave ? s_wave[q] : 0u;
+            total += s_wave[q];
+        }
+        if (total) {  // (uniform)
+            if (t == 0) s_base = atomicAdd(n_fix, total);
+            __syncthreads();
+            uint32_t j0 = s_base + before + inc - mine;
+#pragma unroll
+            for (int q = 0; q < RC_FIX_WPT; ++q) {
+                uint32_t d = diff[q];
+                const uint32_t p0 = (uint32_t)(16 * (w0 + (size_t)q * 256u + t));
+                const uint32_t sw[4] = {now[q].x, now[q].y, now[q].z, now[q].w};
+                while (d) {
+                    const int j = __ffs((int)d) - 1;
+                    d &= d - 1;
+                    if (j0 < cap) {
+                        fix_pos[j0] = p0 + (uint32_t)j;
+                        // (selected without indexing the array at run time: that would put it into scratch memory)
+                        const uint32_t wsel = j < 8 ? (j < 4 ? sw[0] : sw[1]) : (j < 12 ? sw[2] : sw[3]);
+                        fix_chr[j0] = (uint8_t)((wsel >> (8 * (j & 3))) & 0xffu);
+                    }
+                    ++j0;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void k_fix_exceptions(const uint32_t *__restrict__ pos, uint32_t n, const uint8_t *__restrict__ seq,
                                                         uint32_t *__restrict__ n_fix, uint32_t cap, uint32_t *__restrict__ fix_pos, uint8_t *__restrict__ fix_chr)
 {
@@ -168,6 +289,21 @@ int rc_launch_unpack(rc_ctx *ctx, const uint32_t *d_packed, size_t nbytes, const
     }
     if (n_reads) hipLaunchKernelGGL(k_put_nuls, dim3((n_reads + 255) / 256), dim3(256), 0, ctx->stream, d_off, n_reads, d_seq);
     if (n_exc) hipLaunchKernelGGL(k_put_exceptions, dim3((n_exc + 255) / 256), dim3(256), 0, ctx->stream, d_exc_pos, d_exc_chr, n_exc, d_seq);
+    RC_CHECK_HIP(ctx, hipGetLastError());
+    return RC_OK;
+}
+
+int rc_launch_fix_list_bytes(rc_ctx *ctx, const uint8_t *d_orig_a, size_t bytes_a, const uint8_t *d_orig_b, size_t bytes_b, const uint8_t *d_seq,
+                              uint32_t *d_n_fix, uint32_t cap, uint32_t *d_fix_pos, uint8_t *d_fix_chr)
+{
+    RC_CHECK_HIP(ctx, hipMemsetAsync(d_n_fix, 0, 4, ctx->stream));
+    const size_t n_words = (bytes_a + bytes_b + 15) / 16;
+    if (n_words) {
+        size_t g = (n_words + RC_FIX_WORDS - 1) / RC_FIX_WORDS;
+        if (g > (size_t)ctx->n_cu * 32) g = (size_t)ctx->n_cu * 32;
+        hipLaunchKernelGGL(k_fix_list_bytes, dim3((unsigned)g), dim3(256), 0, ctx->stream, d_orig_a, bytes_a, d_orig_b, bytes_b, d_seq, d_n_fix, cap, d_fix_pos,
+                           d_fix_chr);
+    }
     RC_CHECK_HIP(ctx, hipGetLastError());
     return RC_OK;
 }

@@ -191,10 +191,14 @@ def test_error_rate_of_counted_table_equals_file_order_path(rc, tmp_path):
 EXACT_DUMP_FIXTURES = ["fx_sample", "fx_se_k23", "fx_pe_k23", "fx_il_k23", "fx_k31_mc8", "fx_skew", "fx_k32", "fx_k15", "fx_varlen_n"]
 
 
+@pytest.mark.parametrize("resident", ["0", "1", "6"])
 @pytest.mark.parametrize("name", EXACT_DUMP_FIXTURES)
-def test_cli_without_c_reproduces_reference_outputs(name, tmp_path):
+def test_cli_without_c_reproduces_reference_outputs(name, resident, tmp_path, monkeypatch):
     """These fixtures' dump.jf is the exact k-mer count (>= 2) of the fixture's own reads, i.e. what
-    stages 0-2 produce; counting on the GPU instead must give the reference's bytes."""
+    stages 0-2 produce; counting on the GPU instead must give the reference's bytes -- in two passes over the files
+    (RC_RESIDENT=0: count, then read again and correct) and in one (the default for plain files that fit: the text stays
+    in host memory, the bases in HBM with the counter, rc_submit_resident; "6" = the same in batches of 6 reads)."""
+    monkeypatch.setenv("RC_RESIDENT", resident)
     args = open(os.path.join(gu.GOLDEN, name, "cmd.txt")).read().split()
     i = args.index("-c")
     del args[i:i + 2]

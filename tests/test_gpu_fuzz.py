@@ -118,6 +118,32 @@ def test_cli_equals_oracle_cli_on_random_inputs(oracle, seed, tmp_path):
         assert _content(os.path.join(od, f)) == outs["cpu"][1][f], "%s differs through the packed boundary (seed %d, args %s)" % (f, seed, args)
 
 
+def _one_pass_equals_two(args, d, seed):
+    """without -c the k-mers are counted here: one pass over the files (the default for plain inputs: text kept in host
+    memory, bases kept in HBM, rc_submit_resident) must write what the two passes write (count, read again, correct)"""
+    a = list(args)
+    i = a.index("-c")
+    del a[i:i + 2]
+    res = []
+    for tag, env in (("two", {"RC_RESIDENT": "0"}), ("one", {"RC_RESIDENT": "1"}), ("one_small", {"RC_RESIDENT": "1" if seed % 2 else "10"})):
+        od = os.path.join(d, "nc_" + tag)
+        os.makedirs(od)
+        p = subprocess.run([CLI] + a + ["-od", od], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env))
+        res.append((p.returncode, p.stderr, {f: _content(os.path.join(od, f)) for f in sorted(os.listdir(od))}))
+    assert res[0][0] == 0, res[0][1].decode()
+    for r, tag in zip(res[1:], ("one pass", "one pass, small batches")):
+        assert r == res[0], "%s differs from two passes (seed %d, args %s)" % (tag, seed, a)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(900, 940, 2)) + list(range(300, 340, 2)))
+def test_cli_one_pass_without_c_equals_two_passes(seed, tmp_path):
+    import io_quirks
+    d = str(tmp_path)
+    args = _random_case(seed, d) if seed >= 900 else io_quirks.make_case(seed, d, modes=(0, 1, 2))
+    _one_pass_equals_two(args, d, seed)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", list(range(300, 340)))
 def test_cli_equals_oracle_cli_on_io_quirks(oracle, seed, tmp_path):

@@ -766,6 +766,85 @@ def test_packed_boundary_slots_fasta_and_errors(gpu_ctx_factory, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["se_k23", "pe_k23", "il_k23", "pe_var", "nrich", "edge", "varlen", "k31_mc8", "tiers_pe", "long600_k31"])
+def test_resident_boundary_gives_the_oracles_results(gpu_ctx_factory, oracle, name):
+    """rc_submit_resident / rc_wait_resident: the reads are the arenas the k-mer counter kept in HBM (rc_table_count_keep) --
+    counted once, corrected where they lie; only offsets and quality bits go down.  Same contract as the packed boundary:
+    ret / l / m / h are the oracle's, the host arena plus the fix list is the oracle's corrected arena, the kept arenas stay
+    as they were (a second submission gives the same list), sub-ranges of an arena are batches of their own."""
+    d = datasets.make(name)
+    want = datasets.run_oracle(oracle, d)
+    ctx = gpu_ctx_factory(d["k"], d["mfk"])
+    a1, off1 = oracle.pack_reads(d["seqs1"])
+    q1, _ = oracle.pack_reads(d["quals1"])
+    ctx.count_keep(True)
+    ctx.count_begin()
+    ctx.count_add(a1)
+    arena, qa, off = a1, q1, off1
+    if d["mode"] == 1:
+        a2, off2 = oracle.pack_reads(d["seqs2"])
+        q2, _ = oracle.pack_reads(d["quals2"])
+        ctx.count_add(a2)
+        off = np.concatenate([off1, (off2[1:].astype(np.int64) + a1.size).astype(np.uint32)])
+        arena, qa = np.concatenate([a1, a2]), np.concatenate([q1, q2])
+    ctx.count_finish(2)
+    kept = ctx.count_arenas()
+    assert list(kept) == ([a1.size, a2.size] if d["mode"] == 1 else [a1.size])
+    # (counting built a table of these reads' own k-mers: the data set's table and parameters go back in)
+    ctx.table_build(d["keys"], d["counts"])
+    ctx.set_run_params(d["rate"], b"H")
+    qb = ctx.host_array((arena.size + 7) // 8)
+    ctx.pack_quality_bits(qa, b"H", out=qb)
+    args = dict(arena_a=0, begin_a=0, bytes_a=a1.size)
+    if d["mode"] == 1:
+        args.update(arena_b=1, begin_b=0, bytes_b=a2.size)
+    lists = []
+    for _ in range(2):
+        ctx.submit_resident(0, d["mode"], off, qb, **args)
+        ret, l, m, h, fix_pos, fix_chr = ctx.wait_resident(0)
+        for w, g, what in zip(want[:4], (ret, l, m, h), ["ret", "l", "m", "h"]):
+            assert np.array_equal(w, g), "%s differs on %s through the resident boundary" % (what, name)
+        lists.append(sorted(zip(fix_pos.tolist(), fix_chr.tolist())))
+    assert lists[0] == lists[1]
+    host = arena.copy()
+    ctx.apply_fixes(host, fix_pos, fix_chr)
+    want_arena = np.concatenate(want[4:])
+    assert np.array_equal(host, want_arena), "corrected bases differ on %s through the resident boundary" % name
+    assert len(fix_pos) == int((arena != want_arena).sum()) == int(want[0][want[0] > 0].sum())
+    # the second half of the units as a batch of its own: ranges that start inside the kept arenas (any alignment)
+    n1 = len(off1) - 1
+    step = 2 if d["mode"] == 2 else 1
+    lo = (n1 // 2) // step * step
+    if 0 < lo < n1:
+        sub_off = [off1[lo:].astype(np.int64) - int(off1[lo])]
+        sargs = dict(arena_a=0, begin_a=int(off1[lo]), bytes_a=int(a1.size - off1[lo]))
+        sub_q = [q1[off1[lo]:]]
+        if d["mode"] == 1:
+            sub_off.append(off2[lo + 1:].astype(np.int64) - int(off2[lo]) + sargs["bytes_a"])
+            sargs.update(arena_b=1, begin_b=int(off2[lo]), bytes_b=int(a2.size - off2[lo]))
+            sub_q.append(q2[off2[lo]:])
+        sqb = ctx.host_array((sargs["bytes_a"] + sargs.get("bytes_b", 0) + 7) // 8)
+        ctx.pack_quality_bits(np.concatenate(sub_q), b"H", out=sqb)
+        ctx.submit_resident(1, d["mode"], np.concatenate(sub_off).astype(np.uint32), sqb, **sargs)
+        ret, l, m, h, fix_pos, fix_chr = ctx.wait_resident(1)
+        idx = np.arange(lo, n1)
+        if d["mode"] == 1:
+            idx = np.concatenate([idx, n1 + idx])
+        for w, g, what in zip(want[:4], (ret, l, m, h), ["ret", "l", "m", "h"]):
+            assert np.array_equal(w[idx], g), "%s differs on the second half of %s through the resident boundary" % (what, name)
+        sub = np.concatenate([a1[off1[lo]:]] + ([a2[off2[lo]:]] if d["mode"] == 1 else []))
+        ctx.apply_fixes(sub, fix_pos, fix_chr)
+        assert np.array_equal(sub, np.concatenate([want[4][off1[lo]:]] + ([want[5][off2[lo]:]] if d["mode"] == 1 else [])))
+    # errors: a range beyond the arena, an arena that is not there, released arenas
+    with pytest.raises(rcorrector_amd.RcorrectorError, match="kept arena"):
+        ctx.submit_resident(0, d["mode"], off, qb, **dict(args, bytes_a=a1.size + 16))
+    ctx.count_release()
+    assert len(ctx.count_arenas()) == 0
+    with pytest.raises(rcorrector_amd.RcorrectorError, match="kept arena"):
+        ctx.submit_resident(0, d["mode"], off, qb, **args)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", ["se_k23", "pe_k23", "il_k23", "pe_var", "varlen", "edge", "k31_mc8", "long600_k31", "polya_k23",
                                   "se_151", "pe_151", "pe_160_k15", "tiers_se", "tiers_pe", "tiers_il"])
 def test_locality_order_does_not_change_results(oracle, name, monkeypatch):

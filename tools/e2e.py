@@ -101,10 +101,12 @@ def main():
                 kk, vv = toks.pop(0).split("=", 1)
                 venv[kk] = vv
             t0 = time.time()
+            venv["RC_T0"] = repr(t0)
             p = subprocess.run([cli] + inputs + ["-k", str(k), "-od", a.dir + "/out"] + dump + toks,
                                cwd=a.dir, env=venv, stderr=subprocess.PIPE)
             dt = time.time() - t0
             sys.stderr.write(p.stderr.decode())
+            sys.stderr.write("[e2e] process returned at +%.3f s\n" % dt)
             md5 = hashlib.md5(open(a.dir + "/out/" + first_out, "rb").read()).hexdigest()
             print("CLI [%s %s] wall %.2f s -> %.2f M reads/s end to end, output md5 %s" % (
                 " ".join(dump) or "(counting)", variant, dt, n / dt / 1e6, md5), file=sys.stderr if a.json else sys.stdout)
