@@ -101,13 +101,31 @@ __global__ __launch_bounds__(256) void k_fix_list(const uint32_t *__restrict__ p
             const uint32_t sw[4] = {sv.x, sv.y, sv.z, sv.w};
             uint32_t d = 0;
             uint64_t lt = 0;
+            // most words hold no fix: the letters of the packed codes (as k_unpack_bases writes them) against the arena's,
+            // four bytes at a time -- a byte that differs and is not a NUL is looked at one by one below
+            uint32_t cand = 0;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const uint32_t ch = (sw[j >> 2] >> (8 * (j & 3))) & 0xffu;
-                const uint32_t c = (v >> (30 - 2 * j)) & 3u;
-                const int code = ch == 0x41u ? 0 : (ch == 0x43u ? 1 : (ch == 0x47u ? 2 : (ch == 0x54u ? 3 : -1)));
-                d |= (code >= 0 && (uint32_t)code != c ? 1u : 0u) << j;
-                lt |= (uint64_t)(code & 3) << (4 * j);
+            for (int q4 = 0; q4 < 4; ++q4) {
+                uint32_t e = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t c = (v >> (30 - 2 * (4 * q4 + j))) & 3u;
+                    e |= (c == 0 ? 0x41u : (c == 1 ? 0x43u : (c == 2 ? 0x47u : 0x54u))) << (8 * j);
+                }
+                const uint32_t x = sw[q4] ^ e;
+                const uint32_t nz = ((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x;                    // bit 7 of a byte: x's byte is not 0
+                const uint32_t nn = ((sw[q4] & 0x7f7f7f7fu) + 0x7f7f7f7fu) | sw[q4];          // ... the arena's byte is not NUL
+                cand |= nz & nn & 0x80808080u;
+            }
+            if (cand) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const uint32_t ch = (sw[j >> 2] >> (8 * (j & 3))) & 0xffu;
+                    const uint32_t c = (v >> (30 - 2 * j)) & 3u;
+                    const int code = ch == 0x41u ? 0 : (ch == 0x43u ? 1 : (ch == 0x47u ? 2 : (ch == 0x54u ? 3 : -1)));
+                    d |= (code >= 0 && (uint32_t)code != c ? 1u : 0u) << j;
+                    lt |= (uint64_t)(code & 3) << (4 * j);
+                }
             }
             diff[q] = d;
             let[q] = lt;
@@ -222,8 +240,10 @@ __global__ __launch_bounds__(256) void k_fix_list_bytes(const uint8_t *__restric
             }
             const uint32_t sw[4] = {sv.x, sv.y, sv.z, sv.w}, ow[4] = {ov.x, ov.y, ov.z, ov.w};
             uint32_t d = 0;
+            if ((sw[0] ^ ow[0]) | (sw[1] ^ ow[1]) | (sw[2] ^ ow[2]) | (sw[3] ^ ow[3])) {  // (most words hold no fix)
 #pragma unroll
-            for (int j = 0; j < 16; ++j) d |= ((((sw[j >> 2] ^ ow[j >> 2]) >> (8 * (j & 3))) & 0xffu) ? 1u : 0u) << j;
+                for (int j = 0; j < 16; ++j) d |= ((((sw[j >> 2] ^ ow[j >> 2]) >> (8 * (j & 3))) & 0xffu) ? 1u : 0u) << j;
+            }
             diff[q] = d;
             now[q] = sv;
             mine += (uint32_t)__popc(d);
