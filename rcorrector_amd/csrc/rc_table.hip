@@ -679,8 +679,8 @@ int rc_launch_compact_flag(rc_ctx *ctx, const uint8_t *d_flag, uint32_t n, uint3
 // ~130 probes of a read hit ~130 unrelated buckets and nearly every one of them is an HBM access.
 // Reads that overlap share most of their k-mers: probed next to each other, they meet in the L2 /
 // Infinity Cache instead.  Large batches are therefore PROBED in "min-hash order": key of a unit (a
-// read, or a pair through its first mate) = the smallest hash over its canonical k-mers, so units that
-// contain the same k-mer as their minimum -- overlapping reads -- become neighbours in the list
+// read, or a pair through its first mate) = the smallest hash over its canonical m-mers (m = min(k, 16), see
+// k_unit_key), so units that contain the same m-mer as their minimum -- overlapping reads -- become neighbours in the list
 // k_probe_list walks.  Nothing is moved: counts land at the reads' own positions, and the threshold
 // and correction kernels run as ever.
 #define RC_KEY_TILE 40960  // bytes of reads staged per 256-thread workgroup of k_unit_key
@@ -713,6 +713,34 @@ __global__ __launch_bounds__(256) void k_unit_key(const uint8_t *__restrict__ se
     const uint32_t r = mode == 2 ? 2u * u : u;  // the unit's first mate
     const uint32_t o = (uint32_t)(off[r] - a0);
     const int len = (int)(off[r + 1] - off[r]) - 1;
+    // The key only has to make overlapping reads neighbours, so it is the smallest hash over the read's canonical m-mers,
+    // m = min(k, 16): two reads that overlap by m bases or more share their minimum whenever it lies in the overlap, as with
+    // k-mers -- and an m-mer is one 32-bit word, which takes this loop (a thread per unit, bound by instruction issue) from
+    // 64-bit shifts, compares and two more multiplies per base to a handful of 32-bit operations (RC_KEY_KMER=1 at compile
+    // time keeps the k-mer version for A/B runs).
+#ifndef RC_KEY_KMER
+    const int m = k < 16 ? k : 16;
+    const uint32_t mask = m == 16 ? 0xFFFFFFFFu : ((1u << (2 * m)) - 1u);
+    const int top = 2 * (m - 1);
+    uint32_t fw = 0, rv = 0, best = 0xFFFFFFFFu;
+    int valid = 0;
+    for (int i = 0; i < len; ++i) {
+        const uint32_t c = s_raw[o + i];
+        const uint32_t b = ((c >> 1) ^ (c >> 2)) & 3u;                     // A 0, C 1, G 2, T 3
+        const uint32_t d = c - 65u;                                        // 'A' .. 'T': bits 0, 2, 6, 19 of the mask
+        const bool acgt = d < 20u && ((0x80045u >> d) & 1u);
+        valid = acgt ? valid + 1 : 0;
+        fw = ((fw << 2) | b) & mask;
+        rv = (rv >> 2) | ((3u - b) << top);
+        if (valid >= m) {
+            uint32_t h = (fw < rv ? fw : rv) * 0x9E3779B1u;
+            h ^= h >> 15;
+            h *= 0x2C1B3C6Du;
+            h ^= h >> 13;
+            best = h < best ? h : best;
+        }
+    }
+#else
     const uint64_t mask = rc_kmer_mask(k);
     uint64_t fw = 0, rv = 0;
     uint32_t best = 0xFFFFFFFFu;
@@ -732,6 +760,7 @@ __global__ __launch_bounds__(256) void k_unit_key(const uint8_t *__restrict__ se
             best = h < best ? h : best;
         }
     }
+#endif
     keys[u] = best;
     idx[u] = u;
 }
