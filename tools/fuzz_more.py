@@ -3,7 +3,10 @@
 (GPU CLI vs the pinned CPU oracle CLI, every output byte, stderr and -verbose transcript).
   fuzz_more.py LO HI        read-content fuzz
   fuzz_more.py LO HI io     input-format quirks (tests/io_quirks.py)
-  fuzz_more.py LO HI long   read-content fuzz with read lengths up to 1023"""
+  fuzz_more.py LO HI long   read-content fuzz with read lengths up to 1023
+  fuzz_more.py LO HI nodump [io]   without -c: the GPU CLI counts the k-mers itself in ONE pass over the files (text kept in host
+                            memory, bases kept in HBM, rc_submit_resident; every other seed in batches of 10 reads) and writes its
+                            table with -write-dump; the oracle CLI given that dump must produce the same bytes and stderr"""
 import os
 import subprocess
 import sys
@@ -27,6 +30,9 @@ def _content(path):
 
 pyoracle.build()
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
+nodump = len(sys.argv) > 3 and sys.argv[3] == "nodump"
+if nodump:
+    del sys.argv[3]
 io_mode = len(sys.argv) > 3 and sys.argv[3] == "io"
 long_mode = len(sys.argv) > 3 and sys.argv[3] == "long"   # reads of up to 1023 bases   # tests/io_quirks.py cases instead of the read-content fuzz
 if io_mode:
@@ -36,11 +42,19 @@ for seed in range(lo, hi):
     with tempfile.TemporaryDirectory() as d:
         args = io_quirks.make_case(seed, d, modes=(0, 1, 2)) if io_mode else F._random_case(seed, d, max_len=1024 if long_mode else 160)
         outs = {}
-        verbose = ["-verbose"] if (io_mode or seed % 3 == 0) else []
-        for name, binary, more in (("gpu", F.CLI, ["-batch", "64"] if seed % 2 else []), ("cpu", pyoracle.CLI_BIN, ["-t", "2"])):
+        verbose = ["-verbose"] if (io_mode or seed % 3 == 0) and not nodump else []
+        runs = (("gpu", F.CLI, ["-batch", "64"] if seed % 2 else [], args, None), ("cpu", pyoracle.CLI_BIN, ["-t", "2"], args, None))
+        if nodump:
+            a = list(args)
+            i = a.index("-c")
+            del a[i:i + 2]
+            runs = (("gpu", F.CLI, ["-write-dump", os.path.join(d, "own.jf")], a, {"RC_RESIDENT": "10" if seed % 2 else "1"}),
+                    ("cpu", pyoracle.CLI_BIN, ["-t", "2", "-c", os.path.join(d, "own.jf")], a, None))
+        for name, binary, more, argv, env in runs:
             od = os.path.join(d, name)
             os.makedirs(od)
-            p = subprocess.run([binary] + args + ["-od", od] + more + verbose, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            p = subprocess.run([binary] + argv + ["-od", od] + more + verbose, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                               env=dict(os.environ, **env) if env else None)
             outs[name] = (p.returncode, p.stderr, {f: _content(os.path.join(od, f)) for f in sorted(os.listdir(od))}, p.stdout)
         if outs["gpu"] != outs["cpu"]:
             bad += 1
