@@ -211,7 +211,7 @@ void rc_destroy(rc_ctx *c)
     }
     if (ctx->s_h2d) (void)hipStreamDestroy(ctx->s_h2d);
     if (ctx->s_d2h) (void)hipStreamDestroy(ctx->s_d2h);
-    for (auto &a : ctx->cnt_arenas)
+    for (auto &a : ctx->cnt_chunks)
         if (a.p) (void)hipFree(a.p);
     rc_kept_release(ctx);
     rc_table_release(ctx);

@@ -92,13 +92,17 @@ struct rc_ctx {
     rc_dbuf trace;
 
     // k-mer counter (rc_table_count_begin/add/finish): the arenas handed over so far, kept in HBM until finish
+    // (the arenas are views into a few large allocations, cnt_chunks: a hipMalloc / hipFree per arena -- dozens per run, each
+    // a round trip through the kernel driver -- cost more than counting them on a busy host)
     std::vector<rc_dbuf> cnt_arenas;
+    std::vector<rc_dbuf> cnt_chunks;
+    size_t cnt_chunk_used = 0;  // bytes of the last chunk handed out
     size_t cnt_total = 0;  // bytes
     bool cnt_active = false;
     // rc_table_count_keep(on): finish() leaves the arenas here instead of releasing them -- the reads of a data set
     // that was counted on this GPU are corrected where they lie (rc_submit_resident)
     bool cnt_keep = false;
-    std::vector<rc_dbuf> kept_arenas;
+    std::vector<rc_dbuf> kept_arenas, kept_chunks;
 
     // batch scratch
     rc_dbuf counts;   // int32 per arena byte

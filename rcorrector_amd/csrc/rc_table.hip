@@ -23,6 +23,7 @@
 #include <vector>
 #include <rocprim/rocprim.hpp>
 
+#include <chrono>
 #include "rc_internal.h"
 #include "rc_device.h"
 
@@ -1075,7 +1076,7 @@ int rc_launch_probe(rc_ctx *ctx, const uint8_t *d_seq, size_t nbytes, int32_t *d
 // 100 M x 150 bp are 15 GB of 288), and finish() makes P passes over them; pass p looks only at the k-mers whose
 // hash falls into slice p of P -- emit -> radix sort -> run-length encode -> keep count >= min_count -- so that no
 // more than 1/P of the k-mer occurrences is ever in flight, whatever share of them are singletons.  A histogram
-// pass sizes the slices; P follows from the memory the passes may use (RC_COUNT_MEM_MB, default 24 GiB).  The result
+// pass sizes the slices; P follows from the memory the passes may use (RC_COUNT_MEM_MB, default 48 GiB).  The result
 // is what `jellyfish count -C` + `dump -L 2` hands to the reference: every canonical k-mer with its exact count.
 __global__ void k_u32_to_i32_clamped(const uint32_t *in, int32_t *out, size_t n)
 {
@@ -1185,16 +1186,19 @@ __global__ void k_flag_keep(const uint64_t *__restrict__ uniq, const uint32_t *_
 
 static void rc_count_release(rc_ctx *ctx)
 {
-    for (auto &a : ctx->cnt_arenas)
+    for (auto &a : ctx->cnt_chunks)
         if (a.p) (void)hipFree(a.p);
+    ctx->cnt_chunks.clear();
+    ctx->cnt_chunk_used = 0;
     ctx->cnt_arenas.clear();
     ctx->cnt_total = 0;
 }
 
 void rc_kept_release(rc_ctx *ctx)
 {
-    for (auto &a : ctx->kept_arenas)
+    for (auto &a : ctx->kept_chunks)
         if (a.p) (void)hipFree(a.p);
+    ctx->kept_chunks.clear();
     ctx->kept_arenas.clear();
 }
 
@@ -1225,16 +1229,25 @@ int rc_count_add(rc_ctx *ctx, const uint8_t *seq, size_t nbytes, bool from_devic
                           "jellyfish and pass the dump (-c)", (ctx->cnt_total + nbytes) >> 20, cap >> 20);
         return RC_ERR_NOMEM;
     }
+    // the arena's place: behind the last one in the current chunk (256-byte aligned, 64 bytes of slack), or a new chunk
+    const size_t need = (nbytes + 64 + 255) & ~(size_t)255, chunk_bytes = (size_t)2 << 30;
+    if (ctx->cnt_chunks.empty() || ctx->cnt_chunk_used + need > ctx->cnt_chunks.back().bytes) {
+        rc_dbuf c;
+        c.bytes = need > chunk_bytes ? need : chunk_bytes;
+        RC_CHECK_HIP(ctx, hipMalloc(&c.p, c.bytes));
+        ctx->cnt_chunks.push_back(c);
+        ctx->cnt_chunk_used = 0;
+    }
     rc_dbuf a;
-    RC_CHECK_HIP(ctx, hipMalloc(&a.p, nbytes + 64));
+    a.p = (char *)ctx->cnt_chunks.back().p + ctx->cnt_chunk_used;
     a.bytes = nbytes;
     hipError_t e = hipMemcpyAsync(a.p, seq, nbytes, from_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // (the caller's buffer is its own again when this returns)
     if (e != hipSuccess) {
-        (void)hipFree(a.p);
         rc_set_error(ctx, "count_add: copy failed: %s", hipGetErrorString(e));
         return RC_ERR_HIP;
     }
+    ctx->cnt_chunk_used += need;
     ctx->cnt_arenas.push_back(a);
     ctx->cnt_total += nbytes;
     return RC_OK;
@@ -1247,6 +1260,11 @@ int rc_count_finish(rc_ctx *ctx, int min_count, int64_t *n_kmers)
         return RC_ERR_STATE;
     }
     ctx->cnt_active = false;
+    // RC_COUNT_TIMING=1 (dev): where finish() spends its time, on stderr
+    static const bool timing = getenv("RC_COUNT_TIMING") != nullptr;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now();
+    double t_alloc = 0, t_emit = 0, t_sort = 0, t_rle = 0, t_sel = 0;  // (t_sort / t_rle / t_sel: with RC_COUNT_TIMING's extra synchronisations)
     struct release_on_exit {
         rc_ctx *c;
         ~release_on_exit() { rc_count_release(c); }  // (an error leaves nothing behind; success with cnt_keep has moved the arenas out)
@@ -1254,7 +1272,7 @@ int rc_count_finish(rc_ctx *ctx, int min_count, int64_t *n_kmers)
     const int k = ctx->k;
     // passes: a pass holds, per k-mer occurrence of its slice, the key (8 B), its sorted copy (8 B), the sort's scratch
     // (~8 B) and the run-length output (8 + 4 + 1 B)
-    size_t mem = (size_t)24 << 30;
+    size_t mem = (size_t)48 << 30;
     if (const char *e = getenv("RC_COUNT_MEM_MB")) mem = (size_t)atoll(e) << 20;
     const double per_occ = 40.0;
     uint32_t P = (uint32_t)((double)ctx->cnt_total * per_occ * 1.15 / (double)mem) + 1;
@@ -1278,39 +1296,35 @@ int rc_count_finish(rc_ctx *ctx, int min_count, int64_t *n_kmers)
         rc_set_error(ctx, "count: a pass of %zu k-mer occurrences exceeds 2^32 (lower RC_COUNT_MEM_MB for more passes)", max_slice);
         return RC_ERR_ARG;
     }
-    // kept entries of all passes, in chunks (their number is known only at the end)
-    struct kept {
-        uint64_t *keys;
-        int32_t *counts;
-        size_t n;
-    };
-    std::vector<kept> outs;
-    struct free_outs {
-        std::vector<kept> *o;
-        ~free_outs()
-        {
-            for (auto &x : *o) {
-                (void)hipFree(x.keys);
-                (void)hipFree(x.counts);
-            }
-        }
-    } guard2{&outs};
-    size_t total_kept = 0;
+    // The kept entries of all passes go straight into the two arrays the table is built from.  Their number is known only
+    // at the end: the arrays are sized from the first pass that keeps anything (its share of the occurrences, + 15 %) and
+    // regrown in the rare case a later pass does not fit.  One allocation holds the passes' scratch.  (Round 3 allocated
+    // per pass and concatenated at the end: some forty hipMalloc / hipFree calls, each a round trip through the kernel
+    // driver -- 0.1 s on a quiet host, 0.5 s and more on a busy one, against 0.2 s for the counting itself.)
+    rc_dev_tmp b_allk, b_allc;
+    size_t total_kept = 0, cap_kept = 0;
     if (max_slice > 0) {
-        rc_dev_tmp b_keys, b_keys_s, b_cnt, b_runs, b_keep, b_tmp, b_selk, b_selc;
-        size_t t_sort = 0, t_rle = 0, t_sel = 0;
-        RC_CHECK_HIP(ctx, b_keys.alloc(max_slice * 8));
-        RC_CHECK_HIP(ctx, b_keys_s.alloc(max_slice * 8));
-        RC_CHECK_HIP(ctx, b_cnt.alloc(max_slice * 4));
-        RC_CHECK_HIP(ctx, b_keep.alloc(max_slice));
-        RC_CHECK_HIP(ctx, b_runs.alloc(sizeof(size_t) * 2));
-        uint64_t *keys = b_keys.as<uint64_t>(), *keys_s = b_keys_s.as<uint64_t>();
-        uint32_t *cnt = b_cnt.as<uint32_t>();
-        size_t *d_runs = b_runs.as<size_t>();
-        RC_CHECK_HIP(ctx, rocprim::radix_sort_keys(nullptr, t_sort, keys, keys_s, max_slice, 0, 2 * k > 64 ? 64 : 2 * k, ctx->stream));
-        RC_CHECK_HIP(ctx, rocprim::run_length_encode(nullptr, t_rle, keys_s, (unsigned int)max_slice, keys, cnt, d_runs, ctx->stream));
-        RC_CHECK_HIP(ctx, rocprim::select(nullptr, t_sel, keys, b_keep.as<uint8_t>(), keys_s, d_runs, max_slice, ctx->stream));
-        RC_CHECK_HIP(ctx, b_tmp.alloc(std::max(t_sort, std::max(t_rle, t_sel))));
+        size_t ts_sort = 0, ts_rle = 0, ts_sel = 0;
+        RC_CHECK_HIP(ctx, rocprim::radix_sort_keys(nullptr, ts_sort, (uint64_t *)nullptr, (uint64_t *)nullptr, max_slice, 0, 2 * k > 64 ? 64 : 2 * k, ctx->stream));
+        RC_CHECK_HIP(ctx, rocprim::run_length_encode(nullptr, ts_rle, (uint64_t *)nullptr, (unsigned int)max_slice, (uint64_t *)nullptr, (uint32_t *)nullptr,
+                                                     (size_t *)nullptr, ctx->stream));
+        RC_CHECK_HIP(ctx, rocprim::select(nullptr, ts_sel, (uint64_t *)nullptr, (uint8_t *)nullptr, (uint64_t *)nullptr, (size_t *)nullptr, max_slice, ctx->stream));
+        const size_t tmp_bytes = std::max(ts_sort, std::max(ts_rle, ts_sel));
+        auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+        const size_t o_keys = 0, o_keys_s = o_keys + up(max_slice * 8), o_cnt = o_keys_s + up(max_slice * 8), o_keep = o_cnt + up(max_slice * 4),
+                     o_runs = o_keep + up(max_slice), o_tmp = o_runs + 256, pool_bytes = o_tmp + up(tmp_bytes);
+        rc_dev_tmp b_pool;
+        const double ta0 = now();
+        RC_CHECK_HIP(ctx, b_pool.alloc(pool_bytes));
+        t_alloc += now() - ta0;
+        char *pool = b_pool.as<char>();
+        uint64_t *keys = (uint64_t *)(pool + o_keys), *keys_s = (uint64_t *)(pool + o_keys_s);
+        uint32_t *cnt = (uint32_t *)(pool + o_cnt);
+        uint8_t *keep = (uint8_t *)(pool + o_keep);
+        size_t *d_runs = (size_t *)(pool + o_runs);
+        void *tmp = pool + o_tmp;
+        unsigned long long occ_total = 0;
+        for (uint32_t p = 0; p < P; ++p) occ_total += hist[p];
         for (uint32_t p = 0; p < P; ++p) {
             const size_t m = (size_t)hist[p];
             if (m == 0) continue;
@@ -1321,54 +1335,86 @@ int rc_count_finish(rc_ctx *ctx, int min_count, int64_t *n_kmers)
                                    (unsigned long long *)nullptr, keys, b_cursor.as<unsigned long long>());
             }
             RC_CHECK_HIP(ctx, hipGetLastError());
-            RC_CHECK_HIP(ctx, rocprim::radix_sort_keys(b_tmp.p, t_sort, keys, keys_s, m, 0, 2 * k > 64 ? 64 : 2 * k, ctx->stream));
-            RC_CHECK_HIP(ctx, rocprim::run_length_encode(b_tmp.p, t_rle, keys_s, (unsigned int)m, keys, cnt, d_runs, ctx->stream));
+            double tp = now();
+            if (timing) {
+                RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                t_emit += now() - tp;
+                tp = now();
+            }
+            size_t t1 = tmp_bytes;
+            RC_CHECK_HIP(ctx, rocprim::radix_sort_keys(tmp, t1, keys, keys_s, m, 0, 2 * k > 64 ? 64 : 2 * k, ctx->stream));
+            if (timing) {
+                RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                t_sort += now() - tp;
+                tp = now();
+            }
+            t1 = tmp_bytes;
+            RC_CHECK_HIP(ctx, rocprim::run_length_encode(tmp, t1, keys_s, (unsigned int)m, keys, cnt, d_runs, ctx->stream));
             size_t runs = 0;
             RC_CHECK_HIP(ctx, hipMemcpyAsync(&runs, d_runs, sizeof(size_t), hipMemcpyDeviceToHost, ctx->stream));
             RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            t_rle += now() - tp;
             if (runs == 0) continue;
-            hipLaunchKernelGGL(k_flag_keep, dim3((unsigned)((runs + 255) / 256)), dim3(256), 0, ctx->stream, keys, cnt, runs, min_count, b_keep.as<uint8_t>());
-            // the kept keys land in keys_s (free again), their counts behind them in the same buffer's upper half is not
-            // possible (8 vs 4 bytes): counts go through a second select into the sort scratch's neighbour, cnt's own copy
-            RC_CHECK_HIP(ctx, rocprim::select(b_tmp.p, t_sel, keys, b_keep.as<uint8_t>(), keys_s, d_runs, runs, ctx->stream));
+            tp = now();
+            hipLaunchKernelGGL(k_flag_keep, dim3((unsigned)((runs + 255) / 256)), dim3(256), 0, ctx->stream, keys, cnt, runs, min_count, keep);
+            // the kept keys land in keys_s (free again) and are copied out; their counts go through a second select into the
+            // same buffer and from there, clamped to int32, to their place
+            t1 = tmp_bytes;
+            RC_CHECK_HIP(ctx, rocprim::select(tmp, t1, keys, keep, keys_s, d_runs, runs, ctx->stream));
             size_t nsel = 0;
             RC_CHECK_HIP(ctx, hipMemcpyAsync(&nsel, d_runs, sizeof(size_t), hipMemcpyDeviceToHost, ctx->stream));
             RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            t_sel += now() - tp;
             if (nsel == 0) continue;
-            kept o{nullptr, nullptr, nsel};
-            RC_CHECK_HIP(ctx, hipMalloc((void **)&o.keys, nsel * 8));
-            outs.push_back(o);  // (from here on released by guard2)
-            RC_CHECK_HIP(ctx, hipMalloc((void **)&outs.back().counts, nsel * 4));
-            RC_CHECK_HIP(ctx, hipMemcpyAsync(outs.back().keys, keys_s, nsel * 8, hipMemcpyDeviceToDevice, ctx->stream));
+            if (total_kept + nsel > cap_kept) {
+                const double ta1 = now();
+                // what this pass kept of its occurrences, applied to the occurrences still to come
+                unsigned long long seen = 0;
+                for (uint32_t q = 0; q <= p; ++q) seen += hist[q];
+                const double per_occ_kept = (double)(total_kept + nsel) / (double)(seen ? seen : 1);
+                size_t want = (size_t)(per_occ_kept * (double)occ_total * (cap_kept ? 1.5 : 1.15)) + ((size_t)1 << 20);
+                static const bool tight = getenv("RC_COUNT_TIGHT") != nullptr;  // tests: no slack, every pass regrows the arrays
+                if (want < total_kept + nsel || tight) want = total_kept + nsel;
+                rc_dev_tmp nk, nc;
+                RC_CHECK_HIP(ctx, nk.alloc((want + 1) * 8));
+                RC_CHECK_HIP(ctx, nc.alloc((want + 1) * 4));
+                if (total_kept) {
+                    RC_CHECK_HIP(ctx, hipMemcpyAsync(nk.p, b_allk.p, total_kept * 8, hipMemcpyDeviceToDevice, ctx->stream));
+                    RC_CHECK_HIP(ctx, hipMemcpyAsync(nc.p, b_allc.p, total_kept * 4, hipMemcpyDeviceToDevice, ctx->stream));
+                    RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                }
+                std::swap(nk.p, b_allk.p);
+                std::swap(nc.p, b_allc.p);
+                cap_kept = want;
+                t_alloc += now() - ta1;
+            }
+            RC_CHECK_HIP(ctx, hipMemcpyAsync(b_allk.as<uint64_t>() + total_kept, keys_s, nsel * 8, hipMemcpyDeviceToDevice, ctx->stream));
             uint32_t *selc = reinterpret_cast<uint32_t *>(keys_s);  // (keys_s was copied out: the stream orders the reuse)
-            RC_CHECK_HIP(ctx, rocprim::select(b_tmp.p, t_sel, cnt, b_keep.as<uint8_t>(), selc, d_runs, runs, ctx->stream));
-            hipLaunchKernelGGL(k_u32_to_i32_clamped, dim3((unsigned)((nsel + 255) / 256)), dim3(256), 0, ctx->stream, selc, outs.back().counts, nsel);
+            t1 = tmp_bytes;
+            RC_CHECK_HIP(ctx, rocprim::select(tmp, t1, cnt, keep, selc, d_runs, runs, ctx->stream));
+            hipLaunchKernelGGL(k_u32_to_i32_clamped, dim3((unsigned)((nsel + 255) / 256)), dim3(256), 0, ctx->stream, selc, b_allc.as<int32_t>() + total_kept, nsel);
             RC_CHECK_HIP(ctx, hipGetLastError());
             total_kept += nsel;
         }
         RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
+    if (!b_allk.p) {  // nothing kept: the build still wants its two arrays
+        RC_CHECK_HIP(ctx, b_allk.alloc(8));
+        RC_CHECK_HIP(ctx, b_allc.alloc(4));
+    }
     if (ctx->cnt_keep) {  // the reads stay where they are for rc_submit_resident
         ctx->kept_arenas.swap(ctx->cnt_arenas);
+        ctx->kept_chunks.swap(ctx->cnt_chunks);
+        ctx->cnt_chunk_used = 0;
         ctx->cnt_total = 0;
     }
+    const double t_passes = now();
     rc_count_release(ctx);  // the reads are no longer needed: their memory goes to the table build
-    rc_dev_tmp b_allk, b_allc;
-    RC_CHECK_HIP(ctx, b_allk.alloc((total_kept + 1) * 8));
-    RC_CHECK_HIP(ctx, b_allc.alloc((total_kept + 1) * 4));
-    size_t at = 0;
-    for (auto &x : outs) {
-        RC_CHECK_HIP(ctx, hipMemcpyAsync(b_allk.as<uint64_t>() + at, x.keys, x.n * 8, hipMemcpyDeviceToDevice, ctx->stream));
-        RC_CHECK_HIP(ctx, hipMemcpyAsync(b_allc.as<int32_t>() + at, x.counts, x.n * 4, hipMemcpyDeviceToDevice, ctx->stream));
-        at += x.n;
-    }
-    RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (auto &x : outs) {
-        (void)hipFree(x.keys);
-        (void)hipFree(x.counts);
-    }
-    outs.clear();
+    const double t_concat = now();
     int rc = rc_build_table_from_device_pairs(ctx, b_allk.as<uint64_t>(), b_allc.as<int32_t>(), total_kept);
+    if (timing)
+        fprintf(stderr, "[rc count timing] finish %.3f s: histogram + %u passes %.3f (emit %.3f, sort %.3f, run lengths %.3f, select %.3f, hipMalloc %.3f), reads released %.3f, table build %.3f\n",
+                now() - t_begin, P, t_passes - t_begin, t_emit, t_sort, t_rle, t_sel, t_alloc, t_concat - t_passes, now() - t_concat);
     if (rc != RC_OK) rc_kept_release(ctx);
     if (n_kmers) *n_kmers = (int64_t)total_kept;
     return rc;
