@@ -345,6 +345,29 @@ struct PinBuf {
     }
 };
 
+// the formatted records of a slice of a batch: a Buf with a length (big slices are huge-page mappings that go back to the
+// system when the job retires; as std::vector<char> they sat in the malloc heap -- gigabytes of 4 KB pages -- until exit)
+struct OutBuf {
+    Buf b;
+    size_t n = 0;
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    char *data() { return b.p; }
+    const char *data() const { return b.p; }
+    void clear() { n = 0; }
+    void reserve(size_t c) { b.need(c); }
+    void resize(size_t c)
+    {
+        b.need(c);
+        n = c;
+    }
+    void swap(OutBuf &o)
+    {
+        b.swap(o.b);
+        std::swap(n, o.n);
+    }
+};
+
 // ---- input: a stream of bytes cut into blocks of whole records --------------------------------
 struct Source {
     std::string path;
@@ -641,7 +664,7 @@ static void open_file(ReadFile &f, const char *path, bool paired, bool interleav
 // the slices of a batch, in order.  One thread per output file: buffered writes to one file are serialised by the
 // kernel (the inode's lock), so more writers only add contention -- measured on the GPU box's host: 9.1 GB/s from
 // one thread, 8.4 from 32 (tools/mb/iob.cpp); two files written side by side get 14.5 GB/s
-static void emit_slices(ReadFile &f, const std::vector<std::vector<char>> &sl)
+static void emit_slices(ReadFile &f, const std::vector<OutBuf> &sl)
 {
     size_t total = 0;
     for (const auto &v : sl) total += v.size();
@@ -665,7 +688,7 @@ static void emit_slices(ReadFile &f, const std::vector<std::vector<char>> &sl)
 }
 
 // one gzip member (RFC 1952) holding `in`, deflate level 1
-static void gzip_member(const std::vector<char> &in, std::vector<char> &out)
+static void gzip_member(const OutBuf &in, OutBuf &out)
 {
     z_stream z;
     memset(&z, 0, sizeof z);
@@ -711,7 +734,7 @@ struct Job {
     // -packed: the batch as rc_packed_batch wants it (one offset array over both arenas, 2-bit codes, quality bits, the
     // letters outside ACGT) and the room for the fix list
     PinBuf pk_off, pk_bases, pk_qbits, pk_exc_pos, pk_exc_chr, pk_fix_pos, pk_fix_chr;
-    std::vector<std::vector<char>> o1, o2;  // the formatted (and, for .gz, deflated) output records, in slices
+    std::vector<OutBuf> o1, o2;  // the formatted (and, for .gz, deflated) output records, in slices
     bool done = false;
     int rc = 0;
     std::string err;
@@ -882,7 +905,8 @@ static inline char *put_int(char *p, int v)
 
 // Reads.h:360-421: one record.  The quality line is printed as fgets left it in the reference:
 // stripped of its newline only when it is exactly as long as the sequence line (Reads.h:255-262).
-static inline void put_record(std::vector<char> &out, const Arena &A, size_t r, bool fastq, int cor, int l, int m, int h)
+template <class B>
+static inline void put_record(B &out, const Arena &A, size_t r, bool fastq, int cor, int l, int m, int h)
 {
     uint32_t il, ql = 0;
     const char *id = A.line(r, 0, &il);
@@ -1431,7 +1455,7 @@ int main(int argc, char **argv)
                     A.seq.need(arena_bytes);   // (page-locked here: rc_host_register)
                     A.qual.need(arena_bytes);
                 }
-                std::vector<std::vector<char>> &o = sd ? j->o2 : j->o1;
+                std::vector<OutBuf> &o = sd ? j->o2 : j->o1;
                 o.resize(S);
                 for (auto &v : o) v.reserve(out_slice);
             }
@@ -1441,9 +1465,10 @@ int main(int argc, char **argv)
                     Arena &A = sd ? j->b : j->a;
                     const size_t lo = text_bytes * t / 16, hi = text_bytes * (t + 1) / 16;
                     if (!resident) memset(A.blk.text.p + lo, 0, hi - lo);
-                    std::vector<std::vector<char>> &o = sd ? j->o2 : j->o1;
+                    std::vector<OutBuf> &o = sd ? j->o2 : j->o1;
                     for (size_t s2 = t; s2 < S; s2 += 16) {
                         o[s2].resize(out_slice);
+                        memset(o[s2].data(), 0, out_slice);
                         o[s2].clear();
                     }
                 }
@@ -1551,7 +1576,7 @@ int main(int argc, char **argv)
         ReadFile &f = files[(size_t)j->file];
         const bool alternate = j->mode == 1 && g_stdout;  // main.cpp:487-495
         const size_t S = std::max<size_t>(1, std::min<size_t>((size_t)g_threads, (n + 8191) / 8192));
-        std::vector<std::vector<char>> &o1 = J.o1, &o2 = J.o2;
+        std::vector<OutBuf> &o1 = J.o1, &o2 = J.o2;
         o1.resize(S);
         o2.resize(S);
         for (auto &v : o1) v.clear();
@@ -1576,7 +1601,7 @@ int main(int argc, char **argv)
         // `-p a.fq.gz b.fq` writes a gzip stream for the first mates and plain text for the second
         const bool gz1 = f.out_gz && !g_stdout, gz2 = j->mode == 1 && mates[(size_t)j->file].out_gz && !g_stdout;
         if (gz1 || gz2) {  // deflate every slice into its own gzip member, in parallel
-            std::vector<std::vector<char>> z1(S), z2(S);
+            std::vector<OutBuf> z1(S), z2(S);
             g_pool.run(S, [&](size_t s) {
                 if (gz1 && !o1[s].empty()) gzip_member(o1[s], z1[s]);
                 if (gz2 && !o2[s].empty()) gzip_member(o2[s], z2[s]);
@@ -2041,9 +2066,9 @@ int main(int argc, char **argv)
     for (size_t fi = 0; fi < files.size(); ++fi) {
         for (ReadFile *f : {&files[fi], &mates[fi]}) {
             if (f->out && f->out_gz && !f->wrote) {  // an empty .gz is still one (empty) gzip member
-                std::vector<char> none, z;
+                OutBuf none, z;
                 gzip_member(none, z);
-                std::vector<std::vector<char>> one(1);
+                std::vector<OutBuf> one(1);
                 one[0].swap(z);
                 emit_slices(*f, one);
             }
@@ -2074,6 +2099,7 @@ int main(int argc, char **argv)
         stamp("teardown: job buffers unregistered and freed");
         for (rc_ctx *c : ctx) rc_destroy(c);
         stamp("teardown: contexts destroyed");
+
     }
     fflush(NULL);
     _exit(0);  // every output is closed: skip unmapping gigabytes of buffers one by one
