@@ -1024,69 +1024,7 @@ static void put_transcript(std::vector<char> &out, const Job &J, const Arena &A,
     }
 }
 
-// ---- k-mer counting pass (only without -c) ----------------------------------------------------
-// A reader thread cuts each input into blocks of whole records and packs the sequence lines into a
-// NUL-separated arena; this thread hands the arenas to the streaming counter.
-static void count_inputs(rc_ctx *ctx, const std::vector<std::pair<std::string, bool>> &inputs, int64_t *stored)
-{
-    const size_t BLOCK = (size_t)4 << 20;  // records per arena
-    std::mutex mu;
-    std::condition_variable cv;
-    std::deque<std::vector<char>> q;
-    bool done = false;
-    std::thread reader([&]() {
-        for (const auto &in : inputs) {
-            Source s;
-            s.open(in.first);
-            const int lpr = in.second ? 4 : 2;
-            Block b;
-            for (;;) {
-                take_records(s, BLOCK, lpr, b);
-                if (b.records == 0) break;
-                std::vector<uint64_t> off(b.records + 1, 0);
-                for (size_t r = 0; r < b.records; ++r) {
-                    const size_t li = r * (size_t)lpr + 1;
-                    off[r + 1] = off[r] + (b.line[li + 1] - b.line[li]);  // bases + the NUL
-                }
-                std::vector<char> arena(off[b.records]);
-                parallel_for(b.records, [&](size_t lo, size_t hi) {
-                    for (size_t r = lo; r < hi; ++r) {
-                        const size_t li = r * (size_t)lpr + 1;
-                        const uint32_t sl = b.line[li + 1] - b.line[li] - 1;
-                        char *d = arena.data() + off[r];
-                        memcpy(d, b.text.data() + b.line[li], sl);
-                        d[sl] = 0;
-                    }
-                });
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return q.size() < 2; });
-                q.emplace_back(std::move(arena));
-                cv.notify_all();
-            }
-            s.close();
-        }
-        std::lock_guard<std::mutex> lk(mu);
-        done = true;
-        cv.notify_all();
-    });
-    if (rc_table_count_begin(ctx)) die("rcorrector: %s\n", rc_last_error(ctx));
-    for (;;) {
-        std::vector<char> arena;
-        {
-            std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return done || !q.empty(); });
-            if (q.empty()) break;
-            arena.swap(q.front());
-            q.pop_front();
-            cv.notify_all();
-        }
-        if (rc_table_count_add(ctx, arena.data(), arena.size())) die("rcorrector: %s\n", rc_last_error(ctx));
-    }
-    reader.join();
-    if (rc_table_count_finish(ctx, 2, stored)) die("rcorrector: %s\n", rc_last_error(ctx));
-}
-
-// ---- one pass over the input (no -c, plain files that fit): what the counting pass read stays ------------------
+// ---- k-mer counting pass (only without -c); one pass over the input where it fits: what the counting pass read stays ----
 // The reference's pipeline reads every file twice -- jellyfish counts the k-mers (run_rcorrector.pl:262-281), stage 3
 // corrects -- and so does the counting pass above followed by the correction loop.  When the inputs are plain files that
 // fit (text in host memory, bases in HBM), the counting pass cuts them into the correction loop's batches right away:
@@ -1101,46 +1039,71 @@ struct Retained {
     int arena_a = 0, arena_b = 0;
 };
 
+// keep = false: the counting pass of a run in two passes (.gz inputs, inputs beyond the memory test, several GPUs): the same
+// reader -- both mates' files side by side, parallel block reads, page-locked staging -- over sources of its own; the blocks
+// are recycled instead of kept, and the counter releases the arenas when it has counted them.
 static void ingest_resident(rc_ctx *ctx, std::vector<ReadFile> &files, std::vector<ReadFile> &mates, size_t batch_reads,
-                            std::vector<std::unique_ptr<Retained>> &kept, int64_t *stored)
+                            std::vector<std::unique_ptr<Retained>> &kept, int64_t *stored, bool keep)
 {
     std::mutex mu;
     std::condition_variable cv;
     std::deque<std::unique_ptr<Retained>> q;
+    std::vector<std::unique_ptr<Retained>> spare;  // keep = false: blocks to fill again
     bool done = false;
     std::thread reader([&]() {
         for (size_t fi = 0; fi < files.size(); ++fi) {
             ReadFile &f = files[fi];
+            Source own_a, own_b;
+            if (!keep) {
+                own_a.open(f.path);
+                if (f.paired) own_b.open(mates[fi].path);
+            }
+            Source &src_a = keep ? f.src : own_a, &src_b = keep ? mates[fi].src : own_b;
             for (;;) {
-                std::unique_ptr<Retained> R(new Retained);
+                std::unique_ptr<Retained> R;
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    if (!spare.empty()) {
+                        R = std::move(spare.back());
+                        spare.pop_back();
+                    }
+                }
+                if (!R) R.reset(new Retained);
                 R->file = (int)fi;
                 R->mode = f.paired ? 1 : (f.interleaved ? 2 : 0);
                 R->fastq = f.fastq;
                 R->lpr_a = f.fastq ? 4 : 2;
                 R->lpr_b = f.paired ? (mates[fi].fastq ? 4 : 2) : R->lpr_a;
                 const double tr0 = now_s();
+                R->b.records = 0;
                 if (f.paired) {
-                    std::thread mate([&]() { take_records(mates[fi].src, batch_reads, R->lpr_b, R->b); });
-                    take_records(f.src, batch_reads, R->lpr_a, R->a);
+                    std::thread mate([&]() { take_records(src_b, batch_reads, R->lpr_b, R->b); });
+                    take_records(src_a, batch_reads, R->lpr_a, R->a);
                     mate.join();
-                    if (R->b.records != R->a.records) die("ERROR: The files are not paired!\n");
+                    // (two passes: files that are not paired are the correction loop's to refuse, with the reference's message
+                    // in the reference's place on stderr; the counter takes whatever reads there are)
+                    if (keep && R->b.records != R->a.records) die("ERROR: The files are not paired!\n");
                 } else {
-                    take_records(f.src, batch_reads, R->lpr_a, R->a);
+                    take_records(src_a, batch_reads, R->lpr_a, R->a);
                 }
-                if (R->a.records == 0) break;
-                if (R->mode == 2 && (R->a.records & 1)) die("ERROR: interleaved file %s holds an odd number of reads\n", f.path.c_str());
+                if (R->a.records == 0 && R->b.records == 0) break;
+                if (keep && R->mode == 2 && (R->a.records & 1)) die("ERROR: interleaved file %s holds an odd number of reads\n", f.path.c_str());
                 g_t_read += now_s() - tr0;
                 std::unique_lock<std::mutex> lk(mu);
                 cv.wait(lk, [&] { return q.size() < 3; });
                 q.emplace_back(std::move(R));
                 cv.notify_all();
             }
+            if (!keep) {
+                own_a.close();
+                if (f.paired) own_b.close();
+            }
         }
         std::lock_guard<std::mutex> lk(mu);
         done = true;
         cv.notify_all();
     });
-    if (rc_table_count_keep(ctx, 1) || rc_table_count_begin(ctx)) die("rcorrector: %s\n", rc_last_error(ctx));
+    if (rc_table_count_keep(ctx, keep ? 1 : 0) || rc_table_count_begin(ctx)) die("rcorrector: %s\n", rc_last_error(ctx));
     PinBuf stage;  // the sequences of one file's share of a batch on their way to HBM
     int next_arena = 0;
     for (;;) {
@@ -1155,9 +1118,11 @@ static void ingest_resident(rc_ctx *ctx, std::vector<ReadFile> &files, std::vect
         }
         const double tp0 = now_s();
         for (int sd = 0; sd < (R->mode == 1 ? 2 : 1); ++sd) {
+            if ((sd ? R->b : R->a).records == 0) continue;  // (keep = false: one mate's file ended before the other's)
             Arena A;  // (a view for index_arena / pack_sequences: the block is swapped in and out)
             A.lpr = sd ? R->lpr_b : R->lpr_a;
             A.blk.swap(sd ? R->b : R->a);
+            A.off.swap(sd ? R->off_b : R->off_a);  // (its capacity, when the block is a recycled one)
             const uint64_t total = index_arena(A, sd ? mates[(size_t)R->file].path : files[(size_t)R->file].path);
             stage.need(total + 64);
             pack_sequences(A, stage.data());
@@ -1168,10 +1133,15 @@ static void ingest_resident(rc_ctx *ctx, std::vector<ReadFile> &files, std::vect
             A.blk.swap(sd ? R->b : R->a);
         }
         g_t_pack += now_s() - tp0;
-        kept.emplace_back(std::move(R));
+        if (keep) {
+            kept.emplace_back(std::move(R));
+        } else {
+            std::lock_guard<std::mutex> lk(mu);
+            spare.emplace_back(std::move(R));
+        }
     }
     reader.join();
-    stamp("inputs read, indexed and uploaded");
+    stamp(keep ? "inputs read, indexed and uploaded" : "inputs read and uploaded for the k-mer count");
     if (rc_table_count_finish(ctx, 2, stored)) die("rcorrector: %s\n", rc_last_error(ctx));
     stamp("k-mers counted, table built");
 }
@@ -1499,10 +1469,7 @@ int main(int argc, char **argv)
             inputs.emplace_back(files[fi].path, files[fi].fastq);
             if (files[fi].paired) inputs.emplace_back(mates[fi].path, mates[fi].fastq);
         }
-        if (resident)
-            ingest_resident(ctx[0], files, mates, batch_reads, kept, &stored);
-        else
-            count_inputs(ctx[0], inputs, &stored);
+        ingest_resident(ctx[0], files, mates, resident ? batch_reads : std::max<size_t>(batch_reads, (size_t)1 << 20), kept, &stored, resident);
         if (g_timing)
             fprintf(stderr, "[rc timing] k-mer counting pass over %zu file(s): %.2f s%s\n", inputs.size(), now_s() - t_start,
                     resident ? " (one pass: the text stays in host memory, the bases in HBM)" : "");

@@ -1076,7 +1076,7 @@ int rc_launch_probe(rc_ctx *ctx, const uint8_t *d_seq, size_t nbytes, int32_t *d
 // 100 M x 150 bp are 15 GB of 288), and finish() makes P passes over them; pass p looks only at the k-mers whose
 // hash falls into slice p of P -- emit -> radix sort -> run-length encode -> keep count >= min_count -- so that no
 // more than 1/P of the k-mer occurrences is ever in flight, whatever share of them are singletons.  A histogram
-// pass sizes the slices; P follows from the memory the passes may use (RC_COUNT_MEM_MB, default 48 GiB).  The result
+// pass sizes the slices; P follows from the memory the passes may use (RC_COUNT_MEM_MB, default 24 GiB).  The result
 // is what `jellyfish count -C` + `dump -L 2` hands to the reference: every canonical k-mer with its exact count.
 __global__ void k_u32_to_i32_clamped(const uint32_t *in, int32_t *out, size_t n)
 {
@@ -1272,7 +1272,7 @@ int rc_count_finish(rc_ctx *ctx, int min_count, int64_t *n_kmers)
     const int k = ctx->k;
     // passes: a pass holds, per k-mer occurrence of its slice, the key (8 B), its sorted copy (8 B), the sort's scratch
     // (~8 B) and the run-length output (8 + 4 + 1 B)
-    size_t mem = (size_t)48 << 30;
+    size_t mem = (size_t)24 << 30;
     if (const char *e = getenv("RC_COUNT_MEM_MB")) mem = (size_t)atoll(e) << 20;
     const double per_occ = 40.0;
     uint32_t P = (uint32_t)((double)ctx->cnt_total * per_occ * 1.15 / (double)mem) + 1;
