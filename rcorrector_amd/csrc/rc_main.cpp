@@ -1374,6 +1374,12 @@ int main(int argc, char **argv)
                 if (!strncmp(ln, "MemAvailable:", 13)) avail = (uint64_t)atoll(ln + 13) << 10;
             fclose(mi);
         }
+        for (const char *lim : {"/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"})  // a container's own limit
+            if (FILE *cg = fopen(lim, "r")) {
+                char ln[64];
+                if (fgets(ln, sizeof ln, cg) && ln[0] >= '0' && ln[0] <= '9') avail = std::min<uint64_t>(avail, strtoull(ln, nullptr, 10));
+                fclose(cg);
+            }
         const char *e = getenv("RC_RESIDENT");
         resident = plain && (e ? atoi(e) != 0 : (text_bytes <= avail / 3 && text_bytes / 2 <= ((uint64_t)96 << 30)));
         if (e && atoi(e) > 1) batch_reads = std::max<size_t>(2, (size_t)atoi(e)) & ~(size_t)1;  // (tests: RC_RESIDENT=<batch size>)
