@@ -19,6 +19,7 @@
 // for packing / formatting.
 // -verbose prints the reference's per-read transcript (the -t 1 order) from rc_correct_batch_traced;
 // -write-dump FILE keeps the k-mer table as jellyfish-dump text; without -c the k-mers are counted here.
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <malloc.h>
 #include <sched.h>
@@ -54,6 +55,7 @@ static bool g_verbose = false;   // -verbose: the reference's per-read transcrip
 static int g_trace_iter = 64;    // threshold iterations recorded per read under -verbose
 static bool g_timing = false;  // RC_TIMING=1: phase timings on stderr (off by default: stderr is part of the contract)
 static int g_threads = 8;
+static size_t g_deflate_threads = 0;  // helper threads that deflate the slices of .gz outputs (0: no such output)
 static bool g_packed = false;  // -packed / RC_TRANSPORT=packed: batches cross PCIe through rc_submit_packed (2-bit bases, quality bits, fix list)
 
 static double g_w_reader = 0, g_w_writer = 0, g_w_worker = 0;  // RC_TIMING: time blocked on the neighbouring stage
@@ -368,6 +370,44 @@ struct OutBuf {
     }
 };
 
+// libdeflate, where the system has it (libdeflate.so.0, looked up at run time: the image carries the library without its
+// header): whole-buffer inflate and deflate two to three times as fast as zlib's streams.  The bytes of a .gz OUTPUT differ
+// from zlib's (and from the reference's single stream) -- their content does not, which is what the format promises and the
+// tests compare; a .gz INPUT decompresses to the same bytes or the file is read again with zlib.  RC_LIBDEFLATE=0: zlib only.
+struct LibDeflate {
+    void *h = nullptr;
+    void *(*alloc_d)() = nullptr;
+    int (*gunzip_ex)(void *, const void *, size_t, void *, size_t, size_t *, size_t *) = nullptr;
+    void (*free_d)(void *) = nullptr;
+    void *(*alloc_c)(int) = nullptr;
+    size_t (*gzip)(void *, const void *, size_t, void *, size_t) = nullptr;
+    size_t (*gzip_bound)(void *, size_t) = nullptr;
+    void (*free_c)(void *) = nullptr;
+    bool ok = false;
+    LibDeflate()
+    {
+        const char *e = getenv("RC_LIBDEFLATE");
+        if (e && !strcmp(e, "0")) return;
+        h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return;
+        alloc_d = (void *(*)())dlsym(h, "libdeflate_alloc_decompressor");
+        gunzip_ex = (int (*)(void *, const void *, size_t, void *, size_t, size_t *, size_t *))dlsym(h, "libdeflate_gzip_decompress_ex");
+        free_d = (void (*)(void *))dlsym(h, "libdeflate_free_decompressor");
+        alloc_c = (void *(*)(int))dlsym(h, "libdeflate_alloc_compressor");
+        gzip = (size_t(*)(void *, const void *, size_t, void *, size_t))dlsym(h, "libdeflate_gzip_compress");
+        gzip_bound = (size_t(*)(void *, size_t))dlsym(h, "libdeflate_gzip_compress_bound");
+        free_c = (void (*)(void *))dlsym(h, "libdeflate_free_compressor");
+        ok = alloc_d && gunzip_ex && free_d && alloc_c && gzip && gzip_bound && free_c;
+    }
+};
+static const LibDeflate &libdeflate()
+{
+    static LibDeflate L;
+    return L;
+}
+
+static bool g_gz_whole = false;  // one-pass runs: a .gz input is inflated whole, in memory, by libdeflate (Source::inflate_whole)
+
 // ---- input: a stream of bytes cut into blocks of whole records --------------------------------
 struct Source {
     std::string path;
@@ -379,6 +419,81 @@ struct Source {
     off_t pos = 0;  // file offset of the next unread byte (seekable files)
     bool eof = false;
     double per_line = 0;  // bytes per line of the last block: sizes the next block's buffer in one go
+    // .gz, one-pass runs with libdeflate: the file's whole text, inflated at the first large request (the text of such a run
+    // stays in memory anyway); `served` = bytes handed out so far, by zlib before that (the peek at the head of the file)
+    size_t served = 0;
+    bool whole_tried = false, whole = false;
+    Buf dec;
+    size_t dec_len = 0;
+
+    // The whole file through libdeflate: every member, into `dec`.  The size of the text is not known in advance: the last four
+    // bytes of a gzip file hold it modulo 2^32 (exactly, for the usual single-member file), so the room is the smallest
+    // size with that remainder that is at least three times the compressed size, 4 GiB more whenever that was too little.
+    // Anything libdeflate does not like -- not gzip at all (zlib reads such a file as it is), a truncated file, bad data --
+    // returns false, and the file is read on through zlib, which owns the reference's behaviour for those.
+    bool inflate_whole()
+    {
+        const LibDeflate &LD = libdeflate();
+        if (!LD.ok) return false;
+        const int fd2 = ::open(path.c_str(), O_RDONLY);
+        if (fd2 < 0) return false;
+        struct stat st;
+        if (fstat(fd2, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 18) {
+            ::close(fd2);
+            return false;
+        }
+        const size_t csize = (size_t)st.st_size;
+        Buf comp;
+        comp.need(csize + 64);
+        {
+            const size_t SL = (size_t)8 << 20;
+            const size_t T = std::max<size_t>(1, std::min<size_t>((size_t)g_threads, (csize + SL - 1) / SL));
+            std::vector<char> good(T, 1);
+            g_pool.run(T, [&](size_t t) {
+                size_t at = csize * t / T;
+                const size_t hi = csize * (t + 1) / T;
+                while (at < hi) {
+                    const ssize_t n = ::pread(fd2, comp.p + at, hi - at, (off_t)at);
+                    if (n <= 0) {
+                        good[t] = 0;
+                        break;
+                    }
+                    at += (size_t)n;
+                }
+            });
+            ::close(fd2);
+            for (char g : good)
+                if (!g) return false;
+        }
+        const unsigned char *c = (const unsigned char *)comp.p;
+        if (c[0] != 0x1f || c[1] != 0x8b) return false;
+        const uint64_t isize = (uint64_t)c[csize - 4] | ((uint64_t)c[csize - 3] << 8) | ((uint64_t)c[csize - 2] << 16) | ((uint64_t)c[csize - 1] << 24);
+        void *d = LD.alloc_d();
+        if (!d) return false;
+        size_t in_pos = 0, out_pos = 0;
+        bool okay = true;
+        while (in_pos < csize) {
+            if (csize - in_pos < 18 || c[in_pos] != 0x1f || c[in_pos + 1] != 0x8b) break;  // (what follows the last member is ignored, as gzread does)
+            uint64_t room = isize;
+            while (room < 3 * (uint64_t)(csize - in_pos)) room += (uint64_t)1 << 32;
+            int res = 3;
+            size_t ain = 0, aout = 0;
+            for (int attempt = 0; attempt < 16 && res == 3; ++attempt, room += (uint64_t)1 << 32) {
+                dec.need(out_pos + (size_t)room + 64);
+                res = LD.gunzip_ex(d, c + in_pos, csize - in_pos, dec.p + out_pos, (size_t)room, &ain, &aout);  // 3 = not enough room
+            }
+            if (res != 0 || ain == 0) {
+                okay = false;
+                break;
+            }
+            in_pos += ain;
+            out_pos += aout;
+        }
+        LD.free_d(d);
+        if (!okay || out_pos < served) return false;
+        dec_len = out_pos;
+        return true;
+    }
 
     void open(const std::string &p)
     {
@@ -413,6 +528,23 @@ struct Source {
     {
         size_t got = 0;
         if (is_gz) {
+            if (g_gz_whole && !whole_tried && want > ((size_t)1 << 16)) {
+                whole_tried = true;
+                whole = inflate_whole();
+            }
+            if (whole) {  // (copied out by several threads, like the block reads of a plain file)
+                got = std::min(want, dec_len - served);
+                const size_t SL = (size_t)8 << 20;
+                const size_t T = std::max<size_t>(1, std::min<size_t>((size_t)g_threads, (got + SL - 1) / SL));
+                const char *src = dec.p + served;
+                g_pool.run(T, [&](size_t t) { memcpy(dst + got * t / T, src + got * t / T, got * (t + 1) / T - got * t / T); });
+                served += got;
+                if (served == dec_len) {
+                    eof = true;
+                    dec.release();
+                }
+                return got;
+            }
             while (got < want) {
                 const unsigned ch = (unsigned)std::min<size_t>(want - got, (size_t)1 << 30);
                 const int n = gzread(gz, dst + got, ch);
@@ -422,6 +554,7 @@ struct Source {
                 }
                 got += (size_t)n;
             }
+            served += got;
             return got;
         }
         if (!seekable) {
@@ -690,6 +823,19 @@ static void emit_slices(ReadFile &f, const std::vector<OutBuf> &sl)
 // one gzip member (RFC 1952) holding `in`, deflate level 1
 static void gzip_member(const OutBuf &in, OutBuf &out)
 {
+    const LibDeflate &LD = libdeflate();
+    if (LD.ok) {
+        static thread_local void *c = nullptr;  // (a compressor per thread: they are not shareable, and cost a few hundred KB)
+        if (!c) c = LD.alloc_c(1);
+        if (c) {
+            out.resize(LD.gzip_bound(c, in.size()) + 64);
+            const size_t n = LD.gzip(c, in.data(), in.size(), out.data(), out.size());
+            if (n) {
+                out.resize(n);
+                return;
+            }
+        }
+    }
     z_stream z;
     memset(&z, 0, sizeof z);
     if (deflateInit2(&z, 1, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) die("ERROR: zlib deflateInit2 failed\n");
@@ -1343,15 +1489,20 @@ int main(int argc, char **argv)
         const int node = rc_device_numa_node(ctx[0]);
         if (node >= 0 && bind_to_numa_node(node) && g_timing) fprintf(stderr, "[rc timing] host threads bound to NUMA node %d\n", node);
     }
-    g_pool.start((size_t)g_threads * 2);  // (the reader, the mate's reader and the workers call it side by side)
+    for (size_t fi = 0; fi < files.size(); ++fi)
+        if ((files[fi].out_gz || (files[fi].paired && mates[fi].out_gz)) && !g_stdout) {
+            const unsigned hc = std::thread::hardware_concurrency();
+            g_deflate_threads = t_flag > 1 ? (size_t)t_flag : std::min<size_t>(hc ? hc / 2 : 8, 96);
+        }
+    g_pool.start(std::max<size_t>((size_t)g_threads * 2, g_deflate_threads));  // (the reader, the mate's reader and the workers call it side by side)
     stamp("contexts created (HIP initialised, scratch allocated)");
     const double t_start = now_s();
     // While the table loads: the batch buffers of the pipeline -- text blocks, page-locked arenas, output slices --
     // are allocated, sized from the head of the first input, touched and registered with the GPU runtime here, so
     // that the first batches do not pay for a few GB of page faults and hipHostRegister calls one after the other
     const size_t max_in_flight = (size_t)(nworkers + 2);
-    // One pass (see ingest_resident): no dump, one GPU, plain regular files whose text fits a third of the memory that is
-    // available and whose bases fit the counter's share of HBM.  RC_RESIDENT=0 keeps the two passes, =1 skips the size test.
+    // One pass (see ingest_resident): no dump, one GPU, regular files (plain or .gz: one inflate pass instead of two) whose text
+    // fits a third of the memory that is available and whose bases fit the counter's share of HBM.  RC_RESIDENT=0 keeps the two passes, =1 skips the size test.
     bool resident = false;
     std::vector<std::unique_ptr<Retained>> kept;
     if (!dump && !verbose && gpus == 1 && !files.empty()) {
@@ -1361,7 +1512,15 @@ int main(int argc, char **argv)
             for (const ReadFile *f : {(const ReadFile *)&files[fi], files[fi].paired ? (const ReadFile *)&mates[fi] : (const ReadFile *)nullptr}) {
                 if (!f) continue;
                 struct stat st;
-                if (f->src.is_gz || !f->src.seekable || fstat(f->src.fd, &st) != 0) {
+                if (f->src.is_gz) {  // (its text is taken as eight times the file: FASTQ deflates to a fifth or a quarter)
+                    if (stat(f->path.c_str(), &st) != 0 || !S_ISREG(st.st_mode)) {
+                        plain = false;
+                        continue;
+                    }
+                    text_bytes += (uint64_t)st.st_size * 8;
+                    continue;
+                }
+                if (!f->src.seekable || fstat(f->src.fd, &st) != 0) {
                     plain = false;
                     continue;
                 }
@@ -1383,6 +1542,7 @@ int main(int argc, char **argv)
         const char *e = getenv("RC_RESIDENT");
         resident = plain && (e ? atoi(e) != 0 : (text_bytes <= avail / 3 && text_bytes / 2 <= ((uint64_t)96 << 30)));
         if (e && atoi(e) > 1) batch_reads = std::max<size_t>(2, (size_t)atoi(e)) & ~(size_t)1;  // (tests: RC_RESIDENT=<batch size>)
+        g_gz_whole = resident;
     }
     std::vector<std::shared_ptr<Job>> warm_jobs;
     // (the head of the first file is looked at here, not in the thread: the one-pass reader takes it out of the source)
@@ -1548,7 +1708,13 @@ int main(int argc, char **argv)
         const size_t n = j->a.n();
         ReadFile &f = files[(size_t)j->file];
         const bool alternate = j->mode == 1 && g_stdout;  // main.cpp:487-495
-        const size_t S = std::max<size_t>(1, std::min<size_t>((size_t)g_threads, (n + 8191) / 8192));
+        // compression is a property of each output file (Reads::AddReadFile picks it per input name):
+        // `-p a.fq.gz b.fq` writes a gzip stream for the first mates and plain text for the second
+        const bool gz1 = f.out_gz && !g_stdout, gz2 = j->mode == 1 && mates[(size_t)j->file].out_gz && !g_stdout;
+        // (slices of plain output are copied by at most g_threads threads -- memory-bound, more get in each other's way --
+        // slices that are deflated by as many as the pool has: that is arithmetic)
+        const size_t width = (gz1 || gz2) ? std::max<size_t>((size_t)g_threads, g_deflate_threads) : (size_t)g_threads;
+        const size_t S = std::max<size_t>(1, std::min<size_t>(width, (n + 8191) / 8192));
         std::vector<OutBuf> &o1 = J.o1, &o2 = J.o2;
         o1.resize(S);
         o2.resize(S);
@@ -1570,9 +1736,6 @@ int main(int argc, char **argv)
             }
         };
         g_pool.run(S, [&](size_t s) { fmt(s, s + 1); });
-        // compression is a property of each output file (Reads::AddReadFile picks it per input name):
-        // `-p a.fq.gz b.fq` writes a gzip stream for the first mates and plain text for the second
-        const bool gz1 = f.out_gz && !g_stdout, gz2 = j->mode == 1 && mates[(size_t)j->file].out_gz && !g_stdout;
         if (gz1 || gz2) {  // deflate every slice into its own gzip member, in parallel
             std::vector<OutBuf> z1(S), z2(S);
             g_pool.run(S, [&](size_t s) {

@@ -234,6 +234,39 @@ def test_cli_without_c_several_inputs_of_every_kind_one_pass_equals_two(tmp_path
     assert res[1] == res[0] and res[2] == res[0]
 
 
+def test_cli_without_c_gz_inputs_one_pass_equals_two(tmp_path):
+    """.gz inputs without -c: one pass inflates each file once -- whole, in memory, with libdeflate where the system has it
+    (RC_LIBDEFLATE=0: zlib streams) -- two passes inflate it twice with zlib; a file of several gzip members (what this
+    program writes itself, and what `cat a.gz b.gz` makes) must read as their concatenation.  The outputs are .gz files of
+    members deflated in parallel: compared after decompression, as everywhere."""
+    import gzip
+    import shutil
+    d = str(tmp_path)
+    g = gu.GOLDEN
+    for dst, (fx, src) in {"p_1.fq": ("fx_pe_k23", "reads_1.fq"), "p_2.fq": ("fx_pe_k23", "reads_2.fq"), "se.fq": ("fx_se_k23", "reads.fq")}.items():
+        data = open(os.path.join(g, fx, src), "rb").read()
+        if dst == "se.fq":   # three members, cut at record boundaries
+            recs = data.split(b"\n@")
+            cut1, cut2 = len(recs) // 3, 2 * len(recs) // 3
+            parts = [b"\n@".join(recs[:cut1]) + b"\n", b"@" + b"\n@".join(recs[cut1:cut2]) + b"\n", b"@" + b"\n@".join(recs[cut2:])]
+            assert b"".join(parts) == data
+            with open(os.path.join(d, dst + ".gz"), "wb") as f:
+                for part in parts:
+                    f.write(gzip.compress(part, 1))
+        else:
+            with open(os.path.join(d, dst + ".gz"), "wb") as f:
+                f.write(gzip.compress(data, 6))
+    args = ["-p", "p_1.fq.gz", "p_2.fq.gz", "-r", "se.fq.gz", "-k", "23"]
+    res = []
+    for tag, env in (("two", {"RC_RESIDENT": "0"}), ("one", {"RC_RESIDENT": "1"}), ("one_zlib", {"RC_RESIDENT": "1", "RC_LIBDEFLATE": "0"}),
+                     ("one_small", {"RC_RESIDENT": "10"})):
+        err, out = _run_env(CLI, args, d, os.path.join(d, tag), env)
+        res.append((err, {f: gzip.decompress(v) for f, v in out.items()}))
+    assert sorted(res[0][1]) == ["p_1.cor.fq.gz", "p_2.cor.fq.gz", "se.cor.fq.gz"] and all(len(v) > 0 for v in res[0][1].values())
+    for r in res[1:]:
+        assert r == res[0]
+
+
 def _run_env(binary, args, cwd, od, env):
     os.makedirs(od)
     p = subprocess.run([binary] + args + ["-od", od], cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env))
