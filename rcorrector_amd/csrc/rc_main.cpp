@@ -426,6 +426,59 @@ struct Source {
     Buf dec;
     size_t dec_len = 0;
 
+    bool inflate_bgzf(const LibDeflate &LD, const unsigned char *c, size_t csize)
+    {
+        struct Blk {
+            size_t in, out;
+            uint32_t bsize, isize;
+        };
+        std::vector<Blk> blk;
+        size_t pos = 0, out = 0;
+        while (pos < csize) {
+            if (csize - pos < 26 || c[pos] != 0x1f || c[pos + 1] != 0x8b || c[pos + 2] != 8 || !(c[pos + 3] & 4)) return false;
+            const size_t xlen = (size_t)c[pos + 10] | ((size_t)c[pos + 11] << 8);
+            if (pos + 12 + xlen > csize) return false;
+            size_t bsize = 0;
+            for (size_t x = pos + 12; x + 4 <= pos + 12 + xlen;) {
+                const size_t slen = (size_t)c[x + 2] | ((size_t)c[x + 3] << 8);
+                if (c[x] == 'B' && c[x + 1] == 'C' && slen == 2 && x + 6 <= pos + 12 + xlen) bsize = ((size_t)c[x + 4] | ((size_t)c[x + 5] << 8)) + 1;
+                x += 4 + slen;
+            }
+            if (bsize < 12 + xlen + 8 || pos + bsize > csize) return false;
+            const uint32_t isize = (uint32_t)c[pos + bsize - 4] | ((uint32_t)c[pos + bsize - 3] << 8) | ((uint32_t)c[pos + bsize - 2] << 16) |
+                                   ((uint32_t)c[pos + bsize - 1] << 24);
+            if (isize > (1u << 16)) return false;
+            blk.push_back(Blk{pos, out, (uint32_t)bsize, isize});
+            pos += bsize;
+            out += isize;
+        }
+        if (blk.empty()) return false;
+        dec.need(out + 64);
+        const size_t T = std::max<size_t>(1, std::min<size_t>((size_t)g_threads * 2, blk.size() / 64 + 1));
+        std::vector<char> good(T, 1);
+        g_pool.run(T, [&](size_t t) {
+            void *d = LD.alloc_d();
+            if (!d) {
+                good[t] = 0;
+                return;
+            }
+            for (size_t b = blk.size() * t / T; b < blk.size() * (t + 1) / T; ++b) {
+                size_t ain = 0, aout = 0;
+                char dummy;
+                const int res = LD.gunzip_ex(d, c + blk[b].in, blk[b].bsize, blk[b].isize ? dec.p + blk[b].out : &dummy, blk[b].isize, &ain, &aout);
+                if (res != 0 || ain != blk[b].bsize || aout != blk[b].isize) {
+                    good[t] = 0;
+                    break;
+                }
+            }
+            LD.free_d(d);
+        });
+        for (char g : good)
+            if (!g) return false;
+        dec_len = out;
+        return true;
+    }
+
     // The whole file through libdeflate: every member, into `dec`.  The size of the text is not known in advance: the last four
     // bytes of a gzip file hold it modulo 2^32 (exactly, for the usual single-member file), so the room is the smallest
     // size with that remainder that is at least three times the compressed size, 4 GiB more whenever that was too little.
@@ -468,6 +521,9 @@ struct Source {
         const unsigned char *c = (const unsigned char *)comp.p;
         if (c[0] != 0x1f || c[1] != 0x8b) return false;
         const uint64_t isize = (uint64_t)c[csize - 4] | ((uint64_t)c[csize - 3] << 8) | ((uint64_t)c[csize - 2] << 16) | ((uint64_t)c[csize - 1] << 24);
+        // BGZF (bgzip, htslib): members of at most 64 KB whose header says how long they are, so the members are found
+        // without inflating anything and inflated side by side -- the one kind of .gz several threads can share
+        if (inflate_bgzf(LD, c, csize)) return dec_len >= served;
         void *d = LD.alloc_d();
         if (!d) return false;
         size_t in_pos = 0, out_pos = 0;

@@ -237,7 +237,8 @@ def test_cli_without_c_several_inputs_of_every_kind_one_pass_equals_two(tmp_path
 def test_cli_without_c_gz_inputs_one_pass_equals_two(tmp_path):
     """.gz inputs without -c: one pass inflates each file once -- whole, in memory, with libdeflate where the system has it
     (RC_LIBDEFLATE=0: zlib streams) -- two passes inflate it twice with zlib; a file of several gzip members (what this
-    program writes itself, and what `cat a.gz b.gz` makes) must read as their concatenation.  The outputs are .gz files of
+    program writes itself, and what `cat a.gz b.gz` makes) must read as their concatenation, and a BGZF file (bgzip: 64 KB
+    members that carry their length, which are inflated in parallel) as what gunzip makes of it.  The outputs are .gz files of
     members deflated in parallel: compared after decompression, as everywhere."""
     import gzip
     import shutil
@@ -253,6 +254,18 @@ def test_cli_without_c_gz_inputs_one_pass_equals_two(tmp_path):
             with open(os.path.join(d, dst + ".gz"), "wb") as f:
                 for part in parts:
                     f.write(gzip.compress(part, 1))
+        elif dst == "p_1.fq":   # BGZF (bgzip): blocks of at most 64 KB that carry their own length, inflated side by side
+            import struct
+            import zlib
+            with open(os.path.join(d, dst + ".gz"), "wb") as f:
+                for lo in list(range(0, len(data), 60000)) + [len(data)]:   # (the last one: the empty end-of-file block)
+                    chunk = data[lo:lo + 60000] if lo < len(data) else b""
+                    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+                    raw = co.compress(chunk) + co.flush()
+                    bsize = 18 + len(raw) + 8
+                    f.write(b"\x1f\x8b\x08\x04" + b"\0\0\0\0" + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize - 1))
+                    f.write(raw + struct.pack("<II", zlib.crc32(chunk) & 0xffffffff, len(chunk)))
+            assert gzip.decompress(open(os.path.join(d, dst + ".gz"), "rb").read()) == data
         else:
             with open(os.path.join(d, dst + ".gz"), "wb") as f:
                 f.write(gzip.compress(data, 6))
