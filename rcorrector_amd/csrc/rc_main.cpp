@@ -1712,6 +1712,7 @@ int main(int argc, char **argv)
     double rate = 0.01;
     if (rc_estimate_error_rate(ctx[0], wk, &rate)) die("rcorrector: %s\n", rc_last_error(ctx[0]));
     fprintf(stderr, "Weak kmer threshold rate: %lf (estimated from %.3lf/1 of the chosen kmers)\n", rate, wk);
+    stamp("ERROR_RATE known");
 
     // GetBadQuality, main.cpp:88-128: first <= 1M records of the primary files, in order
     char bad_q = 0;

@@ -114,6 +114,66 @@ __device__ __forceinline__ void merges(int (&x)[EC], const int (&c)[4])
     if constexpr (SIZE < EC * 16) merges<EC, SIZE * 2>(x, c);
 }
 
+// The same for 8 registers in the TRANSPOSED layout (round 4): element g of the sorted row in register g % 8 of lane g / 8.
+// A bitonic network does not care where its input comes from -- the counts are loaded (and poly-A-masked) in the layout
+// above and simply read as this one -- and with the low index bits in the registers 18 of the 28 stages of 128 elements
+// are register-to-register compare-exchanges (v_min + v_max per pair: 4 cycles per element) instead of 6; only the 10
+// stages with a stride of 8 and more go through a DPP move + v_med3 (8 cycles per element): 1 250 instead of 1 820 cycles
+// per wave, and the scan for the drop below finds an element's predecessor in the register next to it.
+__device__ __forceinline__ void cx(int &a, int &b)
+{
+    const int lo = a < b ? a : b, hi = a < b ? b : a;
+    a = lo;
+    b = hi;
+}
+__device__ __forceinline__ void t8_tail(int (&x)[8])  // strides 4, 2, 1
+{
+    cx(x[0], x[4]); cx(x[1], x[5]); cx(x[2], x[6]); cx(x[3], x[7]);
+    cx(x[0], x[2]); cx(x[1], x[3]); cx(x[4], x[6]); cx(x[5], x[7]);
+    cx(x[0], x[1]); cx(x[2], x[3]); cx(x[4], x[5]); cx(x[6], x[7]);
+}
+// first stage of a merge of 8 (X + 1) elements: g pairs with g ^ (8 (X + 1) - 1) = register 7 - e of lane l ^ X; BIT = the
+// highest bit of X: the lane that has it clear holds the lower index and keeps the minimum
+template <int X, int BIT>
+__device__ __forceinline__ void t8_flip(int (&x)[8], const int (&c)[4])
+{
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int ya = row_xor<X>(x[7 - e]), yb = row_xor<X>(x[e]);
+        x[e] = med3(x[e], ya, c[BIT]);
+        x[7 - e] = med3(x[7 - e], yb, c[BIT]);
+    }
+}
+template <int X, int BIT>
+__device__ __forceinline__ void t8_lane(int (&x)[8], const int (&c)[4])  // stride 8 X
+{
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = med3(x[e], row_xor<X>(x[e]), c[BIT]);
+}
+__device__ __forceinline__ void sort_t8(int (&x)[8], const int (&c)[4])
+{
+    cx(x[0], x[1]); cx(x[2], x[3]); cx(x[4], x[5]); cx(x[6], x[7]);  // 2
+    cx(x[0], x[3]); cx(x[1], x[2]); cx(x[4], x[7]); cx(x[5], x[6]);  // 4: flip, stride 1
+    cx(x[0], x[1]); cx(x[2], x[3]); cx(x[4], x[5]); cx(x[6], x[7]);
+    cx(x[0], x[7]); cx(x[1], x[6]); cx(x[2], x[5]); cx(x[3], x[4]);  // 8: flip, strides 2, 1
+    cx(x[0], x[2]); cx(x[1], x[3]); cx(x[4], x[6]); cx(x[5], x[7]);
+    cx(x[0], x[1]); cx(x[2], x[3]); cx(x[4], x[5]); cx(x[6], x[7]);
+    t8_flip<1, 0>(x, c);  // 16
+    t8_tail(x);
+    t8_flip<3, 1>(x, c);  // 32
+    t8_lane<1, 0>(x, c);
+    t8_tail(x);
+    t8_flip<7, 2>(x, c);  // 64
+    t8_lane<2, 1>(x, c);
+    t8_lane<1, 0>(x, c);
+    t8_tail(x);
+    t8_flip<15, 3>(x, c);  // 128
+    t8_lane<4, 2>(x, c);
+    t8_lane<2, 1>(x, c);
+    t8_lane<1, 0>(x, c);
+    t8_tail(x);
+}
+
 // the 16 bits of a wave-wide ballot that belong to this lane's row
 __device__ __forceinline__ uint32_t row_bits(uint64_t ballot, int row)
 {
@@ -194,51 +254,98 @@ __device__ __forceinline__ int rcq_threshold_row(const rc_kernel_args &A, uint32
     int c[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) c[b] = __builtin_amdgcn_sbfe(l, b, 1) ^ (int)0x80000000;  // bit ? INT_MAX : INT_MIN
-    merges<E_CNT, 2>(x, c);
+    // T8: 8 count registers take the transposed network -- from here on sorted element g sits in register g % 8 of lane g / 8
+    // (RC_SORT_LAYOUT_A at compile time keeps the layout of the load, for A/B runs)
+#ifdef RC_SORT_LAYOUT_A
+    constexpr bool T8 = false;
+#else
+    constexpr bool T8 = E_CNT == 8;
+#endif
+    if constexpr (T8)
+        sort_t8(x, c);
+    else
+        merges<E_CNT, 2>(x, c);
+    // sorted element idx, read by every lane of the row: its register (a chain of selects: x[] must stay in registers) and lane
+#define RCQ_SORTED_AT(dst, idx_)                                                                       \
+    do {                                                                                               \
+        const int i_ = (idx_);                                                                         \
+        int s_ = x[0];                                                                                 \
+        _Pragma("unroll") for (int e = 1; e < E_CNT; ++e) s_ = (T8 ? (i_ & 7) : (i_ >> 4)) == e ? x[e] : s_; \
+        dst = __builtin_amdgcn_ds_bpermute(((row << 4) + (T8 ? (i_ >> 3) : (i_ & 15))) << 2, s_);      \
+    } while (0)
 
     // the "drop" scan (:1543-1563): highest g in [1, kcnt) with v[g] > 2 v[g-1] && v[g] > 10
     const int row_lane0 = row << 4;
     int strong = 0, prev = 0;
     bool found = false;
     int i0 = kcnt;  // lowest g with v[g] > 0
-    bool have_pos = false;
-    uint32_t fdrop[E_CNT], fpos[E_CNT];
-    int pv[E_CNT];
+    if constexpr (T8) {
+        // an element's predecessor is the register next to it (register 0: register 7 of the lane before); every lane keeps
+        // its own highest drop, the row takes the highest lane that has one
+        const int below = dpp<0x111>(x[7]);  // row_shr:1 (lane 0 of the row: 0, and its g = 0 is never a drop)
+        int hx = 0, hp = 0, npos = 0;
+        bool hf = false;
 #pragma unroll
-    for (int e = 0; e < E_CNT; ++e) {
-        const int g = e * 16 + l;
-        const int same = dpp<0x111>(x[e]);                  // row_shr:1 -- the element before, same register
-        const int wrap = e > 0 ? dpp<0x121>(x[e - 1]) : 0;  // row_ror:1 -- lane 0 sees lane 15 of the register before
-        const int p = l == 0 ? wrap : same;
-        pv[e] = p;
-        const bool drop = g >= 1 && g < kcnt && x[e] > 2 * p && x[e] > 10;
-        fdrop[e] = row_bits(__ballot(drop), row);
-        fpos[e] = row_bits(__ballot(g < kcnt && x[e] > 0), row);
-    }
+        for (int e = 7; e >= 0; --e) {
+            const int g = l * 8 + e;
+            const int p = e > 0 ? x[e > 0 ? e - 1 : 0] : below;
+            const bool drop = g >= 1 && g < kcnt && x[e] > 2 * p && x[e] > 10;
+            const bool take = drop && !hf;
+            hx = take ? x[e] : hx;
+            hp = take ? p : hp;
+            hf = hf || drop;
+            npos += x[e] <= 0 ? 1 : 0;  // (the padding behind kcnt is INT_MAX)
+        }
+        const uint32_t fm = row_bits(__ballot(hf), row);
+        found = fm != 0;
+        const int src = (row_lane0 + (31 - __clz((int)(fm | 1u)))) << 2;
+        const int s = __builtin_amdgcn_ds_bpermute(src, hx), pp = __builtin_amdgcn_ds_bpermute(src, hp);
+        strong = found ? s : 0;
+        prev = found ? pp : 0;
+        // ascending order: what is not positive comes first, so the lowest positive element is as far in as there are others
+        npos += row_xor<1>(npos);
+        npos += row_xor<2>(npos);
+        npos += row_xor<4>(npos);
+        npos += row_xor<8>(npos);
+        i0 = npos < kcnt ? npos : kcnt;
+    } else {
+        bool have_pos = false;
+        uint32_t fdrop[E_CNT], fpos[E_CNT];
+        int pv[E_CNT];
 #pragma unroll
-    for (int e = E_CNT - 1; e >= 0; --e) {
-        const bool hit = !found && fdrop[e] != 0;
-        const int li = 31 - __clz((int)(fdrop[e] | 1u));
-        const int src = (row_lane0 + li) << 2;
-        const int s = __builtin_amdgcn_ds_bpermute(src, x[e]);
-        const int pp = __builtin_amdgcn_ds_bpermute(src, pv[e]);
-        strong = hit ? s : strong;
-        prev = hit ? pp : prev;
-        found = found || hit;
-    }
+        for (int e = 0; e < E_CNT; ++e) {
+            const int g = e * 16 + l;
+            const int same = dpp<0x111>(x[e]);                  // row_shr:1 -- the element before, same register
+            const int wrap = e > 0 ? dpp<0x121>(x[e > 0 ? e - 1 : 0]) : 0;  // row_ror:1 -- lane 0 sees lane 15 of the register before
+            const int p = l == 0 ? wrap : same;
+            pv[e] = p;
+            const bool drop = g >= 1 && g < kcnt && x[e] > 2 * p && x[e] > 10;
+            fdrop[e] = row_bits(__ballot(drop), row);
+            fpos[e] = row_bits(__ballot(g < kcnt && x[e] > 0), row);
+        }
 #pragma unroll
-    for (int e = 0; e < E_CNT; ++e) {
-        const bool hit = !have_pos && fpos[e] != 0;
-        i0 = hit ? e * 16 + (__ffs((int)fpos[e]) - 1) : i0;
-        have_pos = have_pos || hit;
+        for (int e = E_CNT - 1; e >= 0; --e) {
+            const bool hit = !found && fdrop[e] != 0;
+            const int li = 31 - __clz((int)(fdrop[e] | 1u));
+            const int src = (row_lane0 + li) << 2;
+            const int s = __builtin_amdgcn_ds_bpermute(src, x[e]);
+            const int pp = __builtin_amdgcn_ds_bpermute(src, pv[e]);
+            strong = hit ? s : strong;
+            prev = hit ? pp : prev;
+            found = found || hit;
+        }
+#pragma unroll
+        for (int e = 0; e < E_CNT; ++e) {
+            const bool hit = !have_pos && fpos[e] != 0;
+            i0 = hit ? e * 16 + (__ffs((int)fpos[e]) - 1) : i0;
+            have_pos = have_pos || hit;
+        }
     }
     {
         // no drop: the median of the positive part, v[(i0 + kcnt - 1) / 2]   (:1556-1563)
         const int idx = kcnt > 0 ? (i0 + kcnt - 1) / 2 : 0;
-        int sel = x[0];
-#pragma unroll
-        for (int e = 1; e < E_CNT; ++e) sel = (idx >> 4) == e ? x[e] : sel;
-        const int med = __builtin_amdgcn_ds_bpermute((row_lane0 + (idx & 15)) << 2, sel);
+        int med;
+        RCQ_SORTED_AT(med, idx);
         strong = found ? strong : med;
     }
     const int strong_self = screened ? -1 : strong;
@@ -316,14 +423,9 @@ __device__ __forceinline__ int rcq_threshold_row(const rc_kernel_args &A, uint32
         const bool adj = adj_bits != 0;
         const bool clean = !screened && v0 >= t0 && adj;
         const int im = kcnt >> 1, ih = kcnt > 0 ? kcnt - 1 : 0;
-        int sm = x[0], sh = x[0];
-#pragma unroll
-        for (int e = 1; e < E_CNT; ++e) {
-            sm = (im >> 4) == e ? x[e] : sm;
-            sh = (ih >> 4) == e ? x[e] : sh;
-        }
-        const int vm = __builtin_amdgcn_ds_bpermute((row_lane0 + (im & 15)) << 2, sm);
-        const int vh = __builtin_amdgcn_ds_bpermute((row_lane0 + (ih & 15)) << 2, sh);
+        int vm, vh;
+        RCQ_SORTED_AT(vm, im);
+        RCQ_SORTED_AT(vh, ih);
         if (!screened && n_below < kcnt) cls = n_below >= kcnt - (kcnt >> 3) ? 4 : (n_below >= kcnt - (kcnt >> 2) ? 3 : (n_below >= kcnt - (kcnt >> 1) ? 2 : 1));
         // The same on the REAL counts.  The sorted array hides the windows the threshold scan masks as poly-A (:1530-1541:
         // >= k - max(7, k/2) A's or T's -- one read in eight has such a window), so v0 < 0 for a read that is clean in every
