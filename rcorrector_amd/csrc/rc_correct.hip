@@ -224,7 +224,10 @@ __global__ __launch_bounds__(RC_PROBE_THREADS) __attribute__((amdgpu_waves_per_e
     __syncthreads();
     const uint32_t *m_inv = reinterpret_cast<const uint32_t *>(s_inv);
     const uint32_t *m_nul = reinterpret_cast<const uint32_t *>(s_nul);
-#pragma unroll 2
+#ifndef RC_PROBE_UNROLL
+#define RC_PROBE_UNROLL 2
+#endif
+#pragma unroll RC_PROBE_UNROLL
     for (uint32_t a = 4 + (uint32_t)t; a + (uint32_t)k <= total; a += RC_PROBE_THREADS) {  // probe: counts stay in LDS
         const int mw = a >> 5, ms = a & 31;
         const uint64_t nulw = (((uint64_t)m_nul[mw] << 32) | m_nul[mw + 1]) << ms;
