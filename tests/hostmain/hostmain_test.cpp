@@ -1,0 +1,111 @@
+// The host-side arithmetic of rcorrector's one-pass path (rc_main.cpp) checked without a GPU: quality bits packed straight
+// from the FASTQ text (pack_quality_bits_from_text: SSE compares, bit streams cut at byte-aligned piece boundaries, ragged
+// and empty quality lines, two arenas side by side) against rc_pack_quality_bits over the byte arenas pack_arena makes, and
+// fixes applied to the text's sequence lines (apply_fixes_to_text) against fixes applied to the byte arena.
+// Test infrastructure: includes the CLI's translation unit with its main() renamed.
+#define main rc_cli_main
+#include "../../rcorrector_amd/csrc/rc_main.cpp"
+#undef main
+#include <random>
+
+static int fail(const char *what, unsigned seed)
+{
+    printf("FAIL %s (seed %u)\n", what, seed);
+    return 1;
+}
+
+int main(int argc, char **argv)
+{
+    const std::string dir = argc > 1 ? argv[1] : "/tmp";
+    g_threads = 4;
+    g_pool.start(8);
+    for (unsigned seed = 1; seed <= 60; ++seed) {
+        std::mt19937 rng(seed);
+        const bool uniform = seed % 3 == 0;
+        const int n = 1 + (int)(rng() % 700), L0 = 1 + (int)(rng() % 200);
+        std::string paths[2] = {dir + "/hm_1.fq", dir + "/hm_2.fq"};
+        for (int sd = 0; sd < 2; ++sd) {
+            FILE *f = fopen(paths[sd].c_str(), "wb");
+            for (int r = 0; r < n; ++r) {
+                const int sl = uniform ? L0 : (int)(rng() % (unsigned)(L0 + 1));
+                int ql = sl;
+                const unsigned u = rng() % 10;
+                if (!uniform && u == 0) ql = sl ? (int)(rng() % (unsigned)sl) : 0;  // short (or empty) quality line
+                if (!uniform && u == 1) ql = sl + 1 + (int)(rng() % 5);            // long one
+                std::string s(sl, 'A'), q(ql, 'I');
+                for (auto &c : s) c = "ACGTN"[rng() % 5];
+                for (auto &c : q) c = (char)(33 + rng() % 60);
+                fprintf(f, "@r%d\n%s\n+\n%s\n", r, s.c_str(), q.c_str());
+            }
+            fclose(f);
+        }
+        Arena A[2];
+        for (int sd = 0; sd < 2; ++sd) {
+            Source s;
+            s.open(paths[sd]);
+            A[sd].lpr = 4;
+            take_records(s, (size_t)n, 4, A[sd].blk);
+            s.close();
+            if ((int)A[sd].blk.records != n) return fail("records", seed);
+        }
+        const bool paired = seed % 2 == 0;
+        Arena B[2];  // the same blocks through pack_arena: byte arenas (the reference for both checks)
+        for (int sd = 0; sd < 2; ++sd) {
+            B[sd].lpr = 4;
+            B[sd].blk.text.need(A[sd].blk.text.cap);
+            memcpy(B[sd].blk.text.p, A[sd].blk.text.p, A[sd].blk.text.cap);
+            B[sd].blk.line = A[sd].blk.line;
+            B[sd].blk.records = A[sd].blk.records;
+            pack_arena(B[sd], paths[sd]);
+            index_arena(A[sd], paths[sd]);
+            A[sd].seq_in_text = true;
+        }
+        const size_t bytes1 = A[0].off[n], bytes2 = paired ? A[1].off[n] : 0, nbytes = bytes1 + bytes2;
+        const char bad_q = (char)(33 + rng() % 60);
+        // reference bits: rc_pack_quality_bits over the concatenated byte arenas
+        std::vector<char> qcat(nbytes);
+        memcpy(qcat.data(), B[0].qual.data(), bytes1);
+        if (paired) memcpy(qcat.data() + bytes1, B[1].qual.data(), bytes2);
+        std::vector<uint8_t> want((nbytes + 7) / 8 + 8, 0), got((nbytes + 7) / 8 + 8, 0);
+        rc_pack_quality_bits(qcat.data(), nbytes, bad_q, want.data());
+        QualView V{{&A[0], paired ? &A[1] : &A[0]}, paired ? bytes1 : nbytes, nbytes};
+        const size_t Q = 1 + rng() % 7;
+        bool ok = true, expect_ok = true;
+        for (size_t t = 0; t < Q; ++t) {
+            const size_t lo = (nbytes * t / Q) & ~(size_t)7, hi = t + 1 == Q ? nbytes : ((nbytes * (t + 1) / Q) & ~(size_t)7);
+            if (lo < hi) ok = pack_quality_bits_from_text(V, bad_q, lo, hi, got.data()) && ok;
+        }
+        for (int sd = 0; sd < (paired ? 2 : 1); ++sd)
+            for (int r = 0; r < n; ++r)
+                if (B[sd].off[r + 1] - B[sd].off[r] > 1 && B[sd].qual.data()[B[sd].off[r]] == 0) expect_ok = false;
+        if (ok != expect_ok) return fail("empty-quality flag", seed);
+        if (memcmp(want.data(), got.data(), (nbytes + 7) / 8) != 0) return fail("quality bits", seed);
+        // fixes: random positions that hold a base, new letters
+        std::vector<uint32_t> pos;
+        std::vector<uint8_t> chr;
+        for (size_t p = 0; p < nbytes; ++p) {
+            const char c = p < bytes1 ? B[0].seq.data()[p] : B[1].seq.data()[p - bytes1];
+            if (c != 0 && rng() % 50 == 0) {
+                pos.push_back((uint32_t)p);
+                chr.push_back((uint8_t)"ACGT"[rng() % 4]);
+            }
+        }
+        for (size_t i = 0; i < pos.size(); ++i) {
+            if (pos[i] < bytes1)
+                B[0].seq.data()[pos[i]] = (char)chr[i];
+            else
+                B[1].seq.data()[pos[i] - bytes1] = (char)chr[i];
+        }
+        const size_t F = 1 + rng() % 3;
+        for (size_t t = 0; t < F; ++t)
+            apply_fixes_to_text(A[0], paired ? &A[1] : nullptr, bytes1, pos.data(), chr.data(), pos.size() * t / F, pos.size() * (t + 1) / F);
+        for (int sd = 0; sd < (paired ? 2 : 1); ++sd)
+            for (int r = 0; r < n; ++r) {
+                const uint32_t sl = A[sd].off[r + 1] - A[sd].off[r] - 1;
+                if (memcmp(A[sd].sequence((size_t)r), B[sd].sequence((size_t)r), sl) != 0) return fail("fixes applied to the text", seed);
+            }
+    }
+    printf("ok 60 cases\n");
+    fflush(stdout);
+    _exit(0);
+}
