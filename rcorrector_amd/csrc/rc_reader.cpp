@@ -1,0 +1,404 @@
+// rc_reader.cpp -- see rc_reader.h
+#include "rc_reader.h"
+
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+bool Source::inflate_bgzf(const LibDeflate &LD, const unsigned char *c, size_t csize)
+{
+    struct Blk {
+        size_t in, out;
+        uint32_t bsize, isize;
+    };
+    std::vector<Blk> blk;
+    size_t pos = 0, out = 0;
+    while (pos < csize) {
+        if (csize - pos < 26 || c[pos] != 0x1f || c[pos + 1] != 0x8b || c[pos + 2] != 8 || !(c[pos + 3] & 4)) return false;
+        const size_t xlen = (size_t)c[pos + 10] | ((size_t)c[pos + 11] << 8);
+        if (pos + 12 + xlen > csize) return false;
+        size_t bsize = 0;
+        for (size_t x = pos + 12; x + 4 <= pos + 12 + xlen;) {
+            const size_t slen = (size_t)c[x + 2] | ((size_t)c[x + 3] << 8);
+            if (c[x] == 'B' && c[x + 1] == 'C' && slen == 2 && x + 6 <= pos + 12 + xlen) bsize = ((size_t)c[x + 4] | ((size_t)c[x + 5] << 8)) + 1;
+            x += 4 + slen;
+        }
+        if (bsize < 12 + xlen + 8 || pos + bsize > csize) return false;
+        const uint32_t isize = (uint32_t)c[pos + bsize - 4] | ((uint32_t)c[pos + bsize - 3] << 8) | ((uint32_t)c[pos + bsize - 2] << 16) |
+                               ((uint32_t)c[pos + bsize - 1] << 24);
+        if (isize > (1u << 16)) return false;
+        blk.push_back(Blk{pos, out, (uint32_t)bsize, isize});
+        pos += bsize;
+        out += isize;
+    }
+    if (blk.empty()) return false;
+    dec.need(out + 64);
+    const size_t T = std::max<size_t>(1, std::min<size_t>((size_t)g_threads * 2, blk.size() / 64 + 1));
+    std::vector<char> good(T, 1);
+    g_pool.run(T, [&](size_t t) {
+        void *d = LD.alloc_d();
+        if (!d) {
+            good[t] = 0;
+            return;
+        }
+        for (size_t b = blk.size() * t / T; b < blk.size() * (t + 1) / T; ++b) {
+            size_t ain = 0, aout = 0;
+            char dummy;
+            const int res = LD.gunzip_ex(d, c + blk[b].in, blk[b].bsize, blk[b].isize ? dec.p + blk[b].out : &dummy, blk[b].isize, &ain, &aout);
+            if (res != 0 || ain != blk[b].bsize || aout != blk[b].isize) {
+                good[t] = 0;
+                break;
+            }
+        }
+        LD.free_d(d);
+    });
+    for (char g : good)
+        if (!g) return false;
+    dec_len = out;
+    return true;
+}
+
+// The whole file through libdeflate: every member, into `dec`.  The size of the text is not known in advance: the last four
+// bytes of a gzip file hold it modulo 2^32 (exactly, for the usual single-member file), so the room is the smallest
+// size with that remainder that is at least three times the compressed size, 4 GiB more whenever that was too little.
+// Anything libdeflate does not like -- not gzip at all (zlib reads such a file as it is), a truncated file, bad data --
+// returns false, and the file is read on through zlib, which owns the reference's behaviour for those.
+bool Source::inflate_whole()
+{
+    const LibDeflate &LD = libdeflate();
+    if (!LD.ok) return false;
+    const int fd2 = ::open(path.c_str(), O_RDONLY);
+    if (fd2 < 0) return false;
+    struct stat st;
+    if (fstat(fd2, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 18) {
+        ::close(fd2);
+        return false;
+    }
+    const size_t csize = (size_t)st.st_size;
+    Buf comp;
+    comp.need(csize + 64);
+    {
+        const size_t SL = (size_t)8 << 20;
+        const size_t T = std::max<size_t>(1, std::min<size_t>((size_t)g_threads, (csize + SL - 1) / SL));
+        std::vector<char> good(T, 1);
+        g_pool.run(T, [&](size_t t) {
+            size_t at = csize * t / T;
+            const size_t hi = csize * (t + 1) / T;
+            while (at < hi) {
+                const ssize_t n = ::pread(fd2, comp.p + at, hi - at, (off_t)at);
+                if (n <= 0) {
+                    good[t] = 0;
+                    break;
+                }
+                at += (size_t)n;
+            }
+        });
+        ::close(fd2);
+        for (char g : good)
+            if (!g) return false;
+    }
+    const unsigned char *c = (const unsigned char *)comp.p;
+    if (c[0] != 0x1f || c[1] != 0x8b) return false;
+    const uint64_t isize = (uint64_t)c[csize - 4] | ((uint64_t)c[csize - 3] << 8) | ((uint64_t)c[csize - 2] << 16) | ((uint64_t)c[csize - 1] << 24);
+    // BGZF (bgzip, htslib): members of at most 64 KB whose header says how long they are, so the members are found
+    // without inflating anything and inflated side by side -- the one kind of .gz several threads can share
+    if (inflate_bgzf(LD, c, csize)) return dec_len >= served;
+    void *d = LD.alloc_d();
+    if (!d) return false;
+    size_t in_pos = 0, out_pos = 0;
+    bool okay = true;
+    while (in_pos < csize) {
+        if (csize - in_pos < 18 || c[in_pos] != 0x1f || c[in_pos + 1] != 0x8b) break;  // (what follows the last member is ignored, as gzread does)
+        uint64_t room = isize;
+        while (room < 3 * (uint64_t)(csize - in_pos)) room += (uint64_t)1 << 32;
+        int res = 3;
+        size_t ain = 0, aout = 0;
+        for (int attempt = 0; attempt < 16 && res == 3; ++attempt, room += (uint64_t)1 << 32) {
+            dec.need(out_pos + (size_t)room + 64);
+            res = LD.gunzip_ex(d, c + in_pos, csize - in_pos, dec.p + out_pos, (size_t)room, &ain, &aout);  // 3 = not enough room
+        }
+        if (res != 0 || ain == 0) {
+            okay = false;
+            break;
+        }
+        in_pos += ain;
+        out_pos += aout;
+    }
+    LD.free_d(d);
+    if (!okay || out_pos < served) return false;
+    dec_len = out_pos;
+    return true;
+}
+
+void Source::open(const std::string &p)
+{
+    path = p;
+    size_t len = p.size();
+    is_gz = len >= 2 && p[len - 2] == 'g' && p[len - 1] == 'z';  // File.h:51-55
+    if (is_gz) {
+        gz = gzopen(p.c_str(), "r");
+        if (!gz) die("ERROR: Could not access file %s\n", p.c_str());
+        gzbuffer(gz, 1 << 20);
+    } else {
+        fd = ::open(p.c_str(), O_RDONLY);
+        if (fd < 0) die("ERROR: Could not access file %s\n", p.c_str());
+        struct stat st;
+        seekable = fstat(fd, &st) == 0 && S_ISREG(st.st_mode);
+    }
+    left_len = 0;
+    pos = 0;
+    eof = false;
+}
+void Source::close()
+{
+    if (gz) gzclose(gz);
+    if (fd >= 0) ::close(fd);
+    gz = nullptr;
+    fd = -1;
+}
+// appends up to `want` bytes of the file at dst; sets eof when the file ends first.  Regular
+// files are read by several threads at once (pread into disjoint slices: the copy out of the
+// page cache is what limits a single reader), streams and .gz by this thread alone.
+size_t Source::fill(char *dst, size_t want)
+{
+    size_t got = 0;
+    if (is_gz) {
+        if (g_gz_whole && !whole_tried && want > ((size_t)1 << 16)) {
+            whole_tried = true;
+            whole = inflate_whole();
+        }
+        if (whole) {  // (copied out by several threads, like the block reads of a plain file)
+            got = std::min(want, dec_len - served);
+            const size_t SL = (size_t)8 << 20;
+            const size_t T = std::max<size_t>(1, std::min<size_t>((size_t)g_threads, (got + SL - 1) / SL));
+            const char *src = dec.p + served;
+            g_pool.run(T, [&](size_t t) { memcpy(dst + got * t / T, src + got * t / T, got * (t + 1) / T - got * t / T); });
+            served += got;
+            if (served == dec_len) {
+                eof = true;
+                dec.release();
+            }
+            return got;
+        }
+        while (got < want) {
+            const unsigned ch = (unsigned)std::min<size_t>(want - got, (size_t)1 << 30);
+            const int n = gzread(gz, dst + got, ch);
+            if (n <= 0) {
+                eof = true;
+                break;
+            }
+            got += (size_t)n;
+        }
+        served += got;
+        return got;
+    }
+    if (!seekable) {
+        while (got < want) {
+            const ssize_t n = ::read(fd, dst + got, want - got);
+            if (n <= 0) {
+                eof = true;
+                break;
+            }
+            got += (size_t)n;
+        }
+        return got;
+    }
+    const size_t SL = (size_t)8 << 20;
+    const size_t T = std::max<size_t>(1, std::min<size_t>((size_t)g_threads, (want + SL - 1) / SL));
+    std::vector<size_t> done(T, 0);
+    auto rd = [&](size_t t) {
+        const size_t lo = want * t / T, hi = want * (t + 1) / T;
+        size_t at = lo;
+        while (at < hi) {
+            const ssize_t n = ::pread(fd, dst + at, hi - at, pos + (off_t)at);
+            if (n <= 0) break;
+            at += (size_t)n;
+        }
+        done[t] = at - lo;
+    };
+    g_pool.run(T, rd);
+    for (size_t t = 0; t < T; ++t) {
+        got += done[t];
+        if (done[t] < want * (t + 1) / T - want * t / T) {  // the file ended inside this slice
+            eof = true;
+            break;
+        }
+    }
+    pos += (off_t)got;
+    return got;
+}
+
+// positions of the '\n' bytes of p[lo, hi), appended to nl in ascending order
+static void find_newlines(const char *p, size_t lo, size_t hi, std::vector<uint32_t> &nl)
+{
+    const size_t T = std::max<size_t>(1, std::min<size_t>((size_t)g_threads, (hi - lo) >> 22));
+    if (T == 1) {
+        for (size_t at = lo; at < hi;) {
+            const char *q = (const char *)memchr(p + at, '\n', hi - at);
+            if (!q) break;
+            nl.push_back((uint32_t)(q - p));
+            at = (size_t)(q - p) + 1;
+        }
+        return;
+    }
+    std::vector<std::vector<uint32_t>> part(T);
+    g_pool.run(T, [&](size_t t) {
+        const size_t a = lo + (hi - lo) * t / T, b = lo + (hi - lo) * (t + 1) / T;
+        part[t].reserve((b - a) / 32 + 16);
+        for (size_t at = a; at < b;) {
+            const char *q = (const char *)memchr(p + at, '\n', b - at);
+            if (!q) break;
+            part[t].push_back((uint32_t)(q - p));
+            at = (size_t)(q - p) + 1;
+        }
+    });
+    size_t total = nl.size();
+    for (auto &v : part) total += v.size();
+    nl.reserve(total);
+    for (auto &v : part) nl.insert(nl.end(), v.begin(), v.end());
+}
+
+// up to max_records whole records from the source (fewer only at end of file), read straight into
+// the block's own buffer
+void take_records(Source &s, size_t max_records, int lines_per_record, Block &b)
+{
+    b.line.clear();
+    b.records = 0;
+    b.unterminated_last = false;
+    const size_t want_lines = max_records * (size_t)lines_per_record;
+    std::vector<uint32_t> nl;  // newline positions found so far
+    nl.reserve(std::min<size_t>(want_lines, (size_t)1 << 23) + 8);
+    size_t have = s.left_len, scanned = 0;
+    b.text.need(have + 64);
+    if (have) memcpy(b.text.p, s.left.p, have);
+    s.left_len = 0;
+    for (;;) {
+        const double tn0 = now_s();
+        find_newlines(b.text.p, scanned, have, nl);
+        timing_add(g_t_nl, now_s() - tn0);
+        scanned = have;
+        if (nl.size() >= want_lines) break;
+        if (s.eof) break;
+        if (have >= (1ull << 31)) die("ERROR: %s: a batch exceeds 2 GiB of text; lower -batch\n", s.path.c_str());
+        size_t want = (size_t)32 << 20;
+        if (nl.size() < 64 && s.per_line > 0 && want_lines > nl.size()) {
+            want = (size_t)(s.per_line * (double)(want_lines - nl.size()) * 1.01 + 65536.0);
+        }
+        if (nl.size() >= 64) {  // bytes per line so far -> what the missing lines should need, plus 2 %
+            const double per_line = (double)have / (double)nl.size();
+            want = (size_t)(per_line * (double)(want_lines - nl.size()) * 1.02) + (1u << 16);
+        }
+        want = std::min<size_t>(want, ((size_t)1 << 31) - have + 1);
+        b.text.need(have + want + 64);
+        const double tf0 = now_s();
+        have += s.fill(b.text.p + have, want);
+        timing_add(g_t_fill, now_s() - tf0);
+    }
+    size_t n_lines = std::min(nl.size(), want_lines), end;
+    if (nl.size() >= want_lines) {
+        end = (size_t)nl[want_lines - 1] + 1;
+    } else {  // end of file
+        end = nl.empty() ? 0 : (size_t)nl.back() + 1;
+        if (end < have) {  // last line without '\n' (fgets hands it over as it is): add the newline
+            b.text.p[have] = '\n';
+            nl.push_back((uint32_t)have);
+            ++have;
+            end = have;
+            ++n_lines;
+            b.unterminated_last = true;
+        }
+        // a record cut short by the end of the file: its missing lines read as empty (fgets leaves "")
+        while (n_lines % (size_t)lines_per_record) {
+            b.text.need(have + 64);
+            b.text.p[have] = '\n';
+            nl.push_back((uint32_t)have);
+            ++have;
+            end = have;
+            ++n_lines;
+        }
+    }
+    b.records = n_lines / (size_t)lines_per_record;
+    if (n_lines >= 64) s.per_line = (double)end / (double)n_lines;
+    if (have > end) {  // the tail behind the block waits in the source for the next call
+        s.left.need(have - end);
+        memcpy(s.left.p, b.text.p + end, have - end);
+    }
+    s.left_len = have - end;
+    if (b.records == 0) return;
+    const double ti0 = now_s();
+    b.line.resize(n_lines + 1);
+    b.line[0] = 0;
+    parallel_for(n_lines, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) b.line[i + 1] = nl[i] + 1;
+    });
+    timing_add(g_t_idx, now_s() - ti0);
+}
+
+// Reads.h:39-75
+std::string base_name(const std::string &path)
+{
+    std::string in = path;
+    int len = (int)in.size(), i, j;
+    for (i = len; i >= 0 && in.c_str()[i] != '.' && in.c_str()[i] != '/'; --i)
+        ;
+    if (i >= 0 && !strcmp(in.c_str() + i, ".gz")) {
+        int tmp = i;
+        for (i = i - 1; i >= 0 && in[i] != '.' && in[i] != '/'; --i)
+            ;
+        std::string stem = in.substr(0, tmp);
+        const char *e = i >= 0 ? stem.c_str() + i : "";
+        if (!(i >= 0 && (!strcmp(e, ".fastq") || !strcmp(e, ".fasta") || !strcmp(e, ".fq") || !strcmp(e, ".fa")))) i = tmp;
+    }
+    for (j = len; j >= 0 && in.c_str()[j] != '/'; --j)
+        ;
+    if (i >= 0 && in.c_str()[i] == '.') return in.substr(j + 1, i - (j + 1));
+    return in.substr(j + 1);
+}
+
+// Reads.h:108-162: type the file by its first byte, open (truncate) the output
+void open_file(ReadFile &f, const char *path, bool paired, bool interleaved, const std::string &od)
+{
+    f.path = path;
+    f.paired = paired;
+    f.interleaved = interleaved;
+    f.src.open(path);
+    f.src.left.need(4096);  // peek at the head of the file; the bytes stay queued for the first block
+    f.src.left_len = f.src.fill(f.src.left.p, 4096);
+    const char first = f.src.left_len ? f.src.left.p[0] : 0;
+    if (first == '>')
+        f.fastq = false;
+    else if (first == '@')
+        f.fastq = true;
+    else {
+        std::string l(f.src.left.p, std::min<size_t>(f.src.left_len, 200));
+        const size_t nl = l.find('\n');
+        if (nl != std::string::npos) l = l.substr(0, nl + 1);
+        die("\"%s\"'s format is wrong: %s\n", path, l.c_str());
+    }
+    size_t len = strlen(path);
+    f.out_gz = len >= 2 && path[len - 2] == 'g' && path[len - 1] == 'z';
+    std::string outp = od + "/" + base_name(path) + (f.fastq ? ".cor.fq" : ".cor.fa") + (f.out_gz ? ".gz" : "");
+    if (g_stdout) {
+        f.out = stdout;
+        f.out_gz = false;
+    } else if (f.out_gz) {
+        // compressLevel 1 (Reads.h:84, File.h:62-66).  The formatted slices of a batch are deflated
+        // in parallel, each into its own gzip member; a .gz file is a concatenation of members, so
+        // gunzip / gzopen read back exactly the bytes the reference's single-stream file holds.
+        f.out = fopen(outp.c_str(), "wb");
+        if (!f.out) die("ERROR: Could not access file %s\n", outp.c_str());
+    } else {
+        f.out = fopen(outp.c_str(), "w");
+        if (!f.out) die("ERROR: Could not access file %s\n", outp.c_str());
+        // the output of a plain input is the input plus a few bytes per record: its blocks are reserved up front
+        // (buffered writes into preallocated space: 11.8 GB/s against 10.1 on the GPU box's host, tools/mb/iob2.cpp)
+        // -- FALLOC_FL_KEEP_SIZE: the file's length stays what has been written, so a run that ends abnormally leaves a
+        // valid prefix and not gigabytes of NUL bytes; a file system without fallocate fails fast (glibc's posix_fallocate
+        // would write into every block instead) and the output is simply not preallocated.  The ftruncate at close
+        // releases the blocks that were not needed.
+        struct stat st;
+        if (f.src.seekable && fstat(f.src.fd, &st) == 0 && st.st_size > ((off_t)64 << 20) &&
+            fallocate(fileno(f.out), FALLOC_FL_KEEP_SIZE, 0, st.st_size + st.st_size / 8) == 0)
+            f.preallocated = true;
+    }
+}

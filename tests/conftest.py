@@ -30,18 +30,26 @@ def oracle_cli(oracle):
     return oracle.CLI_BIN
 
 
-@pytest.fixture(scope="session")
-def hostsim(oracle):
-    """Lane-serial build of the kernel control flow (tests/hostsim)."""
-    import ctypes as C
+def build_hostsim(so, flags=("-O2",)):
+    """Lane-serial build of the kernel control flow (tests/hostsim) into `so`; `flags`: e.g. a sanitizer's."""
     d = os.path.join(ROOT, "tests", "hostsim")
-    so = os.path.join(d, "libhostsim.so")
-    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, os.path.join(d, "hostsim.cpp"),
+    subprocess.run(["g++", "-std=c++17", "-fPIC", "-shared"] + list(flags) + ["-o", so, os.path.join(d, "hostsim.cpp"),
                     "-L" + os.path.join(ROOT, "oracle"), "-l:liboracle.so",
                     "-Wl,-rpath," + os.path.join(ROOT, "oracle")], check=True)
+
+
+def load_hostsim(so):
+    import ctypes as C
     lib = C.CDLL(so)
     lib.hostsim_correct_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     return lib
+
+
+@pytest.fixture(scope="session")
+def hostsim(oracle):
+    so = os.path.join(ROOT, "tests", "hostsim", "libhostsim.so")
+    build_hostsim(so)
+    return load_hostsim(so)
 
 
 @pytest.fixture(scope="session")

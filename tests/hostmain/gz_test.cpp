@@ -1,10 +1,10 @@
 // .gz inputs of a one-pass run are inflated whole by libdeflate where that is possible (Source::inflate_whole, BGZF blocks in
 // parallel) and read through zlib's gzread otherwise: both ways must hand out the same bytes for every kind of file -- one
 // member, several, BGZF, bytes behind the last member, a truncated file, a plain file called .gz, an empty one.
-// Test infrastructure: includes the CLI's translation unit with its main() renamed.  usage: gz_test <file>...
-#define main rc_cli_main
-#include "../../rcorrector_amd/csrc/rc_main.cpp"
-#undef main
+// Test infrastructure: links the CLI's host units (rc_pool, rc_reader) through their headers.  usage: gz_test <file>...
+#include <unistd.h>
+
+#include "../../rcorrector_amd/csrc/rc_reader.h"
 
 static std::string slurp(const std::string &path, bool whole, bool *used_whole)
 {

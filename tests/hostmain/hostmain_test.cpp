@@ -1,11 +1,11 @@
-// The host-side arithmetic of rcorrector's one-pass path (rc_main.cpp) checked without a GPU: quality bits packed straight
+// The host-side arithmetic of rcorrector's one-pass path (rc_format.cpp, rc_reader.cpp) checked without a GPU: quality bits packed straight
 // from the FASTQ text (pack_quality_bits_from_text: SSE compares, bit streams cut at byte-aligned piece boundaries, ragged
 // and empty quality lines, two arenas side by side) against rc_pack_quality_bits over the byte arenas pack_arena makes, and
 // fixes applied to the text's sequence lines (apply_fixes_to_text) against fixes applied to the byte arena.
-// Test infrastructure: includes the CLI's translation unit with its main() renamed.
-#define main rc_cli_main
-#include "../../rcorrector_amd/csrc/rc_main.cpp"
-#undef main
+// Test infrastructure: links the CLI's host units (rc_pool, rc_reader, rc_format) through their headers.
+#include <unistd.h>
+
+#include "../../rcorrector_amd/csrc/rc_format.h"
 #include <random>
 
 static int fail(const char *what, unsigned seed)

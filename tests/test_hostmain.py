@@ -1,20 +1,36 @@
 """CPU: the arithmetic of the CLI's one-pass path that runs on the host -- quality bits packed from the FASTQ text, fixes
-applied to the text's sequence lines (rc_main.cpp) -- against the byte-arena code paths, on ragged, empty and over-long
+applied to the text's sequence lines (rc_format.cpp) -- against the byte-arena code paths, on ragged, empty and over-long
 quality lines, single and paired arenas, any split into pieces (tests/hostmain/hostmain_test.cpp; no GPU involved: the
 library is only linked for rc_pack_quality_bits / rc_host_register, which fails harmlessly without a device)."""
 import os
 import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "rcorrector_amd", "csrc")
+HOST_UNITS = ["rc_pool", "rc_reader", "rc_format"]
+
+
+def build_host_test(src, exe, flags=("-O2",), objdir=None):
+    """A host test program linked against the CLI's host units (csrc/Makefile: hostobjs; `flags` / `objdir`: a differently
+    compiled set, e.g. with a sanitizer, kept apart from the product's objects)."""
+    lib = os.path.join(ROOT, "rcorrector_amd")
+    if objdir is None:
+        subprocess.run(["make", "-C", CSRC, "-j4", "hostobjs"], check=True, stdout=subprocess.DEVNULL)
+        objdir = CSRC
+    else:
+        os.makedirs(objdir, exist_ok=True)
+        subprocess.run(["make", "-C", CSRC, "-j4", "hostobjs", "HOSTOBJDIR=" + objdir,
+                        "HOSTFLAGS=-std=c++17 -Wall -g " + " ".join(flags)], check=True, stdout=subprocess.DEVNULL)
+    objs = [os.path.join(objdir, u + ".host.o") for u in HOST_UNITS]
+    subprocess.run(["g++", "-std=c++17", "-Wno-unused-function"] + list(flags) + [src, "-o", exe] + objs +
+                   ["-L" + lib, "-lrcorrector_amd", "-lz", "-lpthread", "-ldl", "-Wl,-rpath," + lib], check=True)
 
 
 def test_quality_bits_and_fixes_on_the_text(tmp_path):
     import rcorrector_amd
     rcorrector_amd.build_library()
     exe = str(tmp_path / "hostmain_test")
-    lib = os.path.join(ROOT, "rcorrector_amd")
-    subprocess.run(["g++", "-O2", "-std=c++17", "-Wno-unused-function", os.path.join(ROOT, "tests", "hostmain", "hostmain_test.cpp"), "-o", exe,
-                    "-L" + lib, "-lrcorrector_amd", "-lz", "-lpthread", "-ldl", "-Wl,-rpath," + lib], check=True)
+    build_host_test(os.path.join(ROOT, "tests", "hostmain", "hostmain_test.cpp"), exe)
     p = subprocess.run([exe, str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     out = p.stdout.decode()
     assert p.returncode == 0 and "ok 60 cases" in out, out
@@ -56,9 +72,7 @@ def test_gz_inputs_read_the_same_through_libdeflate_and_zlib(tmp_path):
     for name, content in files.items():
         open(os.path.join(d, name), "wb").write(content)
     exe = str(tmp_path / "gz_test")
-    lib = os.path.join(ROOT, "rcorrector_amd")
-    subprocess.run(["g++", "-O2", "-std=c++17", "-Wno-unused-function", os.path.join(ROOT, "tests", "hostmain", "gz_test.cpp"), "-o", exe,
-                    "-L" + lib, "-lrcorrector_amd", "-lz", "-lpthread", "-ldl", "-Wl,-rpath," + lib], check=True)
+    build_host_test(os.path.join(ROOT, "tests", "hostmain", "gz_test.cpp"), exe)
     p = subprocess.run([exe] + [os.path.join(d, n) for n in files], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     out = p.stdout.decode()
     assert p.returncode == 0 and out.rstrip().endswith("ok"), out
