@@ -34,7 +34,9 @@ typedef enum {
     RC_STATUS_HIP = -2,   /* HIP runtime error */
     RC_STATUS_IO = -3,    /* file could not be read */
     RC_STATUS_STATE = -4, /* call sequence error (no table, no run parameters, ...) */
-    RC_STATUS_NOMEM = -5
+    RC_STATUS_NOMEM = -5,
+    RC_STATUS_NOSPACE = -6 /* rc_wait_packed / rc_wait_resident: more substitutions than fix_cap (n_fix = how many): the batch's
+                              ret / l / m / h are complete, its fix list is not -- resubmit with more room, or through rc_submit */
 } rc_status;
 
 typedef struct {
@@ -51,6 +53,9 @@ const char *rc_last_error(const rc_ctx *ctx);
  * not say: a host that feeds the GPU from page-locked buffers wants its threads and those buffers there
  * (the reference has no counterpart: its workers are plain pthreads, main.cpp:479-483) */
 int rc_device_numa_node(const rc_ctx *ctx);
+/* free and total bytes of the context's GPU memory right now (hipMemGetInfo): what a host checks before it asks the
+ * k-mer counter to keep a data set's bases in HBM (rc_table_count_keep).  No reference counterpart. */
+int rc_device_memory(rc_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes);
 
 /* ---- k-mer table (Store.h:17-88) ------------------------------------------------------------ */
 /* replaces the load loop main.cpp:294-308 when the caller has already parsed the dump:
@@ -322,6 +327,11 @@ int rc_profile_enable(rc_ctx *ctx, int on);
  * probes issued together) and the table buckets they read -- the denominators of the kernel's
  * request-rate figures. */
 int rc_profile_correct_counters(rc_ctx *ctx, uint64_t *reads_listed, uint64_t *gather_rounds, uint64_t *bucket_requests);
+/* d_rounds != NULL: the instrumented build (rc_profile_enable(ctx, 2)) also leaves the gather rounds of every read the
+ * correction kernel processes in d_rounds[read index] (device memory, one int32 per read of the batch, zeroed by the caller:
+ * reads finished before that kernel are not written) -- which reads of a batch the search works hardest on
+ * (MAX_TRIAL, ErrorCorrection.cpp:7; the straggler of tools/find_straggler.py).  NULL switches it off. */
+int rc_profile_read_rounds(rc_ctx *ctx, int32_t *d_rounds);
 /* kernel 0 = probe, 1 = threshold, 2 = correct; accumulated since the last reset */
 int rc_profile_get(rc_ctx *ctx, int kernel, double *total_ms, uint64_t *launches);
 int rc_profile_reset(rc_ctx *ctx);

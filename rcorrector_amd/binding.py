@@ -10,7 +10,7 @@ CSRC = os.path.join(HERE, "csrc")
 
 # every function include/rcorrector_amd.h declares (tests check the .so exports all of them)
 ABI_SYMBOLS = [
-    "rc_create", "rc_destroy", "rc_last_error", "rc_device_numa_node",
+    "rc_create", "rc_destroy", "rc_last_error", "rc_device_numa_node", "rc_device_memory",
     "rc_table_build", "rc_table_build_device", "rc_table_load_jfdump",
     "rc_table_count_begin", "rc_table_count_add", "rc_table_count_add_device", "rc_table_count_finish",
     "rc_table_count_keep", "rc_table_count_arenas", "rc_table_count_release", "rc_submit_resident", "rc_wait_resident",
@@ -19,7 +19,7 @@ ABI_SYMBOLS = [
     "rc_correct_batch", "rc_submit", "rc_wait", "rc_host_alloc", "rc_host_free", "rc_host_register", "rc_host_unregister", "rc_correct_batch_traced", "rc_correct_device", "rc_strong_threshold_device", "rc_probe_device", "rc_sync",
     "rc_strong_threshold_read", "rc_correct_read", "rc_kmer_info_read",
     "rc_pack_bases", "rc_submit_packed", "rc_wait_packed", "rc_apply_fixes",
-    "rc_profile_enable", "rc_profile_get", "rc_profile_reset", "rc_profile_correct_counters", "rc_selftest_get_bound", "rc_summary",
+    "rc_profile_enable", "rc_profile_get", "rc_profile_reset", "rc_profile_correct_counters", "rc_profile_read_rounds", "rc_selftest_get_bound", "rc_summary",
 ]
 
 
@@ -155,6 +155,7 @@ def load_library():
     L.rc_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.rc_profile_reset.argtypes = [vp]
     L.rc_profile_correct_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.rc_profile_read_rounds.argtypes = [vp, vp]
     L.rc_selftest_get_bound.argtypes = [vp, vp, sz, C.c_double, vp, vp]
     L.rc_summary.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     _lib = L
@@ -442,6 +443,12 @@ class Context:
         b, res, fix_pos, fix_chr, _keep = self._inflight_packed.pop(slot)
         return tuple(res) + (fix_pos[:b.n_fix], fix_chr[:b.n_fix])
 
+    def device_memory(self):
+        """(free, total) bytes of the context's GPU memory right now"""
+        f, t = C.c_uint64(0), C.c_uint64(0)
+        self._ck(self._L.rc_device_memory(self._h, C.byref(f), C.byref(t)))
+        return f.value, t.value
+
     # ---- reads the k-mer counter kept in HBM (rc_resident_batch) ----
     def count_keep(self, on=True):
         self._ck(self._L.rc_table_count_keep(self._h, 1 if on else 0))
@@ -548,6 +555,11 @@ class Context:
         a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
         self._ck(self._L.rc_profile_correct_counters(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
+
+    def profile_read_rounds(self, d_rounds=None):
+        """int32 device tensor (one entry per read, zeroed) that the instrumented correction kernel fills with every read's
+        gather rounds; None switches it off."""
+        self._ck(self._L.rc_profile_read_rounds(self._h, None if d_rounds is None else d_rounds.data_ptr()))
 
     def profile_reset(self):
         self._ck(self._L.rc_profile_reset(self._h))

@@ -240,6 +240,17 @@ int rc_device_numa_node(const rc_ctx *ctx)
     return node;
 }
 
+int rc_device_memory(rc_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes)
+{
+    if (!ctx) return RC_ERR_ARG;
+    RC_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    size_t f = 0, t = 0;
+    RC_CHECK_HIP(ctx, hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = (uint64_t)f;
+    if (total_bytes) *total_bytes = (uint64_t)t;
+    return RC_OK;
+}
+
 // ---- table ---------------------------------------------------------------------------------
 int rc_table_build_device(rc_ctx *ctx, uint64_t *d_codes, const int32_t *d_counts, size_t n)
 {
@@ -1722,11 +1733,11 @@ int rc_submit_packed(rc_ctx *c, rc_packed_batch *b, int slot)
     }
     const size_t total = b->mode == 1 ? 2 * b->n : b->n, nbytes = (size_t)b->nbytes;
     b->n_fix = 0;
-    sl.pb = b;
-    sl.rb = nullptr;
-    sl.b.n = b->n;
-    sl.total_reads = total;
     if (total == 0) {
+        sl.pb = b;
+        sl.rb = nullptr;
+        sl.b.n = b->n;
+        sl.total_reads = total;
         sl.busy = true;
         return RC_OK;
     }
@@ -1738,16 +1749,33 @@ int rc_submit_packed(rc_ctx *c, rc_packed_batch *b, int slot)
         rc_set_error(ctx, "submit_packed: %s mode needs an even number of reads", b->mode == 1 ? "paired" : "interleaved");
         return RC_ERR_ARG;
     }
-    if (b->off[total] != nbytes) {
-        rc_set_error(ctx, "submit_packed: off[%zu] = %u is not the arena's %zu bytes", total, b->off[total], nbytes);
+    if (b->off[0] != 0 || b->off[total] != nbytes) {
+        rc_set_error(ctx, "submit_packed: off[0] = %u, off[%zu] = %u do not describe the arena's %zu bytes", b->off[0], total, b->off[total], nbytes);
         return RC_ERR_ARG;
     }
     if (!ctx->d_buckets) {
         rc_set_error(ctx, "correct: no k-mer table loaded");
         return RC_ERR_STATE;
     }
+    // every read ends with its NUL: strictly ascending offsets (the terminator / exception kernels write seq[off[i+1]-1] and
+    // seq[exc_pos[i]] unchecked)
     int max_len = 0;
-    for (size_t i = 0; i < total; ++i) max_len = std::max(max_len, (int)(b->off[i + 1] - b->off[i]) - 1);
+    for (size_t i = 0; i < total; ++i) {
+        if (b->off[i + 1] <= b->off[i]) {
+            rc_set_error(ctx, "submit_packed: off[%zu] = %u, off[%zu] = %u: offsets must ascend (a read is its bases and a NUL)", i, b->off[i], i + 1, b->off[i + 1]);
+            return RC_ERR_ARG;
+        }
+        max_len = std::max(max_len, (int)(b->off[i + 1] - b->off[i]) - 1);
+    }
+    for (size_t i = 0; i < b->n_exc; ++i)
+        if (b->exc_pos[i] >= nbytes) {
+            rc_set_error(ctx, "submit_packed: exc_pos[%zu] = %u lies outside the arena's %zu bytes", i, b->exc_pos[i], nbytes);
+            return RC_ERR_ARG;
+        }
+    sl.pb = b;
+    sl.rb = nullptr;
+    sl.b.n = b->n;
+    sl.total_reads = total;
     const size_t n_words = (nbytes + 15) / 16, qb = (nbytes + 7) / 8, n_exc = b->n_exc;
     const uint32_t cap = (uint32_t)b->fix_cap;
     // device memory: the packed arena, the byte arena it expands into, qualities, offsets, results, exceptions, fixes
@@ -1878,9 +1906,10 @@ int rc_wait_packed(rc_ctx *c, int slot)
     RC_CHECK_HIP(ctx, hipSetDevice(ctx->device));
     RC_CHECK_HIP(ctx, hipEventSynchronize(sl.e_done));  // the results and the fix count have landed; the list was written by the kernel
     const uint32_t n_fix = *(const volatile uint32_t *)sl.p_nfix.p, cap = sl.fix_room;
-    if (n_fix > cap) {
+    if (n_fix > cap) {  // (the kernel stopped writing at cap; the results are complete, the list is not)
+        b->n_fix = n_fix;
         rc_set_error(ctx, "wait_packed: %u substitutions, room for %u (fix_cap)", n_fix, cap);
-        return RC_ERR_ARG;
+        return RC_ERR_NOSPACE;
     }
     const uint32_t *o_pos = (const uint32_t *)sl.p_fix.p;
     const uint8_t *o_chr = (const uint8_t *)sl.p_fix.p + (size_t)cap * 4;
@@ -1919,11 +1948,11 @@ int rc_submit_resident(rc_ctx *c, rc_resident_batch *b, int slot)
     const uint64_t bytes_b = b->mode == 1 ? b->bytes_b : 0;
     const size_t nbytes = (size_t)(b->bytes_a + bytes_b);
     b->n_fix = 0;
-    sl.pb = nullptr;
-    sl.rb = b;
-    sl.b.n = b->n;
-    sl.total_reads = total;
     if (total == 0) {
+        sl.pb = nullptr;
+        sl.rb = b;
+        sl.b.n = b->n;
+        sl.total_reads = total;
         sl.busy = true;
         return RC_OK;
     }
@@ -1943,8 +1972,8 @@ int rc_submit_resident(rc_ctx *c, rc_resident_batch *b, int slot)
         rc_set_error(ctx, "submit_resident: no such range of a kept arena (%zu kept; rc_table_count_keep before counting)", n_kept);
         return RC_ERR_ARG;
     }
-    if (b->off[total] != nbytes || (b->mode == 1 && b->off[b->n] != b->bytes_a)) {
-        rc_set_error(ctx, "submit_resident: the offsets do not describe the ranges (off[%zu] = %u, %zu bytes)", total, b->off[total], nbytes);
+    if (b->off[0] != 0 || b->off[total] != nbytes || (b->mode == 1 && b->off[b->n] != b->bytes_a)) {
+        rc_set_error(ctx, "submit_resident: the offsets do not describe the ranges (off[0] = %u, off[%zu] = %u, %zu bytes)", b->off[0], total, b->off[total], nbytes);
         return RC_ERR_ARG;
     }
     if (!ctx->d_buckets) {
@@ -1952,7 +1981,17 @@ int rc_submit_resident(rc_ctx *c, rc_resident_batch *b, int slot)
         return RC_ERR_STATE;
     }
     int max_len = 0;
-    for (size_t i = 0; i < total; ++i) max_len = std::max(max_len, (int)(b->off[i + 1] - b->off[i]) - 1);
+    for (size_t i = 0; i < total; ++i) {
+        if (b->off[i + 1] <= b->off[i]) {
+            rc_set_error(ctx, "submit_resident: off[%zu] = %u, off[%zu] = %u: offsets must ascend (a read is its bases and a NUL)", i, b->off[i], i + 1, b->off[i + 1]);
+            return RC_ERR_ARG;
+        }
+        max_len = std::max(max_len, (int)(b->off[i + 1] - b->off[i]) - 1);
+    }
+    sl.pb = nullptr;
+    sl.rb = b;
+    sl.b.n = b->n;
+    sl.total_reads = total;
     const size_t qb = (nbytes + 7) / 8;
     const uint32_t cap = (uint32_t)b->fix_cap;
     if ((rc = rc_dbuf_reserve(ctx, &sl.d_seq, ((nbytes + 15) & ~(size_t)15) + 64))) return rc;
@@ -2055,9 +2094,10 @@ int rc_wait_resident(rc_ctx *c, int slot)
     RC_CHECK_HIP(ctx, hipSetDevice(ctx->device));
     RC_CHECK_HIP(ctx, hipEventSynchronize(sl.e_done));
     const uint32_t n_fix = *(const volatile uint32_t *)sl.p_nfix.p, cap = sl.fix_room;
-    if (n_fix > cap) {
+    if (n_fix > cap) {  // (the kernel stopped writing at cap; the results are complete, the list is not)
+        b->n_fix = n_fix;
         rc_set_error(ctx, "wait_resident: %u substitutions, room for %u (fix_cap)", n_fix, cap);
-        return RC_ERR_ARG;
+        return RC_ERR_NOSPACE;
     }
     if (!sl.res_pinned) {
         const int32_t *r = (const int32_t *)sl.p_res.p;
@@ -2105,6 +2145,13 @@ int rc_profile_correct_counters(rc_ctx *ctx, uint64_t *reads_listed, uint64_t *g
     if (reads_listed) *reads_listed = ctx->k3_listed;
     if (gather_rounds) *gather_rounds = ctx->k3_rounds;
     if (bucket_requests) *bucket_requests = ctx->k3_requests;
+    return RC_OK;
+}
+
+int rc_profile_read_rounds(rc_ctx *ctx, int32_t *d_rounds)
+{
+    if (!ctx) return RC_ERR_ARG;
+    ctx->rounds_out = d_rounds;
     return RC_OK;
 }
 

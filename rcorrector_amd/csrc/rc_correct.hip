@@ -342,6 +342,7 @@ static int fill_args(rc_ctx *ctx, const rc_device_batch_args &a, rc_kernel_args 
         A.cap_class = cls;
     }
     A.phase_cycles = nullptr;
+    A.rounds_out = ctx->phase_prof ? ctx->rounds_out : nullptr;
     A.trace = nullptr;
     A.trace_cap = 0;
     A.fused_front_end = a.mode == 0 && !ctx->thr_ready;

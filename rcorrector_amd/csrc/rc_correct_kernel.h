@@ -492,6 +492,7 @@ struct rc_kernel_args {
     int cap;        // LDS capacity of the runtime-layout kernels (k_threshold)
     int cap_class;  // capacity class of k_correct (192 / 320 / 1024)
     unsigned long long *phase_cycles;  // [8], PROF builds only
+    int32_t *rounds_out;               // PROF builds only: gather rounds of every read k_correct processed (nullptr: not wanted)
     uint32_t work_stride;              // entries between the sections of worklist (rc_internal.h)
     int fused_front_end;               // 1: k_correct computes the read's own threshold (single-end, no threshold kernel ran)
     int32_t *trace;                    // TRACE builds only: n x (2 + trace_cap * RC_TRACE_WORDS) words
@@ -735,6 +736,7 @@ __global__ __launch_bounds__(64, rc_k3_waves(CAP)) void k_correct(rc_kernel_args
         w.phase(7);
 #ifndef RC_EXP_ROUNDS
         if (PROF) {
+            if (A.rounds_out && w.lane == 0) A.rounds_out[r] = w.rounds;
             w.rounds_sum += w.rounds;
             w.rounds_max = w.rounds > w.rounds_max ? w.rounds : w.rounds_max;
             w.rounds = 0;

@@ -205,6 +205,15 @@ void warm_buffers(Run &R, const HeadStats &H)
     }
 }
 
+// room for the substitutions of a batch of nbytes arena bytes: one per four bases (0.5 % errors fill a fiftieth of it; the
+// reference's bound, MAX_FIX_PER_K per k-mer window and more with -maxcorK, is about a third of the bases: a batch that
+// needs more comes back with RC_STATUS_NOSPACE and is run again through the byte path).  RC_FIX_CAP=<entries>: tests.
+static size_t fix_list_room(size_t nbytes)
+{
+    static const char *e = getenv("RC_FIX_CAP");
+    return e ? (size_t)atoll(e) : nbytes / 4 + 64;
+}
+
 // the output records of a finished batch, formatted (and deflated for .gz outputs) in slices by
 // the worker that ran it; the writer thread only writes
 static void format_job(Run &R, Job &J)
@@ -296,7 +305,7 @@ static void worker_body(Run &R, int wk)
             // substitutions come back and are applied to the sequence lines of the text
             Job &J = *j;
             const size_t bytes1 = J.a.off[n], bytes2 = J.mode == 1 ? J.b.off[n] : 0, nbytes = bytes1 + bytes2;
-            const size_t cap = nbytes / 4 + 64;
+            const size_t cap = fix_list_room(nbytes);
             J.pk_off.need((total + 1) * 4);
             J.pk_qbits.need((nbytes + 7) / 8 + 64);
             J.pk_fix_pos.need(cap * 4);
@@ -340,13 +349,17 @@ static void worker_body(Run &R, int wk)
                     rrc = rc_submit_resident(ctx[g], &rb, slot);
                 }
                 if (!rrc) rrc = rc_wait_resident(ctx[g], slot);
-                if (!rrc && rb.n_fix) {  // positions are distinct: any number of threads
+                // more substitutions than the list has room for (a heavily corrected tail batch: the list is sized for one fix
+                // per four bases, -maxcorK allows more): the text is untouched, the batch goes through the byte path below
+                const bool overflow = rrc == RC_STATUS_NOSPACE;
+                if (overflow) rrc = 0;
+                if (!rrc && !overflow && rb.n_fix) {  // positions are distinct: any number of threads
                     const size_t F = std::max<size_t>(1, std::min<size_t>((size_t)g_threads, rb.n_fix / 16384 + 1));
                     g_pool.run(F, [&](size_t t) {
                         apply_fixes_to_text(J.a, J.mode == 1 ? &J.b : nullptr, bytes1, rb.fix_pos, rb.fix_chr, rb.n_fix * t / F, rb.n_fix * (t + 1) / F);
                     });
                 }
-                resident_done = true;
+                resident_done = !overflow;
             }
         }
         if (!resident_done) {
@@ -405,7 +418,7 @@ static void worker_body(Run &R, int wk)
             // down, the substitutions come back as a list and are applied to the arenas in front of the formatter
             Job &J = *j;
             const size_t bytes1 = J.a.off[n], bytes2 = J.mode == 1 ? J.b.off[n] : 0, nbytes = bytes1 + bytes2;
-            const size_t n_words = (nbytes + 15) / 16, cap = nbytes / 4 + 64;
+            const size_t n_words = (nbytes + 15) / 16, cap = fix_list_room(nbytes);
             J.pk_off.need((total + 1) * 4);
             J.pk_bases.need(n_words * 4 + 64);
             J.pk_qbits.need((nbytes + 7) / 8 + 64);
@@ -497,6 +510,14 @@ static void worker_body(Run &R, int wk)
                 rc = rc_submit_packed(ctx[g], &pb, slot);
             }
             if (!rc) rc = rc_wait_packed(ctx[g], slot);
+            if (rc == RC_STATUS_NOSPACE) {  // (see the resident path) the arenas are untouched: once more, as bytes
+                {
+                    std::lock_guard<std::mutex> lk(submit_mu[(size_t)g]);
+                    rc = rc_submit(ctx[g], &rb, slot);
+                }
+                if (!rc) rc = rc_wait(ctx[g], slot);
+                pb.n_fix = 0;
+            }
             if (!rc && pb.n_fix) {  // positions are distinct: any number of threads
                 const size_t F = std::max<size_t>(1, std::min<size_t>((size_t)g_threads, pb.n_fix / 16384 + 1));
                 g_pool.run(F, [&](size_t t) {

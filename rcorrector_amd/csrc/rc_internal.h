@@ -18,7 +18,7 @@
         }                                                                                        \
     } while (0)
 
-enum { RC_OK = 0, RC_ERR_ARG = -1, RC_ERR_HIP = -2, RC_ERR_IO = -3, RC_ERR_STATE = -4, RC_ERR_NOMEM = -5 };
+enum { RC_OK = 0, RC_ERR_ARG = -1, RC_ERR_HIP = -2, RC_ERR_IO = -3, RC_ERR_STATE = -4, RC_ERR_NOMEM = -5, RC_ERR_NOSPACE = -6 };
 
 // scoped device allocation: freed on every exit path of the function that owns it
 struct rc_dev_tmp {
@@ -66,6 +66,7 @@ struct rc_ctx {
     bool phase_prof = false;  // the instrumented build of k_correct runs (RC_PHASE_PROF=1 or rc_profile_enable(ctx, 2))
     bool phase_prof_print = false;  // ... and prints its per-phase cycle accounting (RC_PHASE_PROF=1, dev aid)
     uint64_t k3_listed = 0, k3_rounds = 0, k3_requests = 0;  // accumulated by the instrumented build
+    int32_t *rounds_out = nullptr;  // rc_profile_read_rounds: where the instrumented build leaves every read's gather rounds
     rc_kernel_timer timers[RC_T_COUNT];
 
     rc_run_params P;

@@ -208,7 +208,7 @@ int main(int argc, char **argv)
     // that the first batches do not pay for a few GB of page faults and hipHostRegister calls one after the other
     run.max_in_flight = (size_t)(nworkers + 2);
     // One pass (see ingest_resident): no dump, one GPU, regular files (plain or .gz: one inflate pass instead of two) whose text
-    // fits a third of the memory that is available and whose bases fit the counter's share of HBM.  RC_RESIDENT=0 keeps the two passes, =1 skips the size test.
+    // fits a third of the host memory that is available and whose bases, count scratch and table fit the HBM that is free.  RC_RESIDENT=0 keeps the two passes, =1 skips the size test.
     bool &resident = run.resident;
     std::vector<std::unique_ptr<Retained>> &kept = run.kept;
     if (!dump && !verbose && gpus == 1 && !files.empty()) {
@@ -246,7 +246,14 @@ int main(int argc, char **argv)
                 fclose(cg);
             }
         const char *e = getenv("RC_RESIDENT");
-        resident = plain && (e ? atoi(e) != 0 : (text_bytes <= avail / 3 && text_bytes / 2 <= ((uint64_t)96 << 30)));
+        // HBM: the bases stay with the counter through the table build (about half of a FASTQ file's bytes), next to its
+        // sort scratch (RC_COUNT_MEM_MB, 24 GiB by default) and the table itself, which the bases bound from above for
+        // anything but a tiny input -- against what the device has free right now (another process may share it)
+        uint64_t hbm_free = 0, count_mem = (uint64_t)24 << 30;
+        if (const char *cm = getenv("RC_COUNT_MEM_MB")) count_mem = (uint64_t)atoll(cm) << 20;
+        if (rc_device_memory(ctx[0], &hbm_free, nullptr)) hbm_free = 0;
+        const bool fits_hbm = text_bytes + count_mem + ((uint64_t)1 << 30) <= hbm_free;
+        resident = plain && (e ? atoi(e) != 0 : (text_bytes <= avail / 3 && fits_hbm));
         if (e && atoi(e) > 1) batch_reads = std::max<size_t>(2, (size_t)atoi(e)) & ~(size_t)1;  // (tests: RC_RESIDENT=<batch size>)
         g_gz_whole = resident;
     }

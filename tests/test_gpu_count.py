@@ -209,6 +209,24 @@ def test_cli_without_c_reproduces_reference_outputs(name, resident, tmp_path, mo
     gu.assert_same_as_reference(name, tmp_path, p.stderr)
 
 
+@pytest.mark.parametrize("how", ["resident", "packed"])
+@pytest.mark.parametrize("name", ["fx_pe_k23", "fx_se_k23", "fx_k31_mc8"])
+def test_cli_fix_list_overflow_falls_back_to_the_byte_path(name, how, tmp_path, monkeypatch):
+    """A batch with more substitutions than its fix list has room for (RC_FIX_CAP=1 here; in the field a heavily corrected
+    tail batch under -maxcorK) comes back from rc_wait_resident / rc_wait_packed with RC_STATUS_NOSPACE and is run again
+    through rc_submit: same bytes as ever."""
+    monkeypatch.setenv("RC_FIX_CAP", "1")
+    args = open(os.path.join(gu.GOLDEN, name, "cmd.txt")).read().split()
+    if how == "resident":
+        monkeypatch.setenv("RC_RESIDENT", "40")
+        i = args.index("-c")
+        del args[i:i + 2]
+    else:
+        args += ["-packed", "-batch", "40"]
+    p = gu.run_fixture(CLI, name, tmp_path, args_override=args)
+    gu.assert_same_as_reference(name, tmp_path, p.stderr)
+
+
 def test_cli_without_c_several_inputs_of_every_kind_one_pass_equals_two(tmp_path):
     """-r FASTQ, -p FASTQ pair, -i interleaved, -r FASTA and a file with format quirks in ONE run without -c: the k-mers of
     all of them are counted into one table; the one-pass path (batches kept per file in input order, arenas numbered across

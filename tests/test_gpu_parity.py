@@ -367,8 +367,10 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
 def test_full_size_presets_match_the_oracle_on_a_sample(config):
     """BASELINE.json configs[1], [3] and [4] at FULL size (configs[2] is the driver's default bench run): 10 M x 100 bp,
     50 M x 150 bp with the skewed spectrum, 100 M x 150 bp at k = 31 / maxcorK 8 / 5 % errors over the 871 M-k-mer table
-    counted from all of them -- one timed step each through bench.py, then the oracle on the first 200 000 reads of the
-    same batch with the same table: return values and corrected bases must be identical."""
+    counted from all of them -- one timed step each through bench.py, then the oracle with the same table on three strata of
+    the whole shard (bench.py: parity_strata): the first 100 000 reads, 100 000 drawn across every device arena by a seeded
+    stride, and per arena the 1 000 reads with the most gather rounds (with their mates) -- the reads that stress the search
+    at scale are in the sample by construction, not by luck: return values, l / m / h and corrected bases must be identical."""
     import json
     import subprocess
     import sys
@@ -384,7 +386,11 @@ def test_full_size_presets_match_the_oracle_on_a_sample(config):
     assert d["config"]["reads_per_gpu"] == {1: 10_000_000, 3: 50_000_000, 4: 100_000_000}[config]
     cb = d["cpu_baseline"]
     assert cb["gpu_matches_oracle_on_sample"] is True, cb
-    assert "200000 reads" in cb["sample"] and d["config"]["reads_corrected_frac"] > 0.2
+    st = cb["strata"]
+    assert set(st) == {"first", "stride", "heavy"} and all(v["identical"] for v in st.values()), st
+    assert st["first"]["reads"] == 100_000 and abs(st["stride"]["reads"] - 100_000) < 200
+    assert st["heavy"]["reads"] >= 1000 and st["heavy"]["max_gather_rounds"] == cb["worst_read_gather_rounds"] > st["first"]["max_gather_rounds"] - 1
+    assert cb["instrumented_build_same_ret"] is True and "seeded stride" in cb["sample"] and d["config"]["reads_corrected_frac"] > 0.2
 
 
 @pytest.mark.gpu
@@ -763,6 +769,22 @@ def test_packed_boundary_slots_fasta_and_errors(gpu_ctx_factory, oracle):
     assert np.array_equal(ret2, datasets.run_oracle(oracle, sub)[0])
     with pytest.raises(rcorrector_amd.RcorrectorError):
         ctx.submit_packed(0, 1, arena.size + 1, off, bases, qb, exc_pos, exc_chr)   # off[total] is not the arena's size
+    # offsets that do not ascend and exceptions outside the arena are refused before anything is launched (the terminator and
+    # exception kernels write seq[off[i+1]-1] / seq[exc_pos[i]] unchecked), and a refused submit leaves the slot free
+    bad = off.copy()
+    bad[3] = bad[2]
+    with pytest.raises(rcorrector_amd.RcorrectorError, match="ascend"):
+        ctx.submit_packed(0, 1, arena.size, bad, bases, qb, exc_pos, exc_chr)
+    bad = off.copy()
+    bad[0] = 1
+    with pytest.raises(rcorrector_amd.RcorrectorError, match=r"off\[0\]"):
+        ctx.submit_packed(0, 1, arena.size, bad, bases, qb, exc_pos, exc_chr)
+    with pytest.raises(rcorrector_amd.RcorrectorError, match="outside the arena"):
+        ctx.submit_packed(0, 1, arena.size, off, bases, qb, np.array([arena.size], dtype=np.uint32), np.array([ord("N")], dtype=np.uint8))
+    with pytest.raises(rcorrector_amd.RcorrectorError, match="holds no packed batch"):
+        ctx.wait_packed(0)
+    ctx.submit_packed(0, 1, arena.size, off, bases, qb, exc_pos, exc_chr)
+    assert np.array_equal(ctx.wait_packed(0)[0], ret2)
 
 
 @pytest.mark.gpu
