@@ -40,6 +40,9 @@ __device__ __forceinline__ int rc_table_lookup(const rc_table_view &T, uint64_t 
         uint32_t b, rem, xrem, top;
         const int ext = EXT ? T.ext : 0;
         rc_packed_addr(canon, T.k, T.nb_home, ext, &b, &rem, &xrem, &top);
+#ifdef RC_EXP_ADDR_WINDOW  // dev (tools/exp/addr_window.md): every probe lands in the first RC_EXP_ADDR_WINDOW buckets -- WRONG counts; what
+        b &= (RC_EXP_ADDR_WINDOW - 1);  // the probe kernel would cost if the table's lines were always in the L2 / Infinity Cache
+#endif
         if (T.filter) {  // (wave-uniform) large tables: most misses end at one word of the filter
             const uint32_t fm = rc_filter_mask(rem);
             if ((T.filter[rc_mulhi32(top, T.filter_words)] & fm) != fm) return 0;

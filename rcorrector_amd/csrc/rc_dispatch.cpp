@@ -4,6 +4,17 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+// room for the substitutions of a batch of nbytes arena bytes: one per sixteen bases (0.5 % errors fill a twelfth of it, 5 %
+// two thirds; the reference's bound, MAX_FIX_PER_K per k-mer window and more with -maxcorK, is about a third of the bases: a
+// batch that needs more comes back with RC_STATUS_NOSPACE and is run again through the byte path).  The list is page-locked,
+// and page-locking touches every page whether a fix ever lands there or not: at one entry per four bases it was 190 MB per
+// job of a million 150-base reads, most of what a run locks and unlocks.  RC_FIX_CAP=<entries>: tests.
+static size_t fix_list_room(size_t nbytes)
+{
+    static const char *e = getenv("RC_FIX_CAP");
+    return e ? (size_t)atoll(e) : nbytes / 16 + 64;
+}
+
 void ingest_resident(Run &R_, size_t batch_reads, int64_t *stored, bool keep)
 {
     rc_ctx *ctx = R_.ctx[0];
@@ -194,8 +205,8 @@ void warm_buffers(Run &R, const HeadStats &H)
             const size_t nb = (size_t)sides * arena_bytes;
             j->pk_off.need((total + 1) * 4);
             j->pk_qbits.need((nb + 7) / 8 + 64);
-            j->pk_fix_pos.need((nb / 4 + 64) * 4);
-            j->pk_fix_chr.need(nb / 4 + 64);
+            j->pk_fix_pos.need(fix_list_room(nb) * 4);
+            j->pk_fix_chr.need(fix_list_room(nb));
         }
         j->ret.reserve(total);
         j->l.reserve(total);
@@ -203,15 +214,6 @@ void warm_buffers(Run &R, const HeadStats &H)
         j->h.reserve(total);
         warm_jobs.push_back(j);
     }
-}
-
-// room for the substitutions of a batch of nbytes arena bytes: one per four bases (0.5 % errors fill a fiftieth of it; the
-// reference's bound, MAX_FIX_PER_K per k-mer window and more with -maxcorK, is about a third of the bases: a batch that
-// needs more comes back with RC_STATUS_NOSPACE and is run again through the byte path).  RC_FIX_CAP=<entries>: tests.
-static size_t fix_list_room(size_t nbytes)
-{
-    static const char *e = getenv("RC_FIX_CAP");
-    return e ? (size_t)atoll(e) : nbytes / 4 + 64;
 }
 
 // the output records of a finished batch, formatted (and deflated for .gz outputs) in slices by
@@ -235,9 +237,16 @@ static void format_job(Run &R, Job &J)
     o2.resize(S);
     for (auto &v : o1) v.clear();
     for (auto &v : o2) v.clear();
+    std::vector<uint64_t> cor(S, 0);  // (the writer thread is the pipeline's narrow place: it only writes)
     auto fmt = [&](size_t lo, size_t hi) {
         for (size_t s = lo; s < hi; ++s) {
             const size_t r0 = n * s / S, r1 = n * (s + 1) / S;
+            uint64_t c = 0;
+            for (size_t r = r0; r < r1; ++r) {
+                if (j->ret[r] > 0) c += (uint64_t)j->ret[r];
+                if (j->mode == 1 && j->ret[n + r] > 0) c += (uint64_t)j->ret[n + r];
+            }
+            cor[s] = c;
             o1[s].reserve((r1 - r0) * 300);
             for (size_t r = r0; r < r1; ++r) {
                 put_record(o1[s], j->a, r, j->fastq, j->ret[r], j->l[r], j->m[r], j->h[r]);
@@ -251,6 +260,8 @@ static void format_job(Run &R, Job &J)
         }
     };
     g_pool.run(S, [&](size_t s) { fmt(s, s + 1); });
+    J.cor_bases = 0;
+    for (uint64_t c : cor) J.cor_bases += c;
     if (gz1 || gz2) {  // deflate every slice into its own gzip member, in parallel
         std::vector<OutBuf> z1(S), z2(S);
         g_pool.run(S, [&](size_t s) {
@@ -609,10 +620,8 @@ for (;;) {
         if (j->mode == 1 && !alternate) emit_slices(g2, j->o2);
     }
     g_t_write += now_s() - tw0;
-    for (size_t r = 0; r < j->ret.size(); ++r) {  // UpdateSummary, main.cpp:73-79
-        ++total_reads;
-        if (j->ret[r] > 0) total_cor += (uint64_t)j->ret[r];
-    }
+    total_reads += j->ret.size();  // UpdateSummary, main.cpp:73-79
+    total_cor += j->cor_bases;
     bool retire = false;
     {
         std::lock_guard<std::mutex> lk(mu);

@@ -39,6 +39,7 @@ struct Job {
     // letters outside ACGT) and the room for the fix list
     PinBuf pk_off, pk_bases, pk_qbits, pk_exc_pos, pk_exc_chr, pk_fix_pos, pk_fix_chr;
     std::vector<OutBuf> o1, o2;  // the formatted (and, for .gz, deflated) output records, in slices
+    uint64_t cor_bases = 0;  // sum of the positive return values (UpdateSummary, main.cpp:73-79), added up by the formatter
     bool done = false;
     int rc = 0;
     std::string err;

@@ -8,6 +8,14 @@
 
 #include "rc_pool.h"
 
+// where Source::fill leaves the positions (relative to `base`) of the newlines it reads, in ascending order, when it can
+// find them on the way (done = it did: regular files)
+struct NlSink {
+    const char *base;
+    std::vector<uint32_t> *nl;
+    bool done;
+};
+
 // ---- input: a stream of bytes cut into blocks of whole records --------------------------------
 struct Source {
     std::string path;
@@ -34,7 +42,7 @@ struct Source {
     // appends up to `want` bytes of the file at dst; sets eof when the file ends first.  Regular
     // files are read by several threads at once (pread into disjoint slices: the copy out of the
     // page cache is what limits a single reader), streams and .gz by this thread alone.
-    size_t fill(char *dst, size_t want);
+    size_t fill(char *dst, size_t want, NlSink *sink = nullptr);
 };
 
 // a batch of raw records: the text plus the start of every line (lines_per_record per record)

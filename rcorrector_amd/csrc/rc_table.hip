@@ -725,6 +725,10 @@ __global__ __launch_bounds__(256) void k_unit_key(const uint8_t *__restrict__ se
     const int top = 2 * (m - 1);
     uint32_t fw = 0, rv = 0, best = 0xFFFFFFFFu;
     int valid = 0;
+#ifdef RC_KEY_OFFSET
+    int best_i = 0;
+    bool best_rev = false;
+#endif
     for (int i = 0; i < len; ++i) {
         const uint32_t c = s_raw[o + i];
         const uint32_t b = ((c >> 1) ^ (c >> 2)) & 3u;                     // A 0, C 1, G 2, T 3
@@ -738,9 +742,26 @@ __global__ __launch_bounds__(256) void k_unit_key(const uint8_t *__restrict__ se
             h ^= h >> 15;
             h *= 0x2C1B3C6Du;
             h ^= h >> 13;
+#ifdef RC_KEY_OFFSET
+            if (h < best) {
+                best_i = i;
+                best_rev = rv < fw;
+            }
+#endif
             best = h < best ? h : best;
         }
     }
+#ifdef RC_KEY_OFFSET
+    // Within a group of units that share their minimal m-mer, the order is that of the reads' starts in the frame in which
+    // the m-mer is forward (its offset in the read, or in the read's reverse complement): neighbours in the list then
+    // overlap in all but a few bases instead of two thirds of them, and a k-mer's second probe follows its first one a
+    // read later instead of somewhere in the group -- inside what the L2 still holds.  Seven bits of the key, half a base each.
+    if (best != 0xFFFFFFFFu) {
+        int p = best_rev ? len - 1 - best_i : best_i - m + 1;
+        p = (p >> 1) > 127 ? 127 : (p >> 1);
+        best = (best & ~0x7Fu) | (uint32_t)(127 - p);  // (descending offset = ascending start)
+    }
+#endif
 #else
     const uint64_t mask = rc_kmer_mask(k);
     uint64_t fw = 0, rv = 0;

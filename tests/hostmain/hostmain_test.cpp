@@ -105,6 +105,41 @@ int main(int argc, char **argv)
                 if (memcmp(A[sd].sequence((size_t)r), B[sd].sequence((size_t)r), sl) != 0) return fail("fixes applied to the text", seed);
             }
     }
+    {   // a file of several read slices (the reader cuts a request into 8 MB slices read side by side, each a megabyte at a
+        // time with its newlines found on the way): the blocks, put end to end, are the file, and the line index is exact
+        const std::string big = dir + "/hm_big.fq";
+        std::mt19937 rng(99);
+        std::string content;
+        const int n = 260000;
+        for (int r = 0; r < n; ++r) {
+            const int sl = 40 + (int)(rng() % 120);
+            std::string sq(sl, 'A'), q(sl, 'I');
+            for (auto &c : sq) c = "ACGT"[rng() % 4];
+            content += "@big" + std::to_string(r) + "\n" + sq + "\n+\n" + q + "\n";
+        }
+        FILE *f = fopen(big.c_str(), "wb");
+        fwrite(content.data(), 1, content.size(), f);
+        fclose(f);
+        Source s;
+        s.open(big);
+        Block b;
+        size_t at = 0, recs = 0;
+        for (int round = 0;; ++round) {
+            take_records(s, round % 2 ? 90000 : 50001, 4, b);
+            if (b.records == 0) break;
+            const size_t nl = b.records * 4, end = b.line[nl];
+            if (at + end > content.size() || memcmp(b.text.p, content.data() + at, end) != 0) return fail("big file: block bytes", (unsigned)round);
+            for (size_t i = 0; i < nl; ++i) {
+                if (b.text.p[b.line[i + 1] - 1] != '\n') return fail("big file: line end", (unsigned)round);
+                if (memchr(b.text.p + b.line[i], '\n', b.line[i + 1] - 1 - b.line[i])) return fail("big file: newline inside a line", (unsigned)round);
+            }
+            at += end;
+            recs += b.records;
+        }
+        s.close();
+        if (at != content.size() || recs != (size_t)n) return fail("big file: size", 0);
+        unlink(big.c_str());
+    }
     printf("ok 60 cases\n");
     fflush(stdout);
     _exit(0);
