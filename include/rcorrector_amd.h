@@ -83,6 +83,11 @@ int rc_table_count_finish(rc_ctx *ctx, int min_count, int64_t *n_kmers);
 int rc_table_count_keep(rc_ctx *ctx, int on);
 int rc_table_count_arenas(const rc_ctx *ctx, size_t *n_arenas, uint64_t *bytes, size_t cap);
 int rc_table_count_release(rc_ctx *ctx);
+/* ends a session opened by rc_table_count_begin WITHOUT counting: the arenas added since stay in HBM as kept arenas (in the
+ * order of the non-empty count_add calls), no table is built and the context's table, if any, stays.  For a GPU that will
+ * correct reads whose k-mers another GPU counts (the table arrives by rc_table_replicate): one Store, T workers,
+ * main.cpp:294-308,451 -- each worker's reads uploaded once, to the GPU that corrects them. */
+int rc_table_count_park(rc_ctx *ctx);
 /* begin + add_device + finish for one arena */
 int rc_table_count_reads_device(rc_ctx *ctx, const uint8_t *d_seq, size_t nbytes, int min_count,
                                 int64_t *n_kmers);

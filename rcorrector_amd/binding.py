@@ -13,7 +13,7 @@ ABI_SYMBOLS = [
     "rc_create", "rc_destroy", "rc_last_error", "rc_device_numa_node", "rc_device_memory",
     "rc_table_build", "rc_table_build_device", "rc_table_load_jfdump",
     "rc_table_count_begin", "rc_table_count_add", "rc_table_count_add_device", "rc_table_count_finish",
-    "rc_table_count_keep", "rc_table_count_arenas", "rc_table_count_release", "rc_submit_resident", "rc_wait_resident",
+    "rc_table_count_keep", "rc_table_count_arenas", "rc_table_count_release", "rc_table_count_park", "rc_submit_resident", "rc_wait_resident",
     "rc_table_count_reads_device", "rc_table_write_jfdump", "rc_table_share", "rc_table_replicate", "rc_table_replicate_async", "rc_table_lookup", "rc_table_export", "rc_table_digest", "rc_table_layout", "rc_table_stats",
     "rc_estimate_error_rate", "rc_bad_quality_from_hist", "rc_set_run_params", "rc_set_quality_bits", "rc_pack_quality_bits",
     "rc_correct_batch", "rc_submit", "rc_wait", "rc_host_alloc", "rc_host_free", "rc_host_register", "rc_host_unregister", "rc_correct_batch_traced", "rc_correct_device", "rc_strong_threshold_device", "rc_probe_device", "rc_sync",
@@ -114,6 +114,7 @@ def load_library():
     L.rc_table_count_keep.argtypes = [vp, C.c_int]
     L.rc_table_count_arenas.argtypes = [vp, C.POINTER(C.c_size_t), vp, sz]
     L.rc_table_count_release.argtypes = [vp]
+    L.rc_table_count_park.argtypes = [vp]
     L.rc_submit_resident.argtypes = [vp, C.POINTER(_ResidentBatch), C.c_int]
     L.rc_wait_resident.argtypes = [vp, C.c_int]
     L.rc_table_write_jfdump.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64)]
@@ -460,6 +461,10 @@ class Context:
         b = np.zeros(max(1, n.value), dtype=np.uint64)
         self._ck(self._L.rc_table_count_arenas(self._h, C.byref(n), b.ctypes.data, len(b)))
         return b[:n.value]
+
+    def count_park(self):
+        """rc_table_count_park: the arenas added since count_begin become kept arenas; nothing is counted, no table built"""
+        self._ck(self._L.rc_table_count_park(self._h))
 
     def count_release(self):
         self._ck(self._L.rc_table_count_release(self._h))

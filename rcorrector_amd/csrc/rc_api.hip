@@ -103,6 +103,7 @@ rc_table_view rc_view(const rc_ctx *ctx)
     v.k = ctx->k;
     v.filter_words = ctx->filter_words;
     v.filter = ctx->filter_words ? ctx->d_buckets + ctx->table_bytes / 4 : nullptr;
+    v.filter_kind = ctx->filter_kind;
     return v;
 }
 
@@ -553,6 +554,7 @@ int rc_table_share(rc_ctx *dst, const rc_ctx *src)
     dst->n_entries = src->n_entries;
     dst->table_bytes = src->table_bytes;
     dst->filter_words = src->filter_words;
+    dst->filter_kind = src->filter_kind;
     return RC_OK;
 }
 
@@ -641,6 +643,7 @@ int rc_table_replicate_async(rc_ctx *dst, const rc_ctx *src)
     dst->n_entries = src->n_entries;
     dst->table_bytes = src->table_bytes;
     dst->filter_words = src->filter_words;
+    dst->filter_kind = src->filter_kind;
     return RC_OK;
 }
 
@@ -712,6 +715,13 @@ int rc_table_count_finish(rc_ctx *ctx, int min_count, int64_t *n_kmers)
     RC_CHECK_HIP(ctx, hipSetDevice(ctx->device));
     static_cast<rc_ctx_full *>(ctx)->dump.valid = false;
     return rc_count_finish(ctx, min_count, n_kmers);
+}
+
+int rc_table_count_park(rc_ctx *ctx)
+{
+    if (!ctx) return RC_ERR_ARG;
+    RC_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    return rc_count_park(ctx);
 }
 
 // the table as `jellyfish dump` text (">COUNT\nKMER\n" per entry, canonical k-mer), in dump order

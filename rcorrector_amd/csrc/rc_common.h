@@ -61,11 +61,33 @@ struct rc_table_view {
     // the bucket array -- which, beyond the reach of the TLB, is what a miss costs (rc_table.hip: build_attempt).
     const uint32_t *filter;
     uint32_t filter_words;
+    // 0: as above.  1 ("core", round 5): the word of a k-mer is chosen by its first k - 1 bases in ONE of its two orientations
+    // (rc_filter_core_addr), and every entry is entered under both: the four k-mers a search node asks about -- one (k-1)-mer
+    // extended by A, C, G, T (ErrorCorrection.cpp:286-301 / :523-538) -- then share a word, i.e. one request instead of
+    // four, when the caller names the orientation in which the varying base comes last.  Any orientation gives the right
+    // answer; 16 bits per entry instead of 10 (two insertions).
+    int filter_kind;
 };
 // bits of a key in its filter word (three of 32, from 15 bits of the remainder)
 RC_HD uint32_t rc_filter_mask(uint32_t rem)
 {
     return (1u << (rem & 31u)) | (1u << ((rem >> 5) & 31u)) | (1u << ((rem >> 10) & 31u));
+}
+// kind 1: word and bits of the k-mer whose 2k-bit code, in the orientation the caller chose, is f
+RC_HD void rc_filter_core_addr(uint64_t f, uint32_t words, uint32_t *word, uint32_t *mask)
+{
+    const uint64_t core = f >> 2;
+    uint32_t h = (uint32_t)core * 0x9E3779B1u + (uint32_t)(core >> 32) * 0x85EBCA77u;
+    h ^= h >> 15;
+    h *= 0x2C1B3C6Du;
+    h ^= h >> 13;
+#if defined(__HIP_DEVICE_COMPILE__)
+    *word = __umulhi(h, words);
+#else
+    *word = (uint32_t)(((uint64_t)h * words) >> 32);
+#endif
+    const uint32_t r = (h ^ (((uint32_t)f & 3u) * 0x9E3779B1u)) * 0x297A2D39u;
+    *mask = rc_filter_mask(r >> 17);
 }
 #define RC_PACKED_MAX_EXT 8   // counts keep at least 19 bits
 // A count that does not fit the count field is stored as "all ones" and kept in full in a small

@@ -560,7 +560,7 @@ RC_HD int rc_probe4_cached(W &w, rc_read_state &S, rc_spec_state &Z, const rc_ru
         w.for_lanes64(e0, E, [&](int q, int) {
             bool live;
             const rc_kmer km = entry(q, &live);
-            S.spec_cnt[q] = w.get(km);
+            S.spec_cnt[q] = w.get(km, dir);
         });
     }
     if (w.lane == 0) {
@@ -945,7 +945,7 @@ RC_HD void rc_search(W &w, rc_read_state &S, const rc_run_params &P, rc_search_c
                     }
                     if (sN == 0 && m > mc) {
                         const uint64_t hit = w.ballot64(mc + 1, m + 1, [&](int q) {
-                            return w.get(rc_extend_run(S, tmp0, k, dir, pos + dir, q)) >= threshold;
+                            return w.get(rc_extend_run(S, tmp0, k, dir, pos + dir, q), dir) >= threshold;
                         });
                         w.stat(4, 1);
                         w.stat(5, m - mc);

@@ -190,10 +190,14 @@ struct DevWaveT {
 
     uint32_t n_req = 0;  // PROF builds: bucket reads issued by this lane
     uint32_t n_probe = 0, n_absent = 0;  // PROF builds: k-mers looked up by this lane / of them not in the table
-    __device__ __forceinline__ int get(rc_kmer km)
+    // dir: the search direction the k-mer was extended in (+1: its last base is the one that varies between the lanes of a
+    // gather round, -1: its first -- i.e. the last of its reverse complement), 0: no such neighbours
+    __device__ __forceinline__ int get(rc_kmer km, int dir = 0)
     {
         if (km.inv != -1) return 0;
-        const int c = rc_table_lookup(T, rc_canonical(km.code, KT ? KT : k), PROF ? &n_req : nullptr);
+        const uint64_t rv = rc_revcomp(km.code, KT ? KT : k);
+        const uint64_t canon = rv < km.code ? rv : km.code;
+        const int c = rc_table_lookup_o(T, canon, dir > 0 ? km.code : (dir < 0 ? rv : canon), PROF ? &n_req : nullptr);
         if (PROF) {
             ++n_probe;
             n_absent += c == 0 ? 1u : 0u;

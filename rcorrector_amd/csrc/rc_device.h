@@ -30,8 +30,10 @@ __device__ inline int rc_packed_overflow_count(const rc_table_view &T, uint64_t 
 
 // EXT = false: the caller knows that T.ext == 0 (the probe kernels, bound by VALU issue, are compiled
 // both ways: the masks become constants and the extra multiply of rc_packed_addr disappears)
+// orient: canon or its reverse complement -- the orientation in which the caller's neighbours differ in the LAST base (a
+// search node's four extensions), for the "core" filter of rc_common.h; callers without such neighbours pass canon
 template <bool EXT = true>
-__device__ __forceinline__ int rc_table_lookup(const rc_table_view &T, uint64_t canon, uint32_t *n_req = nullptr)
+__device__ __forceinline__ int rc_table_lookup_o(const rc_table_view &T, uint64_t canon, uint64_t orient, uint32_t *n_req = nullptr)
 {
     // The slots are compared as 64-bit words, from the last slot to the first, so that the first slot in
     // probe order is assigned last and wins without a test (two instructions per slot: the probe
@@ -44,8 +46,14 @@ __device__ __forceinline__ int rc_table_lookup(const rc_table_view &T, uint64_t 
         b &= (RC_EXP_ADDR_WINDOW - 1);  // the probe kernel would cost if the table's lines were always in the L2 / Infinity Cache
 #endif
         if (T.filter) {  // (wave-uniform) large tables: most misses end at one word of the filter
-            const uint32_t fm = rc_filter_mask(rem);
-            if ((T.filter[rc_mulhi32(top, T.filter_words)] & fm) != fm) return 0;
+            if (T.filter_kind) {
+                uint32_t fw, fm;
+                rc_filter_core_addr(orient, T.filter_words, &fw, &fm);
+                if ((T.filter[fw] & fm) != fm) return 0;
+            } else {
+                const uint32_t fm = rc_filter_mask(rem);
+                if ((T.filter[rc_mulhi32(top, T.filter_words)] & fm) != fm) return 0;
+            }
         }
         const uint32_t cmask = RC_PACKED_COUNT_MASK >> ext;  // (uniform)
         const uint64_t mask = ((uint64_t)(0x7FFFFFFFu & ~cmask) << 32) | 0xFFFFFFFFull;
@@ -95,6 +103,12 @@ __device__ __forceinline__ int rc_table_lookup(const rc_table_view &T, uint64_t 
         if (r != 0 || !(d[RC_BUCKET_DWORDS - 1] & 1u)) return r;
         ++b;
     }
+}
+
+template <bool EXT = true>
+__device__ __forceinline__ int rc_table_lookup(const rc_table_view &T, uint64_t canon, uint32_t *n_req = nullptr)
+{
+    return rc_table_lookup_o<EXT>(T, canon, canon, n_req);
 }
 
 // ---- pieces of the probe kernels (K1) shared by rc_table.hip and rc_correct.hip ----------------------

@@ -79,8 +79,15 @@ void ingest_resident(Run &R_, size_t batch_reads, int64_t *stored, bool keep)
         cv.notify_all();
     });
     if (rc_table_count_keep(ctx, keep ? 1 : 0) || rc_table_count_begin(ctx)) die("rcorrector: %s\n", rc_last_error(ctx));
+    // Several GPUs, one pass: the batches are dealt round-robin.  Every arena goes to GPU 0, which counts all of them (one
+    // Store for all workers, main.cpp:294-308), and -- once more -- to the GPU that will correct it, which only keeps it
+    // (rc_table_count_park): the files are read once, and a batch is corrected where its bases already are.
+    const int n_gpus = keep ? R_.gpus : 1;
+    for (int g = 1; g < n_gpus; ++g)
+        if (rc_table_count_begin(R_.ctx[(size_t)g])) die("rcorrector: %s\n", rc_last_error(R_.ctx[(size_t)g]));
     PinBuf stage;  // the sequences of one file's share of a batch on their way to HBM
-    int next_arena = 0;
+    std::vector<int> next_arena((size_t)n_gpus, 0);
+    size_t n_batches = 0;
     for (;;) {
         std::unique_ptr<Retained> R;
         {
@@ -92,6 +99,7 @@ void ingest_resident(Run &R_, size_t batch_reads, int64_t *stored, bool keep)
             cv.notify_all();
         }
         const double tp0 = now_s();
+        R->gpu = (int)(n_batches++ % (size_t)n_gpus);
         for (int sd = 0; sd < (R->mode == 1 ? 2 : 1); ++sd) {
             if ((sd ? R->b : R->a).records == 0) continue;  // (keep = false: one mate's file ended before the other's)
             Arena A;  // (a view for index_arena / pack_sequences: the block is swapped in and out)
@@ -103,7 +111,13 @@ void ingest_resident(Run &R_, size_t batch_reads, int64_t *stored, bool keep)
             pack_sequences(A, stage.data());
             // (an arena without a byte is not kept: cannot happen, every record has at least its NUL)
             if (rc_table_count_add(ctx, stage.data(), total)) die("rcorrector: %s\n", rc_last_error(ctx));
-            (sd ? R->arena_b : R->arena_a) = next_arena++;
+            int idx = next_arena[0]++;
+            if (R->gpu != 0) {
+                rc_ctx *cg = R_.ctx[(size_t)R->gpu];
+                if (rc_table_count_add(cg, stage.data(), total)) die("rcorrector: %s\n", rc_last_error(cg));
+                idx = next_arena[(size_t)R->gpu]++;
+            }
+            (sd ? R->arena_b : R->arena_a) = idx;
             (sd ? R->off_b : R->off_a).swap(A.off);
             A.blk.swap(sd ? R->b : R->a);
         }
@@ -117,6 +131,8 @@ void ingest_resident(Run &R_, size_t batch_reads, int64_t *stored, bool keep)
     }
     reader.join();
     stamp(keep ? "inputs read, indexed and uploaded" : "inputs read and uploaded for the k-mer count");
+    for (int g = 1; g < n_gpus; ++g)
+        if (rc_table_count_park(R_.ctx[(size_t)g])) die("rcorrector: %s\n", rc_last_error(R_.ctx[(size_t)g]));
     if (rc_table_count_finish(ctx, 2, stored)) die("rcorrector: %s\n", rc_last_error(ctx));
     stamp("k-mers counted, table built");
 }
@@ -295,11 +311,18 @@ static void worker_body(Run &R, int wk)
         {
             std::unique_lock<std::mutex> lk(mu);
             const double tw = now_s();
-            cv.wait(lk, [&] { return closing || !q.empty(); });
+            // (a resident batch belongs to the GPU that holds its bases; the others go to whichever context is free)
+            auto mine = [&]() {
+                for (auto it = q.begin(); it != q.end(); ++it)
+                    if ((*it)->gpu < 0 || (*it)->gpu == g) return it;
+                return q.end();
+            };
+            cv.wait(lk, [&] { return closing || mine() != q.end(); });
             g_w_worker += now_s() - tw;
-            if (q.empty()) return;
-            j = q.front();
-            q.pop_front();
+            auto it = mine();
+            if (it == q.end()) return;
+            j = *it;
+            q.erase(it);
         }
         const double tp0 = now_s();
         const size_t n = j->a.n();
@@ -683,6 +706,7 @@ void run_pipeline(Run &R)
             j->mode = R->mode;
             j->fastq = R->fastq;
             j->resident = true;
+            j->gpu = R->gpu;
             j->arena_a = R->arena_a;
             j->arena_b = R->arena_b;
             j->a.lpr = R->lpr_a;
@@ -721,6 +745,8 @@ void run_pipeline(Run &R)
                 j->file = (int)fi;
                 j->mode = f.paired ? 1 : (f.interleaved ? 2 : 0);
                 j->fastq = f.fastq;
+                j->resident = false;
+                j->gpu = -1;
                 j->a.lpr = lpr;
                 j->b.lpr = f.paired ? (mates[fi].fastq ? 4 : 2) : lpr;
                 const double tr0 = now_s();

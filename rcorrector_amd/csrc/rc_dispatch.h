@@ -20,7 +20,8 @@ struct Retained {
     int lpr_a = 4, lpr_b = 4;
     Block a, b;
     std::vector<uint32_t> off_a, off_b;
-    int arena_a = 0, arena_b = 0;
+    int arena_a = 0, arena_b = 0;  // kept arenas of GPU `gpu`'s context
+    int gpu = 0;
 };
 
 // everything the stages of a run share

@@ -71,13 +71,15 @@ bool pack_quality_bits_from_text(const QualView &V, char bad_q, size_t lo, size_
     uint64_t acc = 0;
     int nacc = 0;
     uint8_t *out = bits + (lo >> 3);
-    auto put = [&](uint64_t v, int nb) {  // nb <= 16 bits at a time
+    auto put = [&](uint64_t v, int nb) {  // nb <= 16 bits at a time; four bytes leave at once (they all belong to this range)
         acc |= v << nacc;
         nacc += nb;
-        while (nacc >= 8) {
-            *out++ = (uint8_t)acc;
-            acc >>= 8;
-            nacc -= 8;
+        if (nacc >= 32) {
+            const uint32_t w = (uint32_t)acc;
+            memcpy(out, &w, 4);
+            out += 4;
+            acc >>= 32;
+            nacc -= 32;
         }
     };
     const __m128i thr = _mm_set1_epi8(bad_q);
@@ -119,7 +121,10 @@ bool pack_quality_bits_from_text(const QualView &V, char bad_q, size_t lo, size_
         }
         if (pos < end_side) pos = end_side;  // (cannot happen: the reads tile the arena)
     }
-    if (nacc) *out = (uint8_t)acc;
+    for (; nacc > 0; nacc -= 8) {  // (the last byte is a partial one only at the arena's end)
+        *out++ = (uint8_t)acc;
+        acc >>= 8;
+    }
     return ok;
 }
 

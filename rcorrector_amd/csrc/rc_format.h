@@ -35,6 +35,7 @@ struct Job {
     std::vector<int32_t> tr_before, tr_after, tr_flags, tr_niter, tr_iter;  // -verbose only
     bool resident = false;        // the batch's reads are arenas the k-mer counter kept in HBM (rc_submit_resident)
     int arena_a = 0, arena_b = 0;
+    int gpu = -1;                 // the GPU that holds them (-1: any GPU may take the batch)
     // -packed: the batch as rc_packed_batch wants it (one offset array over both arenas, 2-bit codes, quality bits, the
     // letters outside ACGT) and the room for the fix list
     PinBuf pk_off, pk_bases, pk_qbits, pk_exc_pos, pk_exc_chr, pk_fix_pos, pk_fix_chr;

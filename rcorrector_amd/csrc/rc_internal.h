@@ -87,6 +87,7 @@ struct rc_ctx {
     size_t n_entries = 0;   // accepted entries (duplicates included)
     size_t table_bytes = 0;
     uint32_t filter_words = 0;  // absence filter behind the bucket array (rc_common.h: rc_table_view::filter), 0 = none
+    int filter_kind = 0;        // rc_table_view::filter_kind of the filter that is there
 
     // -verbose support: iterations recorded per read by k_correct (0 = off) and the record buffer
     int trace_cap = 0;
@@ -162,6 +163,7 @@ int rc_count_begin(rc_ctx *ctx);
 void rc_kept_release(rc_ctx *ctx);
 int rc_count_add(rc_ctx *ctx, const uint8_t *seq, size_t nbytes, bool from_device);
 int rc_count_finish(rc_ctx *ctx, int min_count, int64_t *n_kmers);
+int rc_count_park(rc_ctx *ctx);
 int rc_count_reads(rc_ctx *ctx, const uint8_t *d_seq, size_t nbytes, int min_count, int64_t *n_kmers);
 int rc_launch_selftest_bound(rc_ctx *ctx, const int32_t *d_c, size_t n, double e, int32_t *d_oi, double *d_od);
 int rc_launch_export(rc_ctx *ctx, uint64_t *d_codes, int32_t *d_counts, unsigned long long *d_n, size_t cap);
@@ -217,6 +219,9 @@ int rc_launch_fix_list(rc_ctx *ctx, const uint32_t *d_packed, size_t nbytes, con
 // the most expensive first, so that the last waves of a launch are not left alone with them
 // (cls value of a read = 1 + its section counted from the back; cls 0 = finished by the threshold kernel)
 #define RC_WORK_CLASSES 4
+#ifndef RC_FILTER_KIND_DEFAULT
+#define RC_FILTER_KIND_DEFAULT 0  // (1 once measured: RC_TABLE_FILTER_KIND=core)
+#endif
 // layout of rc_ctx::work (bytes): RC_WORK_CLASSES x RC_HEADS queue heads of k_correct, 128 B apart,
 // then the lengths of the work-list sections, then the phase counters of PROF builds
 #define RC_WORK_BYTES 5120

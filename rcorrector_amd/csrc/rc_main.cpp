@@ -207,11 +207,11 @@ int main(int argc, char **argv)
     // are allocated, sized from the head of the first input, touched and registered with the GPU runtime here, so
     // that the first batches do not pay for a few GB of page faults and hipHostRegister calls one after the other
     run.max_in_flight = (size_t)(nworkers + 2);
-    // One pass (see ingest_resident): no dump, one GPU, regular files (plain or .gz: one inflate pass instead of two) whose text
+    // One pass (see ingest_resident): no dump, any number of GPUs (the batches are dealt to them as they are read), regular files (plain or .gz: one inflate pass instead of two) whose text
     // fits a third of the host memory that is available and whose bases, count scratch and table fit the HBM that is free.  RC_RESIDENT=0 keeps the two passes, =1 skips the size test.
     bool &resident = run.resident;
     std::vector<std::unique_ptr<Retained>> &kept = run.kept;
-    if (!dump && !verbose && gpus == 1 && !files.empty()) {
+    if (!dump && !verbose && !files.empty()) {
         uint64_t text_bytes = 0;
         bool plain = true;
         for (size_t fi = 0; fi < files.size(); ++fi)

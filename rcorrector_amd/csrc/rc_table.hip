@@ -106,11 +106,24 @@ __global__ void k_scatter(const uint32_t *__restrict__ home_sorted, const uint32
     }
 }
 
-// the absence filter of a PACKED table (rc_common.h: rc_table_view::filter): every entry sets its three bits
-__global__ void k_filter_set(const uint64_t *__restrict__ canon, size_t n, uint32_t nb_home, int k, int ext, uint32_t *__restrict__ filter, uint32_t words)
+// the absence filter of a PACKED table (rc_common.h: rc_table_view::filter): every entry sets its three bits -- kind 1: under
+// both of its orientations
+__global__ void k_filter_set(const uint64_t *__restrict__ canon, size_t n, uint32_t nb_home, int k, int ext, uint32_t *__restrict__ filter, uint32_t words,
+                             int kind)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (kind) {
+        const uint64_t x = canon[i], rv = rc_revcomp(x, k);
+        uint32_t w, m;
+        rc_filter_core_addr(x, words, &w, &m);
+        atomicOr(filter + w, m);
+        if (rv != x) {
+            rc_filter_core_addr(rv, words, &w, &m);
+            atomicOr(filter + w, m);
+        }
+        return;
+    }
     uint32_t h, rem, xrem, top;
     rc_packed_addr(canon[i], k, nb_home, ext, &h, &rem, &xrem, &top);
     atomicOr(filter + rc_mulhi32(top, words), rc_filter_mask(rem));
@@ -179,12 +192,14 @@ static int build_attempt(rc_ctx *ctx, const uint64_t *d_canon, const int32_t *d_
     // filter of 10 bits per entry behind the buckets (a tenth of their size, inside the TLB's reach up to ~2.5 G
     // entries) answers those without touching the buckets.  PACKED tables beyond 2.5 GiB only: below, a bucket read
     // costs what a filter word costs.  RC_TABLE_FILTER=force / off for tests and A/B runs.
+    // RC_TABLE_FILTER_KIND=plain|core: how a k-mer finds its word (rc_common.h: rc_table_view::filter_kind).
     ctx->filter_words = 0;
     {
-        const char *e = getenv("RC_TABLE_FILTER");
+        const char *e = getenv("RC_TABLE_FILTER"), *kd = getenv("RC_TABLE_FILTER_KIND");
         const bool force = e && !strcmp(e, "force"), off = e && !strcmp(e, "off");
+        ctx->filter_kind = kd ? (strcmp(kd, "plain") != 0 ? 1 : 0) : RC_FILTER_KIND_DEFAULT;
         if (layout && n > 0 && !off && (force || ctx->table_bytes > ((size_t)5 << 29))) {
-            uint64_t w = ((uint64_t)n * 10 + 31) / 32 + 64;
+            uint64_t w = ((uint64_t)n * (ctx->filter_kind ? 16 : 10) + 31) / 32 + 64;
             if (w < (1ull << 32)) ctx->filter_words = (uint32_t)w;
         }
     }
@@ -232,7 +247,7 @@ static int build_attempt(rc_ctx *ctx, const uint64_t *d_canon, const int32_t *d_
                            b_qm.as<long long>(), d_canon, d_counts, ctx->d_buckets, n, nb_home, layout, ctx->k, ext);
         if (ctx->filter_words)
             hipLaunchKernelGGL(k_filter_set, dim3(G), dim3(B), 0, ctx->stream, d_canon, n, nb_home, ctx->k, ext,
-                               ctx->d_buckets + ctx->table_bytes / 4, ctx->filter_words);
+                               ctx->d_buckets + ctx->table_bytes / 4, ctx->filter_words, ctx->filter_kind);
         RC_CHECK_HIP(ctx, hipGetLastError());
     }
     RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -332,7 +347,7 @@ __global__ void k_last_base_variants(rc_table_view T, const uint64_t *__restrict
     const uint64_t base = codes[i] & ~3ull;
     int mx = 0, second = 0;
     for (int c = 0; c < 4; ++c) {
-        int cnt = rc_table_lookup(T, rc_canonical(base | (uint64_t)c, k));
+        int cnt = rc_table_lookup_o(T, rc_canonical(base | (uint64_t)c, k), base | (uint64_t)c);  // (the four variants share a filter word)
         if (cnt > mx) {
             second = mx;
             mx = cnt;
@@ -366,7 +381,7 @@ __global__ __launch_bounds__(256) void k_error_rate_candidates(rc_table_view T, 
         code = codes[i];
         const uint64_t base = code & ~3ull;
         for (int c = 0; c < 4; ++c) {
-            int cnt = rc_table_lookup(T, rc_canonical(base | (uint64_t)c, k));
+            int cnt = rc_table_lookup_o(T, rc_canonical(base | (uint64_t)c, k), base | (uint64_t)c);  // (the four variants share a filter word)
             if (cnt > mx) {
                 second = mx;
                 mx = cnt;
@@ -1439,6 +1454,22 @@ int rc_count_finish(rc_ctx *ctx, int min_count, int64_t *n_kmers)
     if (rc != RC_OK) rc_kept_release(ctx);
     if (n_kmers) *n_kmers = (int64_t)total_kept;
     return rc;
+}
+
+// ends a counting session without counting: the arenas it was given become kept arenas (rc_submit_resident), no table is built
+int rc_count_park(rc_ctx *ctx)
+{
+    if (!ctx->cnt_active) {
+        rc_set_error(ctx, "count_park: call rc_table_count_begin first");
+        return RC_ERR_STATE;
+    }
+    ctx->cnt_active = false;
+    ctx->kept_arenas.swap(ctx->cnt_arenas);
+    ctx->kept_chunks.swap(ctx->cnt_chunks);
+    ctx->cnt_chunk_used = 0;
+    ctx->cnt_total = 0;
+    rc_count_release(ctx);
+    return RC_OK;
 }
 
 int rc_count_reads(rc_ctx *ctx, const uint8_t *d_seq, size_t nbytes, int min_count, int64_t *n_kmers)

@@ -65,7 +65,7 @@ struct HostWave {
         for (int i = lo; i < hi; ++i) m = a[i] < m ? a[i] : m;
         return m;
     }
-    int get(rc_kmer km)
+    int get(rc_kmer km, int /*dir*/ = 0)
     {
         ++gets;
         rco_kmer q;

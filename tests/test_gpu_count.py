@@ -227,6 +227,23 @@ def test_cli_fix_list_overflow_falls_back_to_the_byte_path(name, how, tmp_path, 
     gu.assert_same_as_reference(name, tmp_path, p.stderr)
 
 
+@pytest.mark.parametrize("gpus,inflight", [(2, 1), (3, 2), (8, 2)])
+@pytest.mark.parametrize("name", ["fx_pe_k23", "fx_se_k23", "fx_il_k23", "fx_k31_mc8"])
+def test_cli_without_c_on_several_gpus_reads_the_files_once(name, gpus, inflight, tmp_path, monkeypatch):
+    """`-gpus N` without -c in ONE pass: the batches are dealt round-robin as the files are read -- every arena goes to GPU 0,
+    which counts all of them, and to the GPU that will correct it, which only keeps it (rc_table_count_park) -- the table is
+    replicated, and each batch is corrected by the context that holds its bases (a worker only takes its own GPU's batches).
+    The reference's bytes (these fixtures' dumps are the exact counts of their reads).  RC_SHARED_GPU=1: every "GPU" is
+    device 0; batches of 40 reads, so every context gets several."""
+    monkeypatch.setenv("RC_SHARED_GPU", "1")
+    monkeypatch.setenv("RC_RESIDENT", "40")
+    args = open(os.path.join(gu.GOLDEN, name, "cmd.txt")).read().split()
+    i = args.index("-c")
+    del args[i:i + 2]
+    p = gu.run_fixture(CLI, name, tmp_path, args_override=args + ["-gpus", str(gpus), "-inflight", str(inflight)])
+    gu.assert_same_as_reference(name, tmp_path, p.stderr)
+
+
 def test_cli_without_c_several_inputs_of_every_kind_one_pass_equals_two(tmp_path):
     """-r FASTQ, -p FASTQ pair, -i interleaved, -r FASTA and a file with format quirks in ONE run without -c: the k-mers of
     all of them are counted into one table; the one-pass path (batches kept per file in input order, arenas numbered across

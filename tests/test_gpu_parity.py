@@ -572,6 +572,35 @@ def test_correct_batch_refuses_wrong_dtype(gpu_ctx_factory, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["plain", "core"])
+@pytest.mark.parametrize("k", [15, 23, 31, 32])
+def test_table_absence_filter_never_hides_an_entry(k, kind, monkeypatch):
+    """The absence filter of large PACKED tables (forced here): a lookup that fails the filter answers 0 without reading a
+    bucket, so the filter must hold every entry -- in both of its kinds (the word chosen by the mixed code, or by the first
+    k - 1 bases of either orientation: rc_common.h) -- whichever orientation the lookup is made in; absent keys stay absent."""
+    rng = np.random.Generator(np.random.PCG64(7 + k))
+    mask = np.uint64((1 << (2 * k)) - 1) if k < 32 else np.uint64(0xFFFFFFFFFFFFFFFF)
+    fwd = (rng.integers(0, 1 << 63, size=400000, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=400000, dtype=np.uint64)) & mask
+    can = np.unique(np.minimum(fwd, _revcomp_codes(fwd, k)))
+    counts = rng.integers(2, 60000, size=len(can)).astype(np.int32)
+    absent = (rng.integers(0, 1 << 63, size=100000, dtype=np.uint64) * np.uint64(2) + np.uint64(1)) & mask
+    absent = absent[~np.isin(np.minimum(absent, _revcomp_codes(absent, k)), can)]
+    res = {}
+    for filt in ("off", "force"):
+        monkeypatch.setenv("RC_TABLE_FILTER", filt)
+        monkeypatch.setenv("RC_TABLE_FILTER_KIND", kind)
+        ctx = rcorrector_amd.Context(k=k, device=0)
+        ctx.table_build(can, counts)
+        res[filt] = (ctx.table_layout(), ctx.lookup(can), ctx.lookup(_revcomp_codes(can, k)), ctx.lookup(absent), ctx.table_digest())
+        ctx.close()
+    if res["force"][0] == 1:   # (PACKED: the filter is there)
+        assert np.array_equal(res["force"][1], counts) and np.array_equal(res["force"][2], counts)
+        assert not res["force"][3].any()
+    for a, b in zip(res["off"], res["force"]):
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("k,n", [(11, 300000), (16, 300000), (17, 300000), (23, 300000), (25, 300000), (28, 300000),
                                  (31, 300000), (31, 17000000), (32, 300000)])
 def test_table_packed_and_wide_layouts_hold_the_same_table(k, n, monkeypatch):
@@ -1135,7 +1164,10 @@ def test_counts_in_the_tens_of_thousands_and_millions(oracle, name, scale):
 KNOBS = [{"RC_TABLE_LAYOUT": "wide"}, {"RC_TABLE_LOAD": "0.85"}, {"RC_TABLE_LOAD": "0.25"}, {"RC_LOCALITY": "force"},
          {"RC_NO_FUSE": "1", "RC_LOCALITY": "force"}, {"RC_K2_WAVE_PER_READ": "1"}, {"RC_NO_CLASSIFY": "1"},
          {"RC_NO_ALT": "1"}, {"RC_K3_GENERIC": "1"}, {"RC_K3_GENERIC": "1", "RC_NO_ALT": "1", "RC_LOCALITY": "force"},
-         {"RC_TABLE_FILTER": "force"}, {"RC_TABLE_FILTER": "force", "RC_LOCALITY": "force", "RC_TABLE_LOAD": "0.85"},
+         {"RC_TABLE_FILTER": "force", "RC_TABLE_FILTER_KIND": "plain"}, {"RC_TABLE_FILTER": "force", "RC_TABLE_FILTER_KIND": "core"},
+         {"RC_TABLE_FILTER": "force", "RC_TABLE_FILTER_KIND": "plain", "RC_LOCALITY": "force", "RC_TABLE_LOAD": "0.85"},
+         {"RC_TABLE_FILTER": "force", "RC_TABLE_FILTER_KIND": "core", "RC_LOCALITY": "force", "RC_TABLE_LOAD": "0.85"},
+         {"RC_TABLE_FILTER": "force", "RC_TABLE_FILTER_KIND": "core", "RC_K3_GENERIC": "1", "RC_NO_ALT": "1"},
          {"RC_NO_SINGLE": "1"}, {"RC_NO_SINGLE": "1", "RC_NO_ALT": "1"}, {"RC_NO_BS_EXT": "1"}, {"RC_NO_TIER": "1"},
          {"RC_NO_TIER": "1", "RC_LOCALITY": "force"}]
 
