@@ -220,7 +220,7 @@ int rc_launch_fix_list(rc_ctx *ctx, const uint32_t *d_packed, size_t nbytes, con
 // (cls value of a read = 1 + its section counted from the back; cls 0 = finished by the threshold kernel)
 #define RC_WORK_CLASSES 4
 #ifndef RC_FILTER_KIND_DEFAULT
-#define RC_FILTER_KIND_DEFAULT 0  // (1 once measured: RC_TABLE_FILTER_KIND=core)
+#define RC_FILTER_KIND_DEFAULT 1  // "core": config 4's k_correct 6.31 -> 5.61 s (RC_TABLE_FILTER_KIND=plain for the other)
 #endif
 // layout of rc_ctx::work (bytes): RC_WORK_CLASSES x RC_HEADS queue heads of k_correct, 128 B apart,
 // then the lengths of the work-list sections, then the phase counters of PROF builds

@@ -199,7 +199,9 @@ static int build_attempt(rc_ctx *ctx, const uint64_t *d_canon, const int32_t *d_
         const bool force = e && !strcmp(e, "force"), off = e && !strcmp(e, "off");
         ctx->filter_kind = kd ? (strcmp(kd, "plain") != 0 ? 1 : 0) : RC_FILTER_KIND_DEFAULT;
         if (layout && n > 0 && !off && (force || ctx->table_bytes > ((size_t)5 << 29))) {
-            uint64_t w = ((uint64_t)n * (ctx->filter_kind ? 16 : 10) + 31) / 32 + 64;
+            uint64_t bits = ctx->filter_kind ? 16 : 10;  // per entry
+            if (const char *fb = getenv("RC_TABLE_FILTER_BITS")) bits = (uint64_t)atoi(fb) >= 4 ? (uint64_t)atoi(fb) : bits;  // dev
+            uint64_t w = ((uint64_t)n * bits + 31) / 32 + 64;
             if (w < (1ull << 32)) ctx->filter_words = (uint32_t)w;
         }
     }
