@@ -43,12 +43,13 @@ for seed in range(lo, hi):
         args = io_quirks.make_case(seed, d, modes=(0, 1, 2)) if io_mode else F._random_case(seed, d, max_len=1024 if long_mode else 160)
         outs = {}
         verbose = ["-verbose"] if (io_mode or seed % 3 == 0) and not nodump else []
-        runs = (("gpu", F.CLI, ["-batch", "64"] if seed % 2 else [], args, None), ("cpu", pyoracle.CLI_BIN, ["-t", "2"], args, None))
+        gpu_flags = os.environ.get("RC_FUZZ_GPU_FLAGS", "").split()   # e.g. "-gpus 3 -inflight 2" (with RC_SHARED_GPU=1 on a one-GPU box)
+        runs = (("gpu", F.CLI, (["-batch", "64"] if seed % 2 else []) + gpu_flags, args, None), ("cpu", pyoracle.CLI_BIN, ["-t", "2"], args, None))
         if nodump:
             a = list(args)
             i = a.index("-c")
             del a[i:i + 2]
-            runs = (("gpu", F.CLI, ["-write-dump", os.path.join(d, "own.jf")], a, {"RC_RESIDENT": "10" if seed % 2 else "1"}),
+            runs = (("gpu", F.CLI, ["-write-dump", os.path.join(d, "own.jf")] + gpu_flags, a, {"RC_RESIDENT": "10" if seed % 2 else "1"}),
                     ("cpu", pyoracle.CLI_BIN, ["-t", "2", "-c", os.path.join(d, "own.jf")], a, None))
         for name, binary, more, argv, env in runs:
             od = os.path.join(d, name)
