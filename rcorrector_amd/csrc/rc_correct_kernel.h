@@ -501,7 +501,7 @@ struct rc_kernel_args {
     int fused_front_end;               // 1: k_correct computes the read's own threshold (single-end, no threshold kernel ran)
     int32_t *trace;                    // TRACE builds only: n x (2 + trace_cap * RC_TRACE_WORDS) words
     int trace_cap;
-    // Length tiers (rc_api.hip: correct_device_impl).  A batch whose reads do not all fit the fastest kernels is
+    // Length tiers (rc_api_batch.hip: rc_correct_device_impl).  A batch whose reads do not all fit the fastest kernels is
     // processed tier by tier; a unit (a read, or a pair: mates need each other's threshold) belongs to the tier
     // (tier_lo, tier_hi] that holds the length of its longer read, and a threshold kernel launched for one tier
     // leaves the reads of the others alone (cls = 0: not on this pass's work list).  RC_TIER_ALL: no tiers.

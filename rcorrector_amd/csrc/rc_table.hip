@@ -837,7 +837,7 @@ int rc_launch_locality_order(rc_ctx *ctx, const rc_device_batch_args &a, size_t 
     return RC_OK;
 }
 
-// Length tiers of a mixed-length batch (rc_api.hip: correct_device_impl): flag of list position i = 0 if the unit of the read
+// Length tiers of a mixed-length batch (rc_api_batch.hip: rc_correct_device_impl): flag of list position i = 0 if the unit of the read
 // there -- the read, or the pair it is a mate of -- belongs to the short tier (its longer read has at most s_hi bases), 1 for
 // the middle tier (at most m_hi), 2 for the long one.  Compacted, the positions of a tier give the reads of that tier in
 // locality order, mates still adjacent: what the list-driven probe and threshold kernels of the tier's pass walk.

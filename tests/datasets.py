@@ -26,7 +26,7 @@ CONFIGS = {
     "pe_160_k15": dict(k=15, mfk=4, rate=0.01, mode=1, kw=dict(seed=118, n=1200, length=160, e=0.006, paired=True, n_tx=60)),
 }
 
-# read lengths either side of every tier boundary of rc_api.hip (k = 23: S <= 160 < M <= 278 < L), mates drawn independently
+# read lengths either side of every tier boundary of rc_api_batch.hip (k = 23: S <= 160 < M <= 278 < L), mates drawn independently
 TIER_LENGTHS = [60, 100, 128, 150, 150, 150, 151, 151, 160, 161, 200, 250, 278, 279, 320, 321, 400]
 
 

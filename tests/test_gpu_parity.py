@@ -1004,7 +1004,7 @@ def test_default_dispatch_on_151_base_reads_and_on_a_mixed_length_batch(oracle, 
     alike, utils.h:7).  `len151`: 151-base pairs at k = 23 have 129 k-mers -- the nine-register instances of the fused probe
     + threshold kernel and of k_single.  `mixed`: 90 % 150-base, 9 % 151-base, 1 % 250-base reads, mates drawn
     independently: the short units stay on the fused kernel / k_single / the compiled-for-k k_correct, the units with a
-    250-base read take the list-driven probe kernel, the quarter-wave threshold kernel and k_correct<320> (rc_api.hip:
+    250-base read take the list-driven probe kernel, the quarter-wave threshold kernel and k_correct<320> (rc_api_batch.hip:
     length tiers).  400 k paired reads over a table beyond 128 MB, no knob; the first 10 000 pairs against the oracle."""
     import torch
     import bench as B

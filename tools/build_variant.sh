@@ -9,7 +9,7 @@ SRC=$REPO/rcorrector_amd/csrc
 OUT=$REPO/rcorrector_amd/variants
 mkdir -p "$OUT/obj_$NAME"
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -ffp-contract=off $*"
-for f in rc_api rc_table rc_transport rc_correct rc_correct_k23 rc_correct_k25 rc_correct_k31; do
+for f in rc_api rc_api_table rc_api_batch rc_api_packed rc_table rc_transport rc_correct rc_correct_k23 rc_correct_k25 rc_correct_k31; do
   hipcc $FLAGS -c "$SRC/$f.hip" -o "$OUT/obj_$NAME/$f.o" &
 done
 wait

@@ -8,7 +8,7 @@ REPO=$(cd "$(dirname "$0")/.." && pwd)
 SRC=$REPO/rcorrector_amd/csrc
 OUT=$REPO/rcorrector_amd/variants
 mkdir -p "$OUT"
-OBJS="rc_api rc_table rc_transport rc_correct rc_correct_k23 rc_correct_k25 rc_correct_k31"
+OBJS="rc_api rc_api_table rc_api_batch rc_api_packed rc_table rc_transport rc_correct rc_correct_k23 rc_correct_k25 rc_correct_k31"
 make -s -C "$SRC" $(for o in $OBJS; do echo $o.o; done) >/dev/null
 hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -ffp-contract=off "$@" -c "$SRC/$UNIT.hip" -o "$OUT/$NAME.$UNIT.o"
 LINK=""
