@@ -34,6 +34,9 @@ void rc_table_release(rc_ctx *ctx)
     if (ctx->d_buckets && !ctx->buckets_borrowed) (void)hipFree(reinterpret_cast<char *>(ctx->d_buckets) - RC_TABLE_PREFIX_BYTES);
     ctx->d_buckets = nullptr;
     ctx->buckets_borrowed = false;
+    if (ctx->counted_codes) (void)hipFree(ctx->counted_codes);
+    ctx->counted_codes = nullptr;
+    ctx->counted_n = 0;
     ctx->filter_words = 0;
     ctx->table_bytes = 0;
     ctx->n_entries = 0;
@@ -51,6 +54,7 @@ rc_table_view rc_view(const rc_ctx *ctx)
     v.filter_words = ctx->filter_words;
     v.filter = ctx->filter_words ? ctx->d_buckets + ctx->table_bytes / 4 : nullptr;
     v.filter_kind = ctx->filter_kind;
+    v.filter_all = ctx->filter_all;
     return v;
 }
 

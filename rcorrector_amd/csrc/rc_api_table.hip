@@ -307,6 +307,7 @@ int rc_table_share(rc_ctx *dst, const rc_ctx *src)
     dst->table_bytes = src->table_bytes;
     dst->filter_words = src->filter_words;
     dst->filter_kind = src->filter_kind;
+    dst->filter_all = src->filter_all;
     return RC_OK;
 }
 
@@ -396,6 +397,7 @@ int rc_table_replicate_async(rc_ctx *dst, const rc_ctx *src)
     dst->table_bytes = src->table_bytes;
     dst->filter_words = src->filter_words;
     dst->filter_kind = src->filter_kind;
+    dst->filter_all = src->filter_all;
     return RC_OK;
 }
 
@@ -653,7 +655,15 @@ int rc_estimate_error_rate(rc_ctx *c, double wk, double *rate_out)
         // rc_table_write_jfdump would write them -- what the reference would see if it were given that dump
         uint64_t *d_codes = nullptr;
         size_t n = 0;
-        int rc = rc_table_codes_device(ctx, &d_codes, &n);
+        int rc = RC_OK;
+        if (ctx->counted_codes && ctx->counted_n == (size_t)ctx->n_entries) {  // the table was counted here: its codes are still there
+            d_codes = (uint64_t *)ctx->counted_codes;
+            n = ctx->counted_n;
+            ctx->counted_codes = nullptr;
+            ctx->counted_n = 0;
+        } else {
+            rc = rc_table_codes_device(ctx, &d_codes, &n);
+        }
         if (rc) return rc;
         rc = rc_error_rate_candidates(ctx, d_codes, n, true, (size_t)rate_size, &vals);
         (void)hipFree(d_codes);

@@ -67,6 +67,11 @@ struct rc_table_view {
     // four, when the caller names the orientation in which the varying base comes last.  Any orientation gives the right
     // answer; 16 bits per entry instead of 10 (two insertions).
     int filter_kind;
+    // 1: every lookup goes through the filter (tables beyond the TLB's reach: a miss costs a page walk).  0: only the
+    // search's lookups do (rc_table_lookup_o<EXT, true>: k_correct) -- most of them are substitution candidates that do not
+    // exist, four to a word -- while the probe kernels, nine tenths of whose k-mers are in the table, go straight to the
+    // buckets (a filter word in front of every probe cost them 3 %).
+    int filter_all;
 };
 // bits of a key in its filter word (three of 32, from 15 bits of the remainder)
 RC_HD uint32_t rc_filter_mask(uint32_t rem)
@@ -361,7 +366,19 @@ inline void rc_bound_steps_build(double e, uint32_t *B)  // host only
     if (!(e >= 0.0) || !(top < 2147483648.0)) return;  // NaN / negative rates, or the (int) conversion overflows: no table
     for (int v = 2; v < RC_BOUND_STEPS; ++v) {
         if (rc_bound_i(2147483647, e) < v) break;  // never reached (and no larger v is)
-        long long lo = 0, hi = 2147483647;  // smallest c in [lo, hi] with bound_i(c) >= v
+        // smallest c with bound_i(c) >= v.  c E + 6 sqrt(c E) + 1 = v solved for c gives a first guess a step or two from it
+        // (sqrt(c E) = sqrt(8 + v) - 3); the walk to the exact step uses rc_bound_i itself, and a guess that is further off
+        // than 64 steps (E tiny or huge) is settled by bisection as before.  (65 534 bisections of 31 steps each were 25 ms of
+        // a two-second run, once per context.)
+        long long lo = 0, hi = 2147483647;
+        if (e > 0.0) {
+            const double r = __builtin_sqrt(8.0 + (double)v) - 3.0, g = r > 0.0 ? r * r / e : 0.0;
+            long long c = g >= 2147483647.0 ? 2147483647 : (long long)g;
+            int steps = 0;
+            while (steps < 64 && c > 0 && rc_bound_i((int)(c - 1), e) >= v) --c, ++steps;
+            while (steps < 64 && c < 2147483647 && rc_bound_i((int)c, e) < v) ++c, ++steps;
+            if (steps < 64 && rc_bound_i((int)c, e) >= v && (c == 0 || rc_bound_i((int)(c - 1), e) < v)) lo = hi = c;
+        }
         while (lo < hi) {
             const long long mid = (lo + hi) >> 1;
             if (rc_bound_i((int)mid, e) >= v)

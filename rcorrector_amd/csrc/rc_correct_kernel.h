@@ -197,7 +197,7 @@ struct DevWaveT {
         if (km.inv != -1) return 0;
         const uint64_t rv = rc_revcomp(km.code, KT ? KT : k);
         const uint64_t canon = rv < km.code ? rv : km.code;
-        const int c = rc_table_lookup_o(T, canon, dir > 0 ? km.code : (dir < 0 ? rv : canon), PROF ? &n_req : nullptr);
+        const int c = rc_table_lookup_o<true, true>(T, canon, dir > 0 ? km.code : (dir < 0 ? rv : canon), PROF ? &n_req : nullptr);
         if (PROF) {
             ++n_probe;
             n_absent += c == 0 ? 1u : 0u;

@@ -32,7 +32,7 @@ __device__ inline int rc_packed_overflow_count(const rc_table_view &T, uint64_t 
 // both ways: the masks become constants and the extra multiply of rc_packed_addr disappears)
 // orient: canon or its reverse complement -- the orientation in which the caller's neighbours differ in the LAST base (a
 // search node's four extensions), for the "core" filter of rc_common.h; callers without such neighbours pass canon
-template <bool EXT = true>
+template <bool EXT = true, bool SEARCH = false>
 __device__ __forceinline__ int rc_table_lookup_o(const rc_table_view &T, uint64_t canon, uint64_t orient, uint32_t *n_req = nullptr)
 {
     // The slots are compared as 64-bit words, from the last slot to the first, so that the first slot in
@@ -45,7 +45,7 @@ __device__ __forceinline__ int rc_table_lookup_o(const rc_table_view &T, uint64_
 #ifdef RC_EXP_ADDR_WINDOW  // dev (tools/exp/addr_window.md): every probe lands in the first RC_EXP_ADDR_WINDOW buckets -- WRONG counts; what
         b &= (RC_EXP_ADDR_WINDOW - 1);  // the probe kernel would cost if the table's lines were always in the L2 / Infinity Cache
 #endif
-        if (T.filter) {  // (wave-uniform) large tables: most misses end at one word of the filter
+        if (T.filter && (SEARCH || T.filter_all)) {  // (wave-uniform) most misses end at one word of the filter
             if (T.filter_kind) {
                 uint32_t fw, fm;
                 rc_filter_core_addr(orient, T.filter_words, &fw, &fm);

@@ -86,8 +86,14 @@ struct rc_ctx {
     uint32_t nb_alloc = 0;
     size_t n_entries = 0;   // accepted entries (duplicates included)
     size_t table_bytes = 0;
+    // the canonical codes of the entries a table was counted from (rc_count_finish), kept until the ERROR_RATE pass has used them
+    // or the table goes: that pass wants every entry's code, and reading them back out of the buckets (k_export: a decode and
+    // a probe walk per slot) costs more than the 8 bytes per entry it frees
+    void *counted_codes = nullptr;
+    size_t counted_n = 0;
     uint32_t filter_words = 0;  // absence filter behind the bucket array (rc_common.h: rc_table_view::filter), 0 = none
     int filter_kind = 0;        // rc_table_view::filter_kind of the filter that is there
+    int filter_all = 0;         // rc_table_view::filter_all
 
     // -verbose support: iterations recorded per read by k_correct (0 = off) and the record buffer
     int trace_cap = 0;

@@ -192,13 +192,21 @@ static int build_attempt(rc_ctx *ctx, const uint64_t *d_canon, const int32_t *d_
     // filter of 10 bits per entry behind the buckets (a tenth of their size, inside the TLB's reach up to ~2.5 G
     // entries) answers those without touching the buckets.  PACKED tables beyond 2.5 GiB only: below, a bucket read
     // costs what a filter word costs.  RC_TABLE_FILTER=force / off for tests and A/B runs.
-    // RC_TABLE_FILTER_KIND=plain|core: how a k-mer finds its word (rc_common.h: rc_table_view::filter_kind).
+    // RC_TABLE_FILTER_KIND=plain|core: how a k-mer finds its word (rc_common.h: rc_table_view::filter_kind); RC_TABLE_FILTER=search:
+    // the filter of a mid-size table (the search's lookups only) on a table of any size (tests).
     ctx->filter_words = 0;
     {
         const char *e = getenv("RC_TABLE_FILTER"), *kd = getenv("RC_TABLE_FILTER_KIND");
-        const bool force = e && !strcmp(e, "force"), off = e && !strcmp(e, "off");
+        const bool force = e && !strcmp(e, "force"), off = e && !strcmp(e, "off"), search = e && !strcmp(e, "search");
         ctx->filter_kind = kd ? (strcmp(kd, "plain") != 0 ? 1 : 0) : RC_FILTER_KIND_DEFAULT;
-        if (layout && n > 0 && !off && (force || ctx->table_bytes > ((size_t)5 << 29))) {
+        // beyond 2.5 GiB every lookup asks the filter.  RC_TABLE_FILTER=search (dev): a core filter that only the search's
+        // lookups ask, on a table of any size -- measured on the tables inside the TLB's reach and not taken: k_correct is
+        // bound by instruction issue there, and the filter's hash costs it more than the bucket reads it saves (config 2:
+        // 20.1 / 20.3 ms against 19.6 / 19.5; config 3: 53.1 / 51.8 against 51.3 / 49.4; profiles/r5_search_filter_ab.txt)
+        const bool big = ctx->table_bytes > ((size_t)5 << 29);
+        const bool mid = ctx->filter_kind == 1 && search;
+        ctx->filter_all = (force || big) ? 1 : 0;
+        if (layout && n > 0 && !off && (force || big || mid)) {
             uint64_t bits = ctx->filter_kind ? 16 : 10;  // per entry
             if (const char *fb = getenv("RC_TABLE_FILTER_BITS")) bits = (uint64_t)atoi(fb) >= 4 ? (uint64_t)atoi(fb) : bits;  // dev
             uint64_t w = ((uint64_t)n * bits + 31) / 32 + 64;
@@ -1454,6 +1462,11 @@ int rc_count_finish(rc_ctx *ctx, int min_count, int64_t *n_kmers)
         fprintf(stderr, "[rc count timing] finish %.3f s: histogram + %u passes %.3f (emit %.3f, sort %.3f, run lengths %.3f, select %.3f, hipMalloc %.3f), reads released %.3f, table build %.3f\n",
                 now() - t_begin, P, t_passes - t_begin, t_emit, t_sort, t_rle, t_sel, t_alloc, t_concat - t_passes, now() - t_concat);
     if (rc != RC_OK) rc_kept_release(ctx);
+    if (rc == RC_OK && total_kept) {  // (rc_estimate_error_rate takes them from here; rc_table_release frees them)
+        ctx->counted_codes = b_allk.p;
+        ctx->counted_n = total_kept;
+        b_allk.p = nullptr;
+    }
     if (n_kmers) *n_kmers = (int64_t)total_kept;
     return rc;
 }

@@ -1168,6 +1168,7 @@ KNOBS = [{"RC_TABLE_LAYOUT": "wide"}, {"RC_TABLE_LOAD": "0.85"}, {"RC_TABLE_LOAD
          {"RC_TABLE_FILTER": "force", "RC_TABLE_FILTER_KIND": "plain", "RC_LOCALITY": "force", "RC_TABLE_LOAD": "0.85"},
          {"RC_TABLE_FILTER": "force", "RC_TABLE_FILTER_KIND": "core", "RC_LOCALITY": "force", "RC_TABLE_LOAD": "0.85"},
          {"RC_TABLE_FILTER": "force", "RC_TABLE_FILTER_KIND": "core", "RC_K3_GENERIC": "1", "RC_NO_ALT": "1"},
+         {"RC_TABLE_FILTER": "search"}, {"RC_TABLE_FILTER": "search", "RC_K3_GENERIC": "1"}, {"RC_TABLE_FILTER": "search", "RC_TABLE_LOAD": "0.85", "RC_NO_SINGLE": "1"},
          {"RC_NO_SINGLE": "1"}, {"RC_NO_SINGLE": "1", "RC_NO_ALT": "1"}, {"RC_NO_BS_EXT": "1"}, {"RC_NO_TIER": "1"},
          {"RC_NO_TIER": "1", "RC_LOCALITY": "force"}]
 

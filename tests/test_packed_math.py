@@ -14,3 +14,14 @@ def test_packed_addressing_round_trips(tmp_path):
     p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
     out = p.stdout.decode()
     assert p.returncode == 0 and out.startswith("ok "), out
+
+
+def test_bound_steps_table_equals_bisection(tmp_path):
+    """rc_bound_steps_build (the integer steps of GetBound the kernels compare counts against) from its closed-form first guess
+    against plain bisection, 14 error rates including degenerate ones"""
+    exe = str(tmp_path / "bound_steps")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "rcorrector_amd", "csrc"),
+                    os.path.join(ROOT, "tests", "hostmath", "bound_steps.cpp"), "-o", exe], check=True)
+    p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    out = p.stdout.decode()
+    assert p.returncode == 0 and out.rstrip().endswith("ok") and " 0 differences" in out, out
