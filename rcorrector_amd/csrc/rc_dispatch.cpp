@@ -219,10 +219,7 @@ void warm_buffers(Run &R, const HeadStats &H)
         const size_t total = (size_t)sides * recs;
         if (resident) {  // what a resident batch sends and receives (page-locked)
             const size_t nb = (size_t)sides * arena_bytes;
-            j->pk_off.need((total + 1) * 4);
-            j->pk_qbits.need((nb + 7) / 8 + 64);
-            j->pk_fix_pos.need(fix_list_room(nb) * 4);
-            j->pk_fix_chr.need(fix_list_room(nb));
+            (void)j->pk_carve(total, nb, fix_list_room(nb));
         }
         j->ret.reserve(total);
         j->l.reserve(total);
@@ -340,11 +337,8 @@ static void worker_body(Run &R, int wk)
             Job &J = *j;
             const size_t bytes1 = J.a.off[n], bytes2 = J.mode == 1 ? J.b.off[n] : 0, nbytes = bytes1 + bytes2;
             const size_t cap = fix_list_room(nbytes);
-            J.pk_off.need((total + 1) * 4);
-            J.pk_qbits.need((nbytes + 7) / 8 + 64);
-            J.pk_fix_pos.need(cap * 4);
-            J.pk_fix_chr.need(cap);
-            uint32_t *off = (uint32_t *)J.pk_off.data();
+            const Job::PkView pk = J.pk_carve(total, nbytes, cap);
+            uint32_t *off = pk.off;
             memcpy(off, J.a.off.data(), (n + 1) * 4);
             if (J.mode == 1)
                 for (size_t r = 0; r <= n; ++r) off[n + r] = (uint32_t)bytes1 + J.b.off[r];
@@ -355,7 +349,7 @@ static void worker_body(Run &R, int wk)
                 std::vector<char> okv(Q, 1);
                 g_pool.run(Q, [&](size_t t) {
                     const size_t lo = (nbytes * t / Q) & ~(size_t)7, hi = t + 1 == Q ? nbytes : ((nbytes * (t + 1) / Q) & ~(size_t)7);
-                    if (lo < hi) okv[t] = pack_quality_bits_from_text(V, bad_q, lo, hi, (uint8_t *)J.pk_qbits.data()) ? 1 : 0;
+                    if (lo < hi) okv[t] = pack_quality_bits_from_text(V, bad_q, lo, hi, pk.qbits) ? 1 : 0;
                 });
                 for (char c : okv) bits_ok = bits_ok && c;
             }
@@ -370,13 +364,13 @@ static void worker_body(Run &R, int wk)
                 rb.arena_b = J.arena_b;
                 rb.bytes_b = bytes2;
                 rb.off = off;
-                rb.qual_bits = J.fastq ? (const uint8_t *)J.pk_qbits.data() : nullptr;
+                rb.qual_bits = J.fastq ? (const uint8_t *)pk.qbits : nullptr;
                 rb.ret = J.ret.data();
                 rb.l = J.l.data();
                 rb.m = J.m.data();
                 rb.h = J.h.data();
-                rb.fix_pos = (uint32_t *)J.pk_fix_pos.data();
-                rb.fix_chr = (uint8_t *)J.pk_fix_chr.data();
+                rb.fix_pos = pk.fix_pos;
+                rb.fix_chr = pk.fix_chr;
                 rb.fix_cap = cap;
                 {
                     std::lock_guard<std::mutex> lk(submit_mu[(size_t)g]);
@@ -453,12 +447,9 @@ static void worker_body(Run &R, int wk)
             Job &J = *j;
             const size_t bytes1 = J.a.off[n], bytes2 = J.mode == 1 ? J.b.off[n] : 0, nbytes = bytes1 + bytes2;
             const size_t n_words = (nbytes + 15) / 16, cap = fix_list_room(nbytes);
-            J.pk_off.need((total + 1) * 4);
+            const Job::PkView pk = J.pk_carve(total, nbytes, cap);
             J.pk_bases.need(n_words * 4 + 64);
-            J.pk_qbits.need((nbytes + 7) / 8 + 64);
-            J.pk_fix_pos.need(cap * 4);
-            J.pk_fix_chr.need(cap);
-            uint32_t *off = (uint32_t *)J.pk_off.data();
+            uint32_t *off = pk.off;
             memcpy(off, J.a.off.data(), (n + 1) * 4);
             if (J.mode == 1)
                 for (size_t r = 0; r <= n; ++r) off[n + r] = (uint32_t)bytes1 + J.b.off[r];
@@ -506,7 +497,7 @@ static void worker_body(Run &R, int wk)
             // quality bits (FASTQ) over the combined arena; byte-aligned pieces
             const bool fq = J.fastq;
             if (fq) {
-                uint8_t *qb = (uint8_t *)J.pk_qbits.data();
+                uint8_t *qb = pk.qbits;
                 const size_t Q = std::max<size_t>(1, std::min<size_t>((size_t)g_threads, nbytes / 65536 + 1));
                 // (arena 2's bits start at bit bytes1 of the same array: pack the two arenas' bytes through one view)
                 g_pool.run(Q, [&](size_t t) {
@@ -528,7 +519,7 @@ static void worker_body(Run &R, int wk)
             pb.nbytes = nbytes;
             pb.off = off;
             pb.bases = (const uint32_t *)J.pk_bases.data();
-            pb.qual_bits = fq ? (const uint8_t *)J.pk_qbits.data() : nullptr;
+            pb.qual_bits = fq ? (const uint8_t *)pk.qbits : nullptr;
             pb.exc_pos = n_exc ? (const uint32_t *)J.pk_exc_pos.data() : nullptr;
             pb.exc_chr = n_exc ? (const uint8_t *)J.pk_exc_chr.data() : nullptr;
             pb.n_exc = n_exc;
@@ -536,8 +527,8 @@ static void worker_body(Run &R, int wk)
             pb.l = J.l.data();
             pb.m = J.m.data();
             pb.h = J.h.data();
-            pb.fix_pos = (uint32_t *)J.pk_fix_pos.data();
-            pb.fix_chr = (uint8_t *)J.pk_fix_chr.data();
+            pb.fix_pos = pk.fix_pos;
+            pb.fix_chr = pk.fix_chr;
             pb.fix_cap = cap;
             {
                 std::lock_guard<std::mutex> lk(submit_mu[(size_t)g]);

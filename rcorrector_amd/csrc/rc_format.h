@@ -38,7 +38,24 @@ struct Job {
     int gpu = -1;                 // the GPU that holds them (-1: any GPU may take the batch)
     // -packed: the batch as rc_packed_batch wants it (one offset array over both arenas, 2-bit codes, quality bits, the
     // letters outside ACGT) and the room for the fix list
-    PinBuf pk_off, pk_bases, pk_qbits, pk_exc_pos, pk_exc_chr, pk_fix_pos, pk_fix_chr;
+    PinBuf pk_bases, pk_exc_pos, pk_exc_chr;
+    // offsets, quality bits and the room for the fix list: ONE page-locked allocation per job -- a registration costs
+    // milliseconds to make and to undo (at exit, too) whatever its size, and four of them per job were 0.1 s of a 1.5 s run
+    PinBuf pk_slab;
+    struct PkView {
+        uint32_t *off;
+        uint8_t *qbits;
+        uint32_t *fix_pos;
+        uint8_t *fix_chr;
+    };
+    PkView pk_carve(size_t total_reads, size_t nbytes, size_t fix_cap)
+    {
+        auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+        const size_t o_q = up((total_reads + 1) * 4), o_fp = o_q + up((nbytes + 7) / 8 + 64), o_fc = o_fp + up(fix_cap * 4), end = o_fc + up(fix_cap + 1);
+        pk_slab.need(end);
+        char *p = pk_slab.data();
+        return PkView{(uint32_t *)p, (uint8_t *)(p + o_q), (uint32_t *)(p + o_fp), (uint8_t *)(p + o_fc)};
+    }
     std::vector<OutBuf> o1, o2;  // the formatted (and, for .gz, deflated) output records, in slices
     uint64_t cor_bases = 0;  // sum of the positive return values (UpdateSummary, main.cpp:73-79), added up by the formatter
     bool done = false;

@@ -369,7 +369,24 @@ int main(int argc, char **argv)
         stamp("teardown: job buffers unregistered and freed");
         for (rc_ctx *c : ctx) rc_destroy(c);
         stamp("teardown: contexts destroyed");
-
+        if (atoi(getenv("RC_TEARDOWN")) >= 2) {  // ... and what is left once the helper threads, the heap and the HIP runtime are gone too
+            g_pool.stop_and_join();
+            stamp("teardown: helper threads joined");
+            malloc_trim(0);
+            stamp("teardown: heap trimmed");
+            if (void *h = dlopen("libamdhip64.so", RTLD_NOW | RTLD_NOLOAD)) {
+                typedef int (*reset_fn)();
+                if (reset_fn f = (reset_fn)dlsym(h, "hipDeviceReset")) f();
+                stamp("teardown: hipDeviceReset");
+            }
+            if (FILE *st = fopen("/proc/self/status", "r")) {
+                char ln[256];
+                while (fgets(ln, sizeof ln, st))
+                    if (!strncmp(ln, "VmRSS:", 6) || !strncmp(ln, "RssAnon:", 8) || !strncmp(ln, "RssFile:", 8) || !strncmp(ln, "RssShmem:", 9) || !strncmp(ln, "Threads:", 8) || !strncmp(ln, "VmPTE:", 6))
+                        fprintf(stderr, "[rc timing] at exit %s", ln);
+                fclose(st);
+            }
+        }
     }
     fflush(NULL);
     _exit(0);  // every output is closed: skip unmapping gigabytes of buffers one by one

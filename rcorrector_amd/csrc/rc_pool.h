@@ -105,6 +105,16 @@ struct Pool {
         std::unique_lock<std::mutex> lk(call.m);
         call.c.wait(lk, [&] { return call.left == 0; });
     }
+    void stop_and_join()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        cv.notify_all();
+        for (auto &x : th) x.join();
+        th.clear();
+    }
     ~Pool()
     {
         {
