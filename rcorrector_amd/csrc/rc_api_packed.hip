@@ -211,7 +211,10 @@ int rc_submit_packed(rc_ctx *c, rc_packed_batch *b, int slot)
     // results; the fix list follows in rc_wait_packed, once its length is known
     RC_CHECK_HIP(ctx, hipStreamWaitEvent(ctx->s_d2h, sl.e_k, 0));
     RC_CHECK_HIP(ctx, hipMemcpyAsync(sl.p_nfix.p, d_nfix, 4, hipMemcpyDeviceToHost, ctx->s_d2h));
-    if (sl.res_pinned) {
+    if (sl.res_pinned && b->l == b->ret + total && b->m == b->l + total && b->h == b->m + total) {
+        // (the caller's four arrays are one block, as the device's are: one copy instead of four)
+        RC_CHECK_HIP(ctx, hipMemcpyAsync(b->ret, d_res, total * 16, hipMemcpyDeviceToHost, ctx->s_d2h));
+    } else if (sl.res_pinned) {
         RC_CHECK_HIP(ctx, hipMemcpyAsync(b->ret, db.d_ret, total * 4, hipMemcpyDeviceToHost, ctx->s_d2h));
         RC_CHECK_HIP(ctx, hipMemcpyAsync(b->l, db.d_l, total * 4, hipMemcpyDeviceToHost, ctx->s_d2h));
         RC_CHECK_HIP(ctx, hipMemcpyAsync(b->m, db.d_m, total * 4, hipMemcpyDeviceToHost, ctx->s_d2h));
@@ -399,7 +402,10 @@ int rc_submit_resident(rc_ctx *c, rc_resident_batch *b, int slot)
     RC_CHECK_HIP(ctx, hipEventRecord(sl.e_k, ctx->stream));
     RC_CHECK_HIP(ctx, hipStreamWaitEvent(ctx->s_d2h, sl.e_k, 0));
     RC_CHECK_HIP(ctx, hipMemcpyAsync(sl.p_nfix.p, d_nfix, 4, hipMemcpyDeviceToHost, ctx->s_d2h));
-    if (sl.res_pinned) {
+    if (sl.res_pinned && b->l == b->ret + total && b->m == b->l + total && b->h == b->m + total) {
+        // (the caller's four arrays are one block, as the device's are: one copy instead of four)
+        RC_CHECK_HIP(ctx, hipMemcpyAsync(b->ret, d_res, total * 16, hipMemcpyDeviceToHost, ctx->s_d2h));
+    } else if (sl.res_pinned) {
         RC_CHECK_HIP(ctx, hipMemcpyAsync(b->ret, db.d_ret, total * 4, hipMemcpyDeviceToHost, ctx->s_d2h));
         RC_CHECK_HIP(ctx, hipMemcpyAsync(b->l, db.d_l, total * 4, hipMemcpyDeviceToHost, ctx->s_d2h));
         RC_CHECK_HIP(ctx, hipMemcpyAsync(b->m, db.d_m, total * 4, hipMemcpyDeviceToHost, ctx->s_d2h));
