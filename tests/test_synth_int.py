@@ -57,7 +57,7 @@ def test_gpu_bytes_equal_cpu_bytes():
 
 def test_committed_counter_passes_are_tied_to_the_kernel_sources(monkeypatch):
     """roofline.traffic / served_by and the k_correct counter figures are measured live by bench.py (rocprofv3 --pmc sub-runs);
-    where that cannot run, the committed summary (profiles/r4_traffic.json, written by the same code: tools/measure_r4.sh)
+    where that cannot run, the committed summary (profiles/r5_traffic.json, written by the same code: tools/measure_r5.sh)
     stands in -- it carries the git blob hashes of the kernel sources it measured: bench.py reports it only while the sources
     are the ones measured (a changed kernel nulls the figure with a note instead of leaving a stale one), and never for a
     workload that is no preset."""
@@ -66,7 +66,7 @@ def test_committed_counter_passes_are_tied_to_the_kernel_sources(monkeypatch):
     import types
     import bench
     monkeypatch.setenv("RC_BENCH_PMC", "committed")
-    doc = json.load(open(os.path.join(bench.ROOT, "profiles", "r4_traffic.json")))
+    doc = json.load(open(os.path.join(bench.ROOT, "profiles", "r5_traffic.json")))
     assert set(doc["sources"]) == set(bench.KERNEL_SOURCES)
     fresh = doc["sources"] == bench.source_hashes()
     assert doc["configs"]
