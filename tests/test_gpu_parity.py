@@ -817,6 +817,53 @@ def test_packed_boundary_slots_fasta_and_errors(gpu_ctx_factory, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["pe_k23", "se_k23", "k31_mc8"])
+def test_parked_arenas_are_corrected_with_a_table_from_another_context(gpu_ctx_factory, oracle, name):
+    """rc_table_count_park: a counting session ended WITHOUT counting leaves its arenas in HBM as kept arenas (no table is
+    built, a table that is there stays) -- what a GPU that corrects reads whose k-mers another GPU counts does (`rcorrector -gpus
+    N` without -c: one Store, T workers, main.cpp:294-308,451).  The table comes from a second context (rc_table_replicate); the
+    parked reads, corrected through rc_submit_resident, give the oracle's results; sequence errors are errors."""
+    d = datasets.make(name)
+    want = datasets.run_oracle(oracle, d)
+    owner = _table(gpu_ctx_factory, d)                      # "GPU 0": holds the table
+    ctx = gpu_ctx_factory(d["k"], d["mfk"])                  # the GPU that only keeps and corrects
+    with pytest.raises(rcorrector_amd.RcorrectorError, match="count_begin"):
+        ctx.count_park()
+    a1, off1 = oracle.pack_reads(d["seqs1"])
+    q1, _ = oracle.pack_reads(d["quals1"])
+    ctx.count_begin()
+    ctx.count_add(a1)
+    arena, qa, off = a1, q1, off1
+    if d["mode"] == 1:
+        a2, off2 = oracle.pack_reads(d["seqs2"])
+        q2, _ = oracle.pack_reads(d["quals2"])
+        ctx.count_add(a2)
+        off = np.concatenate([off1, (off2[1:].astype(np.int64) + a1.size).astype(np.uint32)])
+        arena, qa = np.concatenate([a1, a2]), np.concatenate([q1, q2])
+    ctx.count_park()
+    assert list(ctx.count_arenas()) == ([a1.size, a2.size] if d["mode"] == 1 else [a1.size])
+    ctx.replicate_table_of(owner)
+    assert ctx.table_digest() == owner.table_digest()
+    ctx.set_run_params(d["rate"], b"H")
+    qb = ctx.host_array((arena.size + 7) // 8)
+    ctx.pack_quality_bits(qa, b"H", out=qb)
+    args = dict(arena_a=0, begin_a=0, bytes_a=a1.size)
+    if d["mode"] == 1:
+        args.update(arena_b=1, begin_b=0, bytes_b=a2.size)
+    ctx.submit_resident(0, d["mode"], off, qb, **args)
+    ret, l, m, h, fix_pos, fix_chr = ctx.wait_resident(0)
+    for w, g, what in zip(want[:4], (ret, l, m, h), ["ret", "l", "m", "h"]):
+        assert np.array_equal(w, g), "%s differs on %s" % (what, name)
+    host = arena.copy()
+    ctx.apply_fixes(host, fix_pos, fix_chr)
+    assert np.array_equal(host, np.concatenate(want[4:]))
+    ctx.count_release()
+    assert len(ctx.count_arenas()) == 0
+    ctx.close()
+    owner.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", ["se_k23", "pe_k23", "il_k23", "pe_var", "nrich", "edge", "varlen", "k31_mc8", "tiers_pe", "long600_k31"])
 def test_resident_boundary_gives_the_oracles_results(gpu_ctx_factory, oracle, name):
     """rc_submit_resident / rc_wait_resident: the reads are the arenas the k-mer counter kept in HBM (rc_table_count_keep) --
