@@ -185,7 +185,17 @@ int rc_correct_batch(rc_ctx *ctx, rc_batch *b);
  * gets from filling the next batch while its worker threads correct the current one
  * (main.cpp:479-516).  rc_submit(slot) starts a batch and returns; the descriptor is copied, the
  * buffers it points to must stay valid and untouched until rc_wait(slot) returns, after which they
- * hold the results (and rc_summary() includes the batch).  Batches complete in submission order.
+ * hold the results (and rc_summary() includes the batch).  Slot 0 runs in the context itself; every other slot is a LANE with
+ * streams, events and scratch memory of its own (created at its first use; the table, the run parameters and the kept arenas
+ * are the context's, lent), so that the kernels of batches in different slots overlap on the GPU -- a batch's last waves, on
+ * its slowest reads, run under the next batch's probe kernel instead of in front of it (the reference's workers pick up the
+ * next read while another one is still searching: ErrorCorrection.cpp:87-90).  Batches in different slots may therefore
+ * complete in any order; rc_wait(slot) is what orders a caller.  RC_SLOT_LANES=0 in the environment keeps every slot in the
+ * one context (one compute stream: batches complete in submission order), and rc_set_slot_lanes() switches at run time (it
+ * applies to the batches submitted after it): lanes pay where a batch's slowest reads leave the GPU idle -- small batches, error-
+ * laden data: 1 M-read batches of 150-base pairs at 0.5 % errors 174 -> 223 M reads/s, at 5 % errors and k = 31 3.5 -> 9.2 M --
+ * and cost a few per cent where the caller is bound elsewhere and wants its batches back one at a time (`rcorrector` starts
+ * without them and turns them on when its writer starts waiting for the GPU).
  * Buffers obtained from rc_host_alloc() are page-locked: the DMA engines read and write them
  * directly; any other buffer is staged through pinned memory the slot owns (one extra copy each
  * way).  rc_correct_batch(b) == rc_submit(b, 0); rc_wait(0).  Calls on one context come from one
@@ -193,6 +203,7 @@ int rc_correct_batch(rc_ctx *ctx, rc_batch *b);
  * thread while the next rc_submit (a different slot) is issued -- how `rcorrector` keeps several
  * worker threads busy on one context. */
 #define RC_MAX_SLOTS 4
+int rc_set_slot_lanes(rc_ctx *ctx, int on);
 int rc_submit(rc_ctx *ctx, const rc_batch *b, int slot);
 int rc_wait(rc_ctx *ctx, int slot);
 int rc_host_alloc(rc_ctx *ctx, size_t bytes, void **out);

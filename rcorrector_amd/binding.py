@@ -16,7 +16,7 @@ ABI_SYMBOLS = [
     "rc_table_count_keep", "rc_table_count_arenas", "rc_table_count_release", "rc_table_count_park", "rc_submit_resident", "rc_wait_resident",
     "rc_table_count_reads_device", "rc_table_write_jfdump", "rc_table_share", "rc_table_replicate", "rc_table_replicate_async", "rc_table_lookup", "rc_table_export", "rc_table_digest", "rc_table_layout", "rc_table_stats",
     "rc_estimate_error_rate", "rc_bad_quality_from_hist", "rc_set_run_params", "rc_set_quality_bits", "rc_pack_quality_bits",
-    "rc_correct_batch", "rc_submit", "rc_wait", "rc_host_alloc", "rc_host_free", "rc_host_register", "rc_host_unregister", "rc_correct_batch_traced", "rc_correct_device", "rc_strong_threshold_device", "rc_probe_device", "rc_sync",
+    "rc_correct_batch", "rc_set_slot_lanes", "rc_submit", "rc_wait", "rc_host_alloc", "rc_host_free", "rc_host_register", "rc_host_unregister", "rc_correct_batch_traced", "rc_correct_device", "rc_strong_threshold_device", "rc_probe_device", "rc_sync",
     "rc_strong_threshold_read", "rc_correct_read", "rc_kmer_info_read",
     "rc_pack_bases", "rc_submit_packed", "rc_wait_packed", "rc_apply_fixes",
     "rc_profile_enable", "rc_profile_get", "rc_profile_reset", "rc_profile_correct_counters", "rc_profile_read_rounds", "rc_selftest_get_bound", "rc_summary",
@@ -115,6 +115,7 @@ def load_library():
     L.rc_table_count_arenas.argtypes = [vp, C.POINTER(C.c_size_t), vp, sz]
     L.rc_table_count_release.argtypes = [vp]
     L.rc_table_count_park.argtypes = [vp]
+    L.rc_set_slot_lanes.argtypes = [vp, C.c_int]
     L.rc_submit_resident.argtypes = [vp, C.POINTER(_ResidentBatch), C.c_int]
     L.rc_wait_resident.argtypes = [vp, C.c_int]
     L.rc_table_write_jfdump.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64)]
@@ -443,6 +444,10 @@ class Context:
         self._ck(self._L.rc_wait_packed(self._h, slot))
         b, res, fix_pos, fix_chr, _keep = self._inflight_packed.pop(slot)
         return tuple(res) + (fix_pos[:b.n_fix], fix_chr[:b.n_fix])
+
+    def set_slot_lanes(self, on=True):
+        """slots > 0 of the asynchronous entry points in contexts of their own (kernels of batches in flight overlap) or not"""
+        self._ck(self._L.rc_set_slot_lanes(self._h, 1 if on else 0))
 
     def device_memory(self):
         """(free, total) bytes of the context's GPU memory right now"""

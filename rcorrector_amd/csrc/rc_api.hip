@@ -74,8 +74,52 @@ void rc_timer_end(rc_ctx *ctx, int which)
     ctx->timers[which].launches += 1;
 }
 
+void rc_lane_error(rc_ctx *ctx, const rc_ctx *lane)
+{
+    if (ctx != lane) snprintf(ctx->err, sizeof ctx->err, "%s", lane->err);
+}
+
 extern "C" {
 
+rc_ctx *rc_slot_lane(rc_ctx *ctx, int slot, bool create, bool refresh)
+{
+    if (slot <= 0 || slot >= RC_MAX_SLOTS || ctx->is_lane) return ctx;
+    if (!create) return ctx->slot_home[slot] ? ctx->slot_home[slot] : ctx;  // a wait: where that slot's batch went
+    if (!ctx->env_slot_lanes) {
+        ctx->slot_home[slot] = ctx;
+        return ctx;
+    }
+    rc_ctx *&ln = ctx->lane[slot];
+    if (!ln) {
+        rc_config cfg = {ctx->device, ctx->k, ctx->P.max_fix_per_k};
+        char err[256];
+        ln = rc_create(&cfg, err, sizeof err);
+        if (!ln) {
+            rc_set_error(ctx, "slot %d: %s", slot, err);
+            return nullptr;
+        }
+        ln->is_lane = true;
+    }
+    if (refresh) {  // plain assignments: the table (borrowed, as rc_table_share lends it), the parameters, the mode, the kept arenas
+        ln->d_buckets = ctx->d_buckets;
+        ln->buckets_borrowed = true;
+        ln->nb_home = ctx->nb_home;
+        ln->layout = ctx->layout;
+        ln->ext = ctx->ext;
+        ln->nb_alloc = ctx->nb_alloc;
+        ln->n_entries = ctx->n_entries;
+        ln->table_bytes = ctx->table_bytes;
+        ln->filter_words = ctx->filter_words;
+        ln->filter_kind = ctx->filter_kind;
+        ln->filter_all = ctx->filter_all;
+        ln->P = ctx->P;
+        ln->params_set = ctx->params_set;
+        ln->qual_bits = ctx->qual_bits;
+        ln->kept_arenas = ctx->kept_arenas;  // (descriptors only: the chunks stay the parent's)
+    }
+    ctx->slot_home[slot] = ln;
+    return ln;
+}
 
 rc_ctx *rc_create(const rc_config *cfg, char *errbuf, size_t errbuf_len)
 {
@@ -84,6 +128,10 @@ rc_ctx *rc_create(const rc_config *cfg, char *errbuf, size_t errbuf_len)
         return nullptr;
     };
     if (!cfg) return fail("rc_create: null config");
+    // Slot lanes (rc_internal.h) want their streams on hardware queues of their own: the runtime multiplexes a process's
+    // streams onto GPU_MAX_HW_QUEUES queues (4 by default), and two compute streams that share one run one after the other --
+    // which is what made "two contexts" slower than one in round 4.  Only a process that has not initialised HIP yet takes it.
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);
     if (cfg->k < 1 || cfg->k > 32) return fail("rc_create: k must be in 1..32 (run_rcorrector.pl:225-228)");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -132,6 +180,7 @@ rc_ctx *rc_create(const rc_config *cfg, char *errbuf, size_t errbuf_len)
     ctx->env_no_alt = getenv("RC_NO_ALT") != nullptr;  // dev / tests: no alternative chains in the search's speculation rounds
     if (const char *e = getenv("RC_LOCALITY")) ctx->locality_mode = !strcmp(e, "force") ? 1 : (!strcmp(e, "off") ? -1 : 0);  // tests / A-B
     if (const char *e = getenv("RC_K3_GRID_WAVES")) ctx->env_k3_grid_waves = atoi(e);
+    if (const char *e = getenv("RC_SLOT_LANES")) ctx->env_slot_lanes = atoi(e) != 0;
     return ctx;
 }
 
@@ -139,6 +188,13 @@ void rc_destroy(rc_ctx *c)
 {
     if (!c) return;
     rc_ctx_full *ctx = static_cast<rc_ctx_full *>(c);
+    for (rc_ctx *&ln : ctx->lane) {  // (they borrow this context's table and arenas: they go first)
+        if (ln) {
+            ln->kept_arenas.clear();
+            rc_destroy(ln);
+        }
+        ln = nullptr;
+    }
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     rc_dbuf *bufs[] = {&ctx->counts, &ctx->strong, &ctx->info, &ctx->stack, &ctx->work,
@@ -175,6 +231,13 @@ void rc_destroy(rc_ctx *c)
 }
 
 const char *rc_last_error(const rc_ctx *ctx) { return ctx ? ctx->err : g_create_err; }
+
+int rc_set_slot_lanes(rc_ctx *ctx, int on)
+{
+    if (!ctx) return RC_ERR_ARG;
+    ctx->env_slot_lanes = on != 0;
+    return RC_OK;
+}
 
 int rc_device_numa_node(const rc_ctx *ctx)
 {
@@ -271,6 +334,14 @@ int rc_summary(const rc_ctx *c, uint64_t *total_reads, uint64_t *total_correctio
     RC_CHECK_HIP(ctx, hipSetDevice(ctx->device));
     RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     RC_CHECK_HIP(ctx, hipMemcpy(v, (char *)ctx->work.p + RC_WORK_SUMMARY_OFF, sizeof v, hipMemcpyDeviceToHost));
+    for (rc_ctx *ln : ctx->lane) {  // (the batches its slot lanes ran)
+        if (!ln) continue;
+        unsigned long long w[2] = {0, 0};
+        RC_CHECK_HIP(ctx, hipStreamSynchronize(ln->stream));
+        RC_CHECK_HIP(ctx, hipMemcpy(w, (char *)ln->work.p + RC_WORK_SUMMARY_OFF, sizeof w, hipMemcpyDeviceToHost));
+        v[0] += w[0];
+        v[1] += w[1];
+    }
     if (total_reads) *total_reads = v[0];
     if (total_corrections) *total_corrections = v[1];
     return RC_OK;

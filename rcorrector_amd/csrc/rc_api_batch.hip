@@ -294,6 +294,8 @@ int rc_sync(rc_ctx *ctx)
 {
     if (!ctx) return RC_ERR_ARG;
     RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (rc_ctx *ln : ctx->lane)
+        if (ln) RC_CHECK_HIP(ctx, hipStreamSynchronize(ln->stream));
     return RC_OK;
 }
 
@@ -495,6 +497,12 @@ int rc_slots_init(rc_ctx *ctx)
 int rc_submit(rc_ctx *c, const rc_batch *b, int slot)
 {
     if (!c || !b || slot < 0 || slot >= RC_MAX_SLOTS) return RC_ERR_ARG;
+    if (rc_ctx *ln = rc_slot_lane(c, slot, true, true); ln != c) {  // (slot lanes, rc_internal.h: this slot runs in a context of its own)
+        if (!ln) return RC_ERR_HIP;
+        const int lrc = rc_submit(ln, b, 0);
+        if (lrc) rc_lane_error(c, ln);
+        return lrc;
+    }
     rc_ctx_full *ctx = static_cast<rc_ctx_full *>(c);
     if (b->mode < 0 || b->mode > 2 || (b->n && (!b->seq || !b->qual || !b->off || !b->ret || !b->l || !b->m || !b->h)) ||
         (b->n && b->mode == 1 && (!b->seq2 || !b->qual2 || !b->off2))) {
@@ -639,6 +647,12 @@ int rc_submit(rc_ctx *c, const rc_batch *b, int slot)
 int rc_wait(rc_ctx *c, int slot)
 {
     if (!c || slot < 0 || slot >= RC_MAX_SLOTS) return RC_ERR_ARG;
+    if (rc_ctx *ln = rc_slot_lane(c, slot, false, false); ln != c) {  // (slot lanes, rc_internal.h: this slot runs in a context of its own)
+        if (!ln) return RC_ERR_HIP;
+        const int lrc = rc_wait(ln, 0);
+        if (lrc) rc_lane_error(c, ln);
+        return lrc;
+    }
     rc_ctx_full *ctx = static_cast<rc_ctx_full *>(c);
     if (!ctx->slots || !ctx->slots[slot].busy) {
         rc_set_error(ctx, "wait: slot %d holds no batch", slot);

@@ -65,4 +65,9 @@ int rc_correct_device_impl(rc_ctx *ctx, const rc_device_batch *b, uint32_t qual_
 int rc_hbuf_reserve(rc_ctx *ctx, rc_hbuf *h, size_t bytes);
 bool rc_is_pinned(const void *p, size_t bytes);
 int rc_slots_init(rc_ctx *ctx);
+// the context slot `slot` runs in: ctx itself (slot 0, a lane, or RC_SLOT_LANES=0), else its lane -- created if `create`, and
+// brought up to date with ctx's table / parameters / kept arenas if `refresh` (submits); nullptr + error text on failure
+rc_ctx *rc_slot_lane(rc_ctx *ctx, int slot, bool create, bool refresh);
+// the lane's error text and summary counters seen through the parent
+void rc_lane_error(rc_ctx *ctx, const rc_ctx *lane);
 }

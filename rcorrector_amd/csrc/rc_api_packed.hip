@@ -53,6 +53,12 @@ void rc_apply_fixes(char *seq, const uint32_t *fix_pos, const uint8_t *fix_chr, 
 int rc_submit_packed(rc_ctx *c, rc_packed_batch *b, int slot)
 {
     if (!c || !b || slot < 0 || slot >= RC_MAX_SLOTS) return RC_ERR_ARG;
+    if (rc_ctx *ln = rc_slot_lane(c, slot, true, true); ln != c) {  // (slot lanes, rc_internal.h: this slot runs in a context of its own)
+        if (!ln) return RC_ERR_HIP;
+        const int lrc = rc_submit_packed(ln, b, 0);
+        if (lrc) rc_lane_error(c, ln);
+        return lrc;
+    }
     rc_ctx_full *ctx = static_cast<rc_ctx_full *>(c);
     if (b->mode < 0 || b->mode > 2 || (b->n && (!b->off || !b->bases || !b->ret || !b->l || !b->m || !b->h)) ||
         (b->n_exc && (!b->exc_pos || !b->exc_chr)) || (b->fix_cap && (!b->fix_pos || !b->fix_chr))) {
@@ -231,6 +237,12 @@ int rc_submit_packed(rc_ctx *c, rc_packed_batch *b, int slot)
 int rc_wait_packed(rc_ctx *c, int slot)
 {
     if (!c || slot < 0 || slot >= RC_MAX_SLOTS) return RC_ERR_ARG;
+    if (rc_ctx *ln = rc_slot_lane(c, slot, false, false); ln != c) {  // (slot lanes, rc_internal.h: this slot runs in a context of its own)
+        if (!ln) return RC_ERR_HIP;
+        const int lrc = rc_wait_packed(ln, 0);
+        if (lrc) rc_lane_error(c, ln);
+        return lrc;
+    }
     rc_ctx_full *ctx = static_cast<rc_ctx_full *>(c);
     if (!ctx->slots || !ctx->slots[slot].busy || !ctx->slots[slot].pb) {
         rc_set_error(ctx, "wait_packed: slot %d holds no packed batch", slot);
@@ -270,6 +282,12 @@ int rc_wait_packed(rc_ctx *c, int slot)
 int rc_submit_resident(rc_ctx *c, rc_resident_batch *b, int slot)
 {
     if (!c || !b || slot < 0 || slot >= RC_MAX_SLOTS) return RC_ERR_ARG;
+    if (rc_ctx *ln = rc_slot_lane(c, slot, true, true); ln != c) {  // (slot lanes, rc_internal.h: this slot runs in a context of its own)
+        if (!ln) return RC_ERR_HIP;
+        const int lrc = rc_submit_resident(ln, b, 0);
+        if (lrc) rc_lane_error(c, ln);
+        return lrc;
+    }
     rc_ctx_full *ctx = static_cast<rc_ctx_full *>(c);
     if (b->mode < 0 || b->mode > 2 || (b->n && (!b->off || !b->ret || !b->l || !b->m || !b->h)) || (b->fix_cap && (!b->fix_pos || !b->fix_chr))) {
         rc_set_error(ctx, "submit_resident: bad batch descriptor");
@@ -422,6 +440,12 @@ int rc_submit_resident(rc_ctx *c, rc_resident_batch *b, int slot)
 int rc_wait_resident(rc_ctx *c, int slot)
 {
     if (!c || slot < 0 || slot >= RC_MAX_SLOTS) return RC_ERR_ARG;
+    if (rc_ctx *ln = rc_slot_lane(c, slot, false, false); ln != c) {  // (slot lanes, rc_internal.h: this slot runs in a context of its own)
+        if (!ln) return RC_ERR_HIP;
+        const int lrc = rc_wait_resident(ln, 0);
+        if (lrc) rc_lane_error(c, ln);
+        return lrc;
+    }
     rc_ctx_full *ctx = static_cast<rc_ctx_full *>(c);
     if (!ctx->slots || !ctx->slots[slot].busy || !ctx->slots[slot].rb) {
         rc_set_error(ctx, "wait_resident: slot %d holds no resident batch", slot);

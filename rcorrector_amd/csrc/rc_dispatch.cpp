@@ -314,12 +314,16 @@ static void worker_body(Run &R, int wk)
                     if ((*it)->gpu < 0 || (*it)->gpu == g) return it;
                 return q.end();
             };
-            cv.wait(lk, [&] { return closing || mine() != q.end(); });
+            cv.wait(lk, [&] { return closing || (slot < R.lane_limit && R.active[(size_t)g] < R.lane_limit && mine() != q.end()); });
             g_w_worker += now_s() - tw;
             auto it = mine();
-            if (it == q.end()) return;
+            if (it == q.end() || slot >= R.lane_limit || R.active[(size_t)g] >= R.lane_limit) {
+                if (closing) return;
+                continue;
+            }
             j = *it;
             q.erase(it);
+            ++R.active[(size_t)g];
         }
         const double tp0 = now_s();
         const size_t n = j->a.n();
@@ -574,6 +578,7 @@ static void worker_body(Run &R, int wk)
             j->rc = rc;
             if (rc) j->err = rc_last_error(ctx[g]);
             j->done = true;
+            --R.active[(size_t)g];
         }
         cv.notify_all();
     }
@@ -589,13 +594,16 @@ static void writer_body(Run &R)
     const bool &reader_done = R.reader_done;
     uint64_t &total_reads = R.total_reads, &total_cor = R.total_cor;
     const int k = R.k;
+    double waited = 0;
+    int starved = 0;
 for (;;) {
     std::shared_ptr<Job> j;
     {
         std::unique_lock<std::mutex> lk(mu);
         const double tw = now_s();
         cv.wait(lk, [&] { return (!order.empty() && order.front()->done) || (reader_done && order.empty()); });
-        g_w_writer += now_s() - tw;
+        waited = now_s() - tw;
+        g_w_writer += waited;
         if (order.empty()) return;
         j = order.front();
     }
@@ -633,7 +641,25 @@ for (;;) {
         if (!(g_verbose && g_stdout)) emit_slices(f, j->o1);
         if (j->mode == 1 && !alternate) emit_slices(g2, j->o2);
     }
-    g_t_write += now_s() - tw0;
+    const double wrote = now_s() - tw0;
+    g_t_write += wrote;
+    if (R.adaptive) {  // (see Run::lane_limit) the writer waited for this batch longer than it then took to write it: three in a row
+        starved = waited > wrote ? starved + 1 : 0;
+        if (starved >= 3) {
+            starved = 0;
+            std::lock_guard<std::mutex> lk(mu);
+            if (R.lane_limit < R.inflight) {
+                ++R.lane_limit;
+                if (!getenv("RC_SLOT_LANES"))
+                    for (size_t g = 0; g < R.ctx.size(); ++g) {  // (between two submits of that GPU)
+                        std::lock_guard<std::mutex> sk(R.submit_mu[g]);
+                        rc_set_slot_lanes(R.ctx[g], 1);
+                    }
+                if (g_timing) fprintf(stderr, "[rc timing] the writer waits for the GPU: %d batches in flight per GPU from now on\n", R.lane_limit);
+            }
+            cv.notify_all();
+        }
+    }
     total_reads += j->ret.size();  // UpdateSummary, main.cpp:73-79
     total_cor += j->cor_bases;
     bool retire = false;
@@ -672,8 +698,10 @@ void run_pipeline(Run &R)
     bool &closing = R.closing, &reader_done = R.reader_done;
     std::vector<std::unique_ptr<Retained>> &kept = R.kept;
     const bool resident = R.resident;
-    const size_t batch_reads = R.batch_reads, max_in_flight = R.max_in_flight;
+    const size_t batch_reads = R.batch_reads;
     pool = R.warm_jobs;
+    R.active.assign((size_t)R.gpus, 0);
+    auto in_flight_cap = [&R]() { return (size_t)(R.gpus * R.lane_limit + 2); };  // (called under mu)
     std::vector<std::thread> workers;
     for (int wk = 0; wk < R.nworkers; ++wk) workers.emplace_back([&R, wk]() { worker_body(R, wk); });
     std::thread writer([&R]() { writer_body(R); });
@@ -685,7 +713,7 @@ void run_pipeline(Run &R)
             {
                 std::unique_lock<std::mutex> lk(mu);
                 const double tw = now_s();
-                cv.wait(lk, [&] { return order.size() < max_in_flight; });
+                cv.wait(lk, [&] { return order.size() < in_flight_cap(); });
                 g_w_reader += now_s() - tw;
                 if (!pool.empty()) {
                     j = pool.back();
@@ -760,7 +788,7 @@ void run_pipeline(Run &R)
                 {
                     std::unique_lock<std::mutex> lk(mu);
                     const double tw = now_s();
-                    cv.wait(lk, [&] { return order.size() < max_in_flight; });
+                    cv.wait(lk, [&] { return order.size() < in_flight_cap(); });
                     g_w_reader += now_s() - tw;
                     order.push_back(j);
                     q.push_back(j);

@@ -72,6 +72,14 @@ struct rc_ctx {
     rc_run_params P;
     bool params_set = false;
     bool qual_bits = false;  // quality arenas are bit arrays (rc_set_quality_bits)
+    // Slot lanes: slot s > 0 of the asynchronous entry points runs in a context of its own (lane[s], created at its first use:
+    // own streams, events and scratch; the table, the run parameters and the kept arenas are this context's, lent), so that
+    // the kernels of batches in different slots overlap on the GPU -- a batch's last waves on its slowest reads under the
+    // next batch's probe kernel.  RC_SLOT_LANES=0: every slot in this context, one compute stream (round 4's behaviour).
+    rc_ctx *lane[4] = {nullptr, nullptr, nullptr, nullptr};
+    rc_ctx *slot_home[4] = {nullptr, nullptr, nullptr, nullptr};  // where the batch a slot holds was submitted (lanes can be switched)
+    bool is_lane = false;
+    bool env_slot_lanes = true;
 
     // k-mer table in HBM
     uint32_t *d_buckets = nullptr;

@@ -51,7 +51,7 @@ static void print_help()
             "\twithout -c the k-mers are counted here (exact counts >= 2); ERROR_RATE is then estimated over this program's own\n"
             "\t\tdump order, not Jellyfish's: self-consistent, not byte-comparable with a jellyfish + reference run on large inputs\n"
             "\t-batch INT: reads per GPU batch (default: 1048576)\n"
-            "\t-inflight INT: batches in flight per GPU, 1-4 (default: 2)\n"
+            "\t-inflight INT: batches in flight per GPU, 1-4 (default: 2, raised to 4 while the writer waits for the GPU)\n"
             "\t-write-dump STRING: also write the k-mer table as a jellyfish-dump text file\n"
             "\t-verbose-iter INT: threshold iterations recorded per read for -verbose (default: 64)\n");
 }
@@ -60,6 +60,7 @@ int main(int argc, char **argv)
 {
     Run run;
     int &k = run.k, &gpus = run.gpus, &inflight = run.inflight;
+    bool inflight_given = false;
     size_t &batch_reads = run.batch_reads;
     std::vector<ReadFile> &files = run.files, &mates = run.mates;
     int max_fix_per_k = 4, i;
@@ -107,8 +108,10 @@ int main(int argc, char **argv)
             gpus = atoi(argv[++i]);
         else if (!strcmp("-batch", argv[i]))
             batch_reads = (size_t)atol(argv[++i]);
-        else if (!strcmp("-inflight", argv[i]))
+        else if (!strcmp("-inflight", argv[i])) {
             inflight = atoi(argv[++i]);
+            inflight_given = true;
+        }
         else if (!strcmp("-write-dump", argv[i]))
             write_dump = argv[++i];
         else if (!strcmp("-packed", argv[i]))
@@ -174,6 +177,11 @@ int main(int argc, char **argv)
     // one context per GPU (the table is replicated across GPUs); `inflight` worker threads per GPU keep
     // that many batches in flight in it through rc_submit / rc_wait, one slot each
     if (inflight > RC_MAX_SLOTS) inflight = RC_MAX_SLOTS;
+    run.lane_limit = inflight;
+    if (!inflight_given && !verbose) {  // (Run::lane_limit) two at work, up to four where the GPU is what the writer waits for
+        run.adaptive = true;
+        inflight = RC_MAX_SLOTS;
+    }
     const int nctx = gpus, nworkers = run.nworkers = gpus * inflight;
     run.submit_mu.reset(new std::mutex[(size_t)gpus]);
     std::vector<rc_ctx *> &ctx = run.ctx;
@@ -186,6 +194,10 @@ int main(int argc, char **argv)
         rc_config cfg = {shared_gpu ? 0 : c, k, max_fix_per_k};
         ctx[c] = rc_create(&cfg, err, sizeof err);
         if (!ctx[c]) die("rcorrector: %s\n", err);
+        // slot lanes (rcorrector_amd.h: rc_submit): off while the run is bound by its writer, which wants its batches back one
+        // after the other (two batches side by side on the GPU each take twice as long: 25 M x 150 bp pairs, loop 0.60 against
+        // 0.52 s); on from the moment the writer waits for the GPU (rc_dispatch: Run::lane_limit).  RC_SLOT_LANES decides if set.
+        if (!getenv("RC_SLOT_LANES")) rc_set_slot_lanes(ctx[c], run.adaptive ? 0 : 1);
     }
     // One GPU: the whole host pipeline -- reader, packers, formatters, writers and their buffers -- lives on the NUMA
     // node that GPU hangs off (every byte of a read crosses host memory a dozen times on its way through; across the
@@ -206,7 +218,7 @@ int main(int argc, char **argv)
     // While the table loads: the batch buffers of the pipeline -- text blocks, page-locked arenas, output slices --
     // are allocated, sized from the head of the first input, touched and registered with the GPU runtime here, so
     // that the first batches do not pay for a few GB of page faults and hipHostRegister calls one after the other
-    run.max_in_flight = (size_t)(nworkers + 2);
+    run.max_in_flight = (size_t)(gpus * run.lane_limit + 2);
     // One pass (see ingest_resident): no dump, any number of GPUs (the batches are dealt to them as they are read), regular files (plain or .gz: one inflate pass instead of two) whose text
     // fits a third of the host memory that is available and whose bases, count scratch and table fit the HBM that is free.  RC_RESIDENT=0 keeps the two passes, =1 skips the size test.
     bool &resident = run.resident;

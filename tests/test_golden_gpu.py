@@ -30,10 +30,13 @@ def test_cli_packed_transport_reproduces_reference_outputs(name, extra, tmp_path
     gu.assert_same_as_reference(name, tmp_path, p.stderr)
 
 
+@pytest.mark.parametrize("lanes", ["1", "0"])
 @pytest.mark.parametrize("name", ["fx_se_k23", "fx_pe_k23", "fx_il_k23", "fx_edge"])
-def test_cli_small_batches_and_thread_flag(name, tmp_path):
-    # output must not depend on the batch size (the reference's is 512*T, main.cpp:441)
-    p = gu.run_fixture(CLI, name, tmp_path, extra=["-batch", "50", "-t", "8"])
+def test_cli_small_batches_and_thread_flag(name, lanes, tmp_path, monkeypatch):
+    # output must not depend on the batch size (the reference's is 512*T, main.cpp:441), nor on whether the batches in flight
+    # run in slot lanes (a context per slot, kernels of consecutive batches side by side) or one after the other in one context
+    monkeypatch.setenv("RC_SLOT_LANES", lanes)
+    p = gu.run_fixture(CLI, name, tmp_path, extra=["-batch", "50", "-t", "8", "-inflight", "3"])
     gu.assert_same_as_reference(name, tmp_path, p.stderr)
 
 

@@ -817,6 +817,41 @@ def test_packed_boundary_slots_fasta_and_errors(gpu_ctx_factory, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("lanes", [True, False])
+def test_slot_lanes_run_batches_side_by_side_with_the_same_results(gpu_ctx_factory, oracle, lanes):
+    """Slots > 0 of the asynchronous entry points are lanes -- contexts of their own that borrow the table, the parameters and
+    the kept arenas -- so batches in flight overlap on the GPU and may finish in any order; rc_set_slot_lanes(0) keeps every
+    slot in the one context.  Four packed batches in four slots, waited for in reverse order, and a switch between a submit
+    and its wait: every batch gives the oracle's results either way, and rc_summary counts them all."""
+    d = datasets.make("pe_var")
+    ctx = _table(gpu_ctx_factory, d)
+    ctx.set_slot_lanes(lanes)
+    n1 = len(d["seqs1"])
+    parts = []
+    for j in range(4):
+        lo, hi = j * n1 // 4, (j + 1) * n1 // 4
+        sub = dict(d, seqs1=d["seqs1"][lo:hi], quals1=d["quals1"][lo:hi], seqs2=d["seqs2"][lo:hi], quals2=d["quals2"][lo:hi])
+        parts.append((sub, _packed_inputs(ctx, oracle, sub)))
+    for rnd in range(2):
+        for j, (sub, (arena, off, bases, exc_pos, exc_chr, qb)) in enumerate(parts):
+            ctx.submit_packed(j, 1, arena.size, off, bases, qb, exc_pos, exc_chr)
+        if rnd == 1:
+            ctx.set_slot_lanes(not lanes)   # the batches in flight are waited for where they were submitted
+        for j in (3, 2, 1, 0):
+            sub, (arena, off, bases, exc_pos, exc_chr, qb) = parts[j]
+            ret, l, m, h, fix_pos, fix_chr = ctx.wait_packed(j)
+            want = datasets.run_oracle(oracle, sub)
+            a = arena.copy()
+            ctx.apply_fixes(a, fix_pos, fix_chr)
+            assert np.array_equal(ret, want[0]) and np.array_equal(l, want[1]) and np.array_equal(m, want[2]) and np.array_equal(h, want[3])
+            assert np.array_equal(a, np.concatenate(want[4:]))
+    reads, bases_fixed = ctx.summary()
+    want_all = datasets.run_oracle(oracle, d)
+    assert reads == 2 * 2 * n1 and bases_fixed == 2 * int(want_all[0][want_all[0] > 0].sum())
+    ctx.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", ["pe_k23", "se_k23", "k31_mc8"])
 def test_parked_arenas_are_corrected_with_a_table_from_another_context(gpu_ctx_factory, oracle, name):
     """rc_table_count_park: a counting session ended WITHOUT counting leaves its arenas in HBM as kept arenas (no table is

@@ -38,21 +38,27 @@ def write_fq(path, S, Q, L):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reads", type=int, default=25_000_000)
-    ap.add_argument("--len", type=int, default=150)
-    ap.add_argument("-k", type=int, default=23)
+    ap.add_argument("--preset", type=int, default=2, help="bench.py preset whose reads are written (its k, maxcorK, error rate, pairing)")
     ap.add_argument("--dir", default="/tmp/rc_e2e_var")
     ap.add_argument("--repeat", type=int, default=2)
     ap.add_argument("variants", nargs="*", default=["default||"])
     a = ap.parse_args()
     os.makedirs(a.dir, exist_ok=True)
-    L, n = a.len, a.reads
+    import bench
+    P = bench.PRESETS[a.preset]
+    L, n, paired = P["len"], a.reads, P["paired"]
     dev = torch.device("cuda", 0)
-    gen = synth_int.Synth(1002, L, 30000, 1500, 0.8, 0.005, True, device=dev)
-    seq, qual = gen.generate(0, n // 2)
+    gen = synth_int.Synth(P["seed"], L, 30000, 1500, P["alpha"], P["err"], paired, bias3=P["bias3"], device=dev)
+    seq, qual = gen.generate(0, n // 2 if paired else n)
     S = seq.view(n, L + 1)[:, :L].cpu().numpy()
     Q = qual.view(n, L + 1)[:, :L].cpu().numpy()
-    write_fq(os.path.join(a.dir, "x_1.fq"), S[:n // 2], Q[:n // 2], L)
-    write_fq(os.path.join(a.dir, "x_2.fq"), S[n // 2:], Q[n // 2:], L)
+    if paired:
+        write_fq(os.path.join(a.dir, "x_1.fq"), S[:n // 2], Q[:n // 2], L)
+        write_fq(os.path.join(a.dir, "x_2.fq"), S[n // 2:], Q[n // 2:], L)
+        inputs, first_out = ["-p", "x_1.fq", "x_2.fq"], "x_1.cor.fq"
+    else:
+        write_fq(os.path.join(a.dir, "x.fq"), S, Q, L)
+        inputs, first_out = ["-r", "x.fq"], "x.cor.fq"
     del seq, qual, S, Q, gen
     torch.cuda.empty_cache()
     cli = os.path.join(ROOT, "rcorrector_amd", "rcorrector")
@@ -69,7 +75,7 @@ def main():
             os.sync()
             t0 = time.time()
             env["RC_T0"] = repr(t0)
-            p = subprocess.run([cli, "-p", "x_1.fq", "x_2.fq", "-k", str(a.k), "-od", out] + flags.split(), cwd=a.dir, env=env,
+            p = subprocess.run([env.get("RC_CLI_BIN", cli)] + inputs + ["-k", str(P["k"]), "-maxcorK", str(P["maxcork"]), "-od", out] + flags.split(), cwd=a.dir, env=env,
                                stderr=subprocess.PIPE, stdout=subprocess.DEVNULL)
             wall = time.time() - t0
             err = p.stderr.decode()
@@ -77,7 +83,7 @@ def main():
             other = [ln for ln in err.splitlines() if ln.startswith("[rc") and not ln.startswith("[rc timing] +")]
             h = hashlib.md5()
             try:
-                with open(os.path.join(out, "x_1.cor.fq"), "rb") as f:
+                with open(os.path.join(out, first_out), "rb") as f:
                     for blk in iter(lambda: f.read(1 << 24), b""):
                         h.update(blk)
                 md5s.add(h.hexdigest())
