@@ -568,7 +568,7 @@ int rc_launch_correct(rc_ctx *ctx, const rc_device_batch_args &a)
     A.stack = (rc_frame *)ctx->stack.p;
     // queue heads and phase counters to zero; the work-list length (written by the compaction) stays
     RC_CHECK_HIP(ctx, hipMemsetAsync(ctx->work.p, 0, RC_WORK_NWORK_OFF, ctx->stream));
-    RC_CHECK_HIP(ctx, hipMemsetAsync((char *)ctx->work.p + RC_WORK_PHASE_OFF, 0, 192, ctx->stream));
+    RC_CHECK_HIP(ctx, hipMemsetAsync((char *)ctx->work.p + RC_WORK_PHASE_OFF, 0, 34 * 8, ctx->stream));
     RC_CHECK_HIP(ctx, hipMemsetAsync((char *)ctx->work.p + RC_WORK_PHASE_OFF + 64, 0xff, 16, ctx->stream));  // the two minima
     A.phase_cycles = (unsigned long long *)((char *)ctx->work.p + RC_WORK_PHASE_OFF);
     if (ctx->cls_ready) {
@@ -603,7 +603,7 @@ int rc_launch_correct(rc_ctx *ctx, const rc_device_batch_args &a)
         hipLaunchKernelGGL((k_correct<1024, false, false>), dim3(grid), dim3(64), 0, ctx->stream, A);
     rc_timer_end(ctx, RC_T_CORRECT);
     if (ctx->phase_prof) {
-        unsigned long long pc[24];
+        unsigned long long pc[34];
         uint32_t nwork = a.n, nsec[RC_WORK_CLASSES] = {0};
         RC_CHECK_HIP(ctx, hipMemcpyAsync(pc, A.phase_cycles, sizeof pc, hipMemcpyDeviceToHost, ctx->stream));
         if (A.n_work) RC_CHECK_HIP(ctx, hipMemcpyAsync(nsec, A.n_work, sizeof nsec, hipMemcpyDeviceToHost, ctx->stream));
@@ -632,6 +632,10 @@ int rc_launch_correct(rc_ctx *ctx, const rc_device_batch_args &a)
         fprintf(stderr, "[rc phase prof] inside the search, cycles/read:");
         for (int i = 0; i < 7; ++i) fprintf(stderr, " %s=%.0f", sn[i], (double)pc[16 + i] / a.n);
         fprintf(stderr, "\n");
+        const double R = (double)(pc[11] ? pc[11] : 1), KR = (double)(pc[24] ? pc[24] : 1);
+        fprintf(stderr, "[rc phase prof] a gather round: %.1f probes, %.1f %% with alternative chains (%.2f walked per round, %.0f %% of them to the end); a keep-run (%.2f per round) keeps %.2f of the %.2f cached nodes it is offered; gap-window rounds %.3f per round (%.1f probes)\n",
+                (double)pc[32] / R, 100.0 * (double)pc[33] / R, (double)pc[30] / R, 100.0 * (double)pc[31] / (double)(pc[30] ? pc[30] : 1), KR / R, (double)pc[25] / KR,
+                (double)pc[26] / KR, (double)pc[28] / R, (double)pc[29] / (double)(pc[28] ? pc[28] : 1));
         }
     }
     RC_CHECK_HIP(ctx, hipGetLastError());

@@ -127,7 +127,9 @@ struct rc_read_state {
     int len, kcnt;
 };
 
-#define RC_SPEC 16           // nodes of chain 0
+#ifndef RC_SPEC
+#define RC_SPEC 16           // nodes of chain 0 (tools/exp/spec_depth.py: what other depths cost in probes and rounds)
+#endif
 #define RC_SPEC_ENTRIES 128  // probes per gather round: two per lane
 #define RC_MEMO_MAX 32
 
@@ -525,6 +527,8 @@ RC_HD int rc_probe4_cached(W &w, rc_read_state &S, rc_spec_state &Z, const rc_ru
     }
     w.sync();
     const int n4 = 4 * n, E = n4 + 3 * am;
+    w.stat(8, E);
+    w.stat(9, am > 0 ? 1 : 0);
     // entry e: chain 0, node e / 4, extension e % 4 -- or alternative (e - n4) / am, its node (e - n4) % am,
     // whose k-mer is the read's own k-mer there with base z replaced
     auto entry = [&](int e, bool *live) -> rc_kmer {

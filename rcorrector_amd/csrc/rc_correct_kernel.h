@@ -34,9 +34,14 @@ struct DevWaveT {
 #else
     int rounds = 0, rounds_max = 0;  // PROF builds: gather rounds of the current read / of the wave's worst read
     long long rounds_sum = 0;
+    // PROF builds: what the search's speculation bought (rc_correct_core.h: w.stat): [0] keep-runs, [1] nodes they kept, [2] cached
+    // nodes they were offered, [4] gap-window rounds, [5] their probes, [6] alternative chains walked, [7] of them to the end,
+    // [8] probes of the gather rounds, [9] rounds with alternative chains
+    long long stv[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     __device__ __forceinline__ void stat(int i, int v)
     {
         if (PROF && i == 3) rounds += v;
+        if (PROF && i != 3 && i < 10) stv[i] += v;
     }
 #endif
     // trace record of the current read: [0] flags (bit 0: passed the screens, i.e. "Before
@@ -755,6 +760,8 @@ __global__ __launch_bounds__(64, rc_k3_waves(CAP)) void k_correct(rc_kernel_args
 #ifndef RC_EXP_ROUNDS
         atomicAdd(A.phase_cycles + 11, (unsigned long long)w.rounds_sum);
         atomicMax(A.phase_cycles + 12, (unsigned long long)w.rounds_max);
+        for (int i = 0; i < 10; ++i)
+            if (i != 3) atomicAdd(A.phase_cycles + 24 + i, (unsigned long long)w.stv[i]);
 #endif
     }
     if (PROF) {

@@ -15,18 +15,13 @@ static size_t fix_list_room(size_t nbytes)
     return e ? (size_t)atoll(e) : nbytes / 16 + 64;
 }
 
-void ingest_resident(Run &R_, size_t batch_reads, int64_t *stored, bool keep)
+// the reader of the one-pass ingest: host memory only (text blocks and their line index), so that it can run while the GPU
+// runtime is still starting up
+void Ingest::start()
 {
-    rc_ctx *ctx = R_.ctx[0];
-    std::vector<ReadFile> &files = R_.files, &mates = R_.mates;
-    std::vector<std::unique_ptr<Retained>> &kept = R_.kept;
-    std::mutex mu;
-    std::condition_variable cv;
-    std::deque<std::unique_ptr<Retained>> q;
-    std::vector<std::unique_ptr<Retained>> spare;  // keep = false: blocks to fill again
-    bool done = false;
-    std::thread reader([&]() {
-        for (size_t fi = 0; fi < files.size(); ++fi) {
+    reader = std::thread([this]() {
+        std::vector<ReadFile> &files = R.files, &mates = R.mates;
+        for (size_t fi = 0; fi < files.size() && !stop; ++fi) {
             ReadFile &f = files[fi];
             Source own_a, own_b;
             if (!keep) {
@@ -34,39 +29,39 @@ void ingest_resident(Run &R_, size_t batch_reads, int64_t *stored, bool keep)
                 if (f.paired) own_b.open(mates[fi].path);
             }
             Source &src_a = keep ? f.src : own_a, &src_b = keep ? mates[fi].src : own_b;
-            for (;;) {
-                std::unique_ptr<Retained> R;
+            while (!stop) {
+                std::unique_ptr<Retained> B;
                 {
                     std::lock_guard<std::mutex> lk(mu);
                     if (!spare.empty()) {
-                        R = std::move(spare.back());
+                        B = std::move(spare.back());
                         spare.pop_back();
                     }
                 }
-                if (!R) R.reset(new Retained);
-                R->file = (int)fi;
-                R->mode = f.paired ? 1 : (f.interleaved ? 2 : 0);
-                R->fastq = f.fastq;
-                R->lpr_a = f.fastq ? 4 : 2;
-                R->lpr_b = f.paired ? (mates[fi].fastq ? 4 : 2) : R->lpr_a;
+                if (!B) B.reset(new Retained);
+                B->file = (int)fi;
+                B->mode = f.paired ? 1 : (f.interleaved ? 2 : 0);
+                B->fastq = f.fastq;
+                B->lpr_a = f.fastq ? 4 : 2;
+                B->lpr_b = f.paired ? (mates[fi].fastq ? 4 : 2) : B->lpr_a;
                 const double tr0 = now_s();
-                R->b.records = 0;
+                B->b.records = 0;
                 if (f.paired) {
-                    std::thread mate([&]() { take_records(src_b, batch_reads, R->lpr_b, R->b); });
-                    take_records(src_a, batch_reads, R->lpr_a, R->a);
+                    std::thread mate([&]() { take_records(src_b, batch_reads, B->lpr_b, B->b); });
+                    take_records(src_a, batch_reads, B->lpr_a, B->a);
                     mate.join();
                     // (two passes: files that are not paired are the correction loop's to refuse, with the reference's message
                     // in the reference's place on stderr; the counter takes whatever reads there are)
-                    if (keep && R->b.records != R->a.records) die("ERROR: The files are not paired!\n");
+                    if (keep && B->b.records != B->a.records) die("ERROR: The files are not paired!\n");
                 } else {
-                    take_records(src_a, batch_reads, R->lpr_a, R->a);
+                    take_records(src_a, batch_reads, B->lpr_a, B->a);
                 }
-                if (R->a.records == 0 && R->b.records == 0) break;
-                if (keep && R->mode == 2 && (R->a.records & 1)) die("ERROR: interleaved file %s holds an odd number of reads\n", f.path.c_str());
+                if (B->a.records == 0 && B->b.records == 0) break;
+                if (keep && B->mode == 2 && (B->a.records & 1)) die("ERROR: interleaved file %s holds an odd number of reads\n", f.path.c_str());
                 g_t_read += now_s() - tr0;
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return q.size() < 3; });
-                q.emplace_back(std::move(R));
+                cv.wait(lk, [&] { return stop || q.size() < depth; });
+                q.emplace_back(std::move(B));
                 cv.notify_all();
             }
             if (!keep) {
@@ -78,6 +73,31 @@ void ingest_resident(Run &R_, size_t batch_reads, int64_t *stored, bool keep)
         done = true;
         cv.notify_all();
     });
+}
+
+// a reader that ran ahead of a decision that then went the other way (Ingest::depth blocks at most): its blocks are dropped; the
+// caller rewinds the sources
+void Ingest::abort()
+{
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        stop = true;
+    }
+    cv.notify_all();
+    reader.join();
+    q.clear();
+}
+
+void Ingest::consume(int64_t *stored)
+{
+    Run &R_ = R;
+    rc_ctx *ctx = R_.ctx[0];
+    std::vector<ReadFile> &files = R_.files, &mates = R_.mates;
+    std::vector<std::unique_ptr<Retained>> &kept = R_.kept;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        depth = 3;  // (a reader that ran ahead may hold more)
+    }
     if (rc_table_count_keep(ctx, keep ? 1 : 0) || rc_table_count_begin(ctx)) die("rcorrector: %s\n", rc_last_error(ctx));
     // Several GPUs, one pass: the batches are dealt round-robin.  Every arena goes to GPU 0, which counts all of them (one
     // Store for all workers, main.cpp:294-308), and -- once more -- to the GPU that will correct it, which only keeps it
@@ -135,6 +155,13 @@ void ingest_resident(Run &R_, size_t batch_reads, int64_t *stored, bool keep)
         if (rc_table_count_park(R_.ctx[(size_t)g])) die("rcorrector: %s\n", rc_last_error(R_.ctx[(size_t)g]));
     if (rc_table_count_finish(ctx, 2, stored)) die("rcorrector: %s\n", rc_last_error(ctx));
     stamp("k-mers counted, table built");
+}
+
+void ingest_resident(Run &R, size_t batch_reads, int64_t *stored, bool keep)
+{
+    Ingest I(R, batch_reads, keep);
+    I.start();
+    I.consume(stored);
 }
 
 HeadStats head_stats(const Run &R)
@@ -677,13 +704,9 @@ for (;;) {
             pool.push_back(j);
     }
     cv.notify_all();
-    if (retire) {
-        Job *raw = new Job;  // (the job's buffers move to an object of the helper thread's own)
-        raw->a.blk.swap(j->a.blk);
-        raw->b.blk.swap(j->b.blk);
-        raw->o1.swap(j->o1);
-        raw->o2.swap(j->o2);
-        std::thread([raw]() { delete raw; }).detach();
+    if (retire) {  // (the last reference, as a rule: text, line index, page-locked slab, result arrays and output slices go with it)
+        std::shared_ptr<Job> *last = new std::shared_ptr<Job>(std::move(j));
+        std::thread([last]() { delete last; }).detach();
     }
 }
 }
@@ -699,7 +722,8 @@ void run_pipeline(Run &R)
     std::vector<std::unique_ptr<Retained>> &kept = R.kept;
     const bool resident = R.resident;
     const size_t batch_reads = R.batch_reads;
-    pool = R.warm_jobs;
+    pool.swap(R.warm_jobs);  // (the pool holds the only reference to a job at rest: see the writer's retirement)
+    R.warm_jobs.clear();
     R.active.assign((size_t)R.gpus, 0);
     auto in_flight_cap = [&R]() { return (size_t)(R.gpus * R.lane_limit + 2); };  // (called under mu)
     std::vector<std::thread> workers;
@@ -800,6 +824,11 @@ void run_pipeline(Run &R)
     {
         std::lock_guard<std::mutex> lk(mu);
         reader_done = true;
+        if (!pool.empty()) {  // jobs at rest are not needed again either
+            auto *idle = new std::vector<std::shared_ptr<Job>>();
+            idle->swap(pool);
+            std::thread([idle]() { delete idle; }).detach();
+        }
     }
     cv.notify_all();
     writer.join();

@@ -4,6 +4,7 @@
 //   batching     main.cpp:439-523           batches never span files; mates travel together
 //   one Store, T workers                    main.cpp:294-308,451,479-483
 #pragma once
+#include <atomic>
 #include <memory>
 
 #include "rc_writer.h"
@@ -59,6 +60,26 @@ struct Run {
 // reader -- both mates' files side by side, parallel block reads, page-locked staging -- over sources of its own; the blocks
 // are recycled instead of kept, and the counter releases the arenas when it has counted them.
 void ingest_resident(Run &R, size_t batch_reads, int64_t *stored, bool keep);
+// The same in two steps: the reader -- files into text blocks of host memory, `depth` of them ahead of the consumer -- needs no
+// GPU, and `rcorrector` starts it before the contexts exist (HIP takes 0.08-0.25 s to come up, a tenth of a run on 25 M
+// reads); consume() is the rest (index, upload, count, table).  abort(): the run will not be a one-pass run after all.
+struct Ingest {
+    Run &R;
+    size_t batch_reads;
+    bool keep;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::unique_ptr<Retained>> q;
+    std::vector<std::unique_ptr<Retained>> spare;  // keep = false: blocks to fill again
+    bool done = false;
+    std::atomic<bool> stop{false};
+    size_t depth = 3;
+    std::thread reader;
+    Ingest(Run &run, size_t batch, bool keep_) : R(run), batch_reads(batch), keep(keep_) {}
+    void start();
+    void consume(int64_t *stored);
+    void abort();
+};
 
 // the batch buffers of the pipeline -- text blocks, page-locked arenas, output slices -- allocated, sized from the head of
 // the first input, touched and registered with the GPU runtime (runs on a thread of its own while the table loads)

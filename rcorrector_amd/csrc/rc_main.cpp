@@ -186,51 +186,50 @@ int main(int argc, char **argv)
     run.submit_mu.reset(new std::mutex[(size_t)gpus]);
     std::vector<rc_ctx *> &ctx = run.ctx;
     ctx.assign((size_t)nctx, nullptr);
-    char err[512];
     // RC_SHARED_GPU=1 (tests): every "GPU" is device 0, so that the -gpus N path -- one table replica
     // per GPU, batches dealt to whichever context is free -- runs on a one-GPU box
     const bool shared_gpu = run.shared_gpu = getenv("RC_SHARED_GPU") != nullptr;
-    for (int c = 0; c < nctx; ++c) {
-        rc_config cfg = {shared_gpu ? 0 : c, k, max_fix_per_k};
-        ctx[c] = rc_create(&cfg, err, sizeof err);
-        if (!ctx[c]) die("rcorrector: %s\n", err);
-        // slot lanes (rcorrector_amd.h: rc_submit): off while the run is bound by its writer, which wants its batches back one
-        // after the other (two batches side by side on the GPU each take twice as long: 25 M x 150 bp pairs, loop 0.60 against
-        // 0.52 s); on from the moment the writer waits for the GPU (rc_dispatch: Run::lane_limit).  RC_SLOT_LANES decides if set.
-        if (!getenv("RC_SLOT_LANES")) rc_set_slot_lanes(ctx[c], run.adaptive ? 0 : 1);
-    }
-    // One GPU: the whole host pipeline -- reader, packers, formatters, writers and their buffers -- lives on the NUMA
-    // node that GPU hangs off (every byte of a read crosses host memory a dozen times on its way through; across the
-    // socket link each crossing costs more).  Several GPUs: each GPU's worker threads bind themselves (below).
     const bool numa_on = run.numa_on = !(getenv("RC_NUMA") && !strcmp(getenv("RC_NUMA"), "0"));
-    if (numa_on && gpus == 1) {
-        const int node = rc_device_numa_node(ctx[0]);
-        if (node >= 0 && bind_to_numa_node(node) && g_timing) fprintf(stderr, "[rc timing] host threads bound to NUMA node %d\n", node);
-    }
+    const bool lanes_env = getenv("RC_SLOT_LANES") != nullptr;
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);  // (rc_create would: here no other thread reads the environment yet)
+    // The GPU runtime takes 0.08-0.25 s to come up (tools/mb/hipinit.hip): the contexts are created on a thread of their own,
+    // and what needs no GPU goes ahead -- the test whether this is a one-pass run, as far as the host can say, and its reader.
+    std::string ctx_err;
+    std::thread ctx_thread([&]() {
+        char err[512];
+        for (int c = 0; c < nctx; ++c) {
+            rc_config cfg = {shared_gpu ? 0 : c, k, max_fix_per_k};
+            ctx[c] = rc_create(&cfg, err, sizeof err);
+            if (!ctx[c]) {
+                ctx_err = err;
+                return;
+            }
+            // slot lanes (rcorrector_amd.h: rc_submit): off while the run is bound by its writer, which wants its batches back one
+            // after the other (two batches side by side on the GPU each take twice as long: 25 M x 150 bp pairs, loop 0.60 against
+            // 0.52 s); on from the moment the writer waits for the GPU (rc_dispatch: Run::lane_limit).  RC_SLOT_LANES decides if set.
+            if (!lanes_env) rc_set_slot_lanes(ctx[c], run.adaptive ? 0 : 1);
+        }
+    });
     for (size_t fi = 0; fi < files.size(); ++fi)
         if ((files[fi].out_gz || (files[fi].paired && mates[fi].out_gz)) && !g_stdout) {
             const unsigned hc = std::thread::hardware_concurrency();
             g_deflate_threads = t_flag > 1 ? (size_t)t_flag : std::min<size_t>(hc ? hc / 2 : 8, 96);
         }
-    g_pool.start(std::max<size_t>((size_t)g_threads * 2, g_deflate_threads));  // (the reader, the mate's reader and the workers call it side by side)
-    stamp("contexts created (HIP initialised, scratch allocated)");
-    const double t_start = now_s();
-    // While the table loads: the batch buffers of the pipeline -- text blocks, page-locked arenas, output slices --
-    // are allocated, sized from the head of the first input, touched and registered with the GPU runtime here, so
-    // that the first batches do not pay for a few GB of page faults and hipHostRegister calls one after the other
-    run.max_in_flight = (size_t)(gpus * run.lane_limit + 2);
     // One pass (see ingest_resident): no dump, any number of GPUs (the batches are dealt to them as they are read), regular files (plain or .gz: one inflate pass instead of two) whose text
     // fits a third of the host memory that is available and whose bases, count scratch and table fit the HBM that is free.  RC_RESIDENT=0 keeps the two passes, =1 skips the size test.
     bool &resident = run.resident;
     std::vector<std::unique_ptr<Retained>> &kept = run.kept;
-    if (!dump && !verbose && !files.empty()) {
-        uint64_t text_bytes = 0;
-        bool plain = true;
+    const bool one_pass_shape = !dump && !verbose && !files.empty();
+    uint64_t text_bytes = 0;
+    bool plain = true, any_gz = false, host_fits = false;
+    const char *res_env = getenv("RC_RESIDENT");
+    if (one_pass_shape) {
         for (size_t fi = 0; fi < files.size(); ++fi)
             for (const ReadFile *f : {(const ReadFile *)&files[fi], files[fi].paired ? (const ReadFile *)&mates[fi] : (const ReadFile *)nullptr}) {
                 if (!f) continue;
                 struct stat st;
                 if (f->src.is_gz) {  // (its text is taken as eight times the file: FASTQ deflates to a fifth or a quarter)
+                    any_gz = true;
                     if (stat(f->path.c_str(), &st) != 0 || !S_ISREG(st.st_mode)) {
                         plain = false;
                         continue;
@@ -257,20 +256,78 @@ int main(int argc, char **argv)
                 if (fgets(ln, sizeof ln, cg) && ln[0] >= '0' && ln[0] <= '9') avail = std::min<uint64_t>(avail, strtoull(ln, nullptr, 10));
                 fclose(cg);
             }
-        const char *e = getenv("RC_RESIDENT");
+        host_fits = plain && (res_env ? atoi(res_env) != 0 : text_bytes <= avail / 3);
+        if (res_env && atoi(res_env) > 1) batch_reads = std::max<size_t>(2, (size_t)atoi(res_env)) & ~(size_t)1;  // (tests: RC_RESIDENT=<batch size>)
+    }
+    uint64_t count_mem = (uint64_t)24 << 30;
+    if (const char *cm = getenv("RC_COUNT_MEM_MB")) count_mem = (uint64_t)atoll(cm) << 20;
+    // The reader goes ahead where the answer is all but certain -- plain files (a .gz source cannot be rewound, and how it is
+    // inflated depends on the answer), a text that leaves most of an MI355X's HBM free -- and where its buffers land on the right
+    // NUMA node: one GPU means the host side is bound to that GPU's node, which sysfs can tell before HIP can.
+    int node_guess = -2;
+    bool ahead = host_fits && !any_gz && text_bytes + count_mem + ((uint64_t)1 << 30) <= ((uint64_t)160 << 30) && !getenv("RC_NO_READ_AHEAD");
+    if (ahead && numa_on && gpus == 1) {
+        node_guess = first_gpu_numa_node();
+        if (node_guess == -2) ahead = false;
+    }
+    bool pool_started = false;
+    HeadStats head;
+    std::unique_ptr<Ingest> ingest;
+    if (ahead) {
+        if (numa_on && gpus == 1 && node_guess >= 0 && bind_to_numa_node(node_guess) && g_timing)
+            fprintf(stderr, "[rc timing] host threads bound to NUMA node %d (the first GPU's, by sysfs)\n", node_guess);
+        g_pool.start(std::max<size_t>((size_t)g_threads * 2, g_deflate_threads));
+        pool_started = true;
+        if (g_timing) fprintf(stderr, "[rc timing] the reader starts before the GPU runtime is up\n");
+        head = head_stats(run);  // (before the reader takes the head of the first file out of its source)
+        ingest.reset(new Ingest(run, batch_reads, true));
+        ingest->depth = 8;
+        ingest->start();
+    }
+    ctx_thread.join();
+    if (!ctx_err.empty()) die("rcorrector: %s\n", ctx_err.c_str());
+    // One GPU: the whole host pipeline -- reader, packers, formatters, writers and their buffers -- lives on the NUMA
+    // node that GPU hangs off (every byte of a read crosses host memory a dozen times on its way through; across the
+    // socket link each crossing costs more).  Several GPUs: each GPU's worker threads bind themselves (below).
+    if (numa_on && gpus == 1) {
+        const int node = rc_device_numa_node(ctx[0]);
+        if (node >= 0 && node != node_guess && bind_to_numa_node(node) && g_timing)
+            fprintf(stderr, "[rc timing] host threads bound to NUMA node %d%s\n", node, ahead ? " (sysfs had said another: the helper threads and the first blocks stay where they are)" : "");
+    }
+    // (the reader, the mate's reader and the workers call the pool side by side)
+    if (!pool_started) g_pool.start(std::max<size_t>((size_t)g_threads * 2, g_deflate_threads));
+    stamp("contexts created (HIP initialised, scratch allocated)");
+    const double t_start = now_s();
+    // While the table loads: the batch buffers of the pipeline -- text blocks, page-locked arenas, output slices --
+    // are allocated, sized from the head of the first input, touched and registered with the GPU runtime here, so
+    // that the first batches do not pay for a few GB of page faults and hipHostRegister calls one after the other
+    run.max_in_flight = (size_t)(gpus * run.lane_limit + 2);
+    if (one_pass_shape) {
         // HBM: the bases stay with the counter through the table build (about half of a FASTQ file's bytes), next to its
         // sort scratch (RC_COUNT_MEM_MB, 24 GiB by default) and the table itself, which the bases bound from above for
         // anything but a tiny input -- against what the device has free right now (another process may share it)
-        uint64_t hbm_free = 0, count_mem = (uint64_t)24 << 30;
-        if (const char *cm = getenv("RC_COUNT_MEM_MB")) count_mem = (uint64_t)atoll(cm) << 20;
+        uint64_t hbm_free = 0;
         if (rc_device_memory(ctx[0], &hbm_free, nullptr)) hbm_free = 0;
+        if (const char *hf = getenv("RC_HBM_FREE_MB")) hbm_free = (uint64_t)atoll(hf) << 20;  // tests: as if this much were free
         const bool fits_hbm = text_bytes + count_mem + ((uint64_t)1 << 30) <= hbm_free;
-        resident = plain && (e ? atoi(e) != 0 : (text_bytes <= avail / 3 && fits_hbm));
-        if (e && atoi(e) > 1) batch_reads = std::max<size_t>(2, (size_t)atoi(e)) & ~(size_t)1;  // (tests: RC_RESIDENT=<batch size>)
+        resident = plain && (res_env ? atoi(res_env) != 0 : (host_fits && fits_hbm));
         g_gz_whole = resident;
     }
+    if (ahead && !resident) {  // the HBM is not free after all: two passes, from the start of the files
+        ingest->abort();
+        ingest.reset();
+        for (size_t fi = 0; fi < files.size(); ++fi)
+            for (ReadFile *f : {&files[fi], files[fi].paired ? &mates[fi] : (ReadFile *)nullptr}) {
+                if (!f) continue;
+                f->src.rewind();
+                f->src.left.need(4096);
+                f->src.left_len = f->src.fill(f->src.left.p, 4096);
+            }
+        if (g_timing) fprintf(stderr, "[rc timing] the reader had gone ahead for one pass; the device memory says two: started over\n");
+        ahead = false;
+    }
     // (the head of the first file is looked at here, not in the thread: the one-pass reader takes it out of the source)
-    const HeadStats head = head_stats(run);
+    if (!ahead) head = head_stats(run);
     std::thread warm([&]() { warm_buffers(run, head); });
     int64_t stored = 0;
     if (dump) {  // main.cpp:294-308: ONE Store, loaded once
@@ -283,7 +340,10 @@ int main(int argc, char **argv)
             inputs.emplace_back(files[fi].path, files[fi].fastq);
             if (files[fi].paired) inputs.emplace_back(mates[fi].path, mates[fi].fastq);
         }
-        ingest_resident(run, resident ? batch_reads : std::max<size_t>(batch_reads, (size_t)1 << 20), &stored, resident);
+        if (ahead)
+            ingest->consume(&stored);
+        else
+            ingest_resident(run, resident ? batch_reads : std::max<size_t>(batch_reads, (size_t)1 << 20), &stored, resident);
         if (g_timing)
             fprintf(stderr, "[rc timing] k-mer counting pass over %zu file(s): %.2f s%s\n", inputs.size(), now_s() - t_start,
                     resident ? " (one pass: the text stays in host memory, the bases in HBM)" : "");
@@ -390,6 +450,18 @@ int main(int argc, char **argv)
                 typedef int (*reset_fn)();
                 if (reset_fn f = (reset_fn)dlsym(h, "hipDeviceReset")) f();
                 stamp("teardown: hipDeviceReset");
+            }
+            if (FILE *sm = fopen("/proc/self/smaps", "r")) {  // the largest resident mappings that are left
+                std::vector<std::pair<long, std::string>> maps;
+                char ln[512];
+                std::string head;
+                while (fgets(ln, sizeof ln, sm)) {
+                    if (strchr(ln, '-') && strchr(ln, '-') < ln + 20 && !strstr(ln, "kB")) head = ln;
+                    if (!strncmp(ln, "Rss:", 4)) maps.emplace_back(atol(ln + 4), head);
+                }
+                fclose(sm);
+                std::sort(maps.begin(), maps.end(), [](const std::pair<long, std::string> &a, const std::pair<long, std::string> &b) { return a.first > b.first; });
+                for (size_t i2 = 0; i2 < maps.size() && i2 < 8; ++i2) fprintf(stderr, "[rc timing] at exit %8ld kB resident: %s", maps[i2].first, maps[i2].second.c_str());
             }
             if (FILE *st = fopen("/proc/self/status", "r")) {
                 char ln[256];

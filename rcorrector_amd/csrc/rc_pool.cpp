@@ -2,6 +2,7 @@
 #include "rc_pool.h"
 
 #include <dlfcn.h>
+#include <errno.h>
 #include <sched.h>
 #include <stdarg.h>
 #include <unistd.h>
@@ -54,6 +55,50 @@ void die(const char *fmt, ...)
 }
 
 Pool g_pool;
+
+int first_gpu_numa_node()
+{
+    // GPUs this process can use: KFD nodes with SIMDs whose properties it may read and whose render node it may open (a
+    // container is shown all of the host's nodes, but not their properties, and gets the render nodes of its own GPUs only)
+    bool reordered = false;
+    for (const char *v : {"HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "GPU_DEVICE_ORDINAL"})
+        if (getenv(v)) reordered = true;
+    int found = 0, node_of_first = -2;
+    for (int n = 0; n < 1024; ++n) {
+        char path[160];
+        snprintf(path, sizeof path, "/sys/class/kfd/kfd/topology/nodes/%d/properties", n);
+        FILE *fp = fopen(path, "r");
+        if (!fp) {
+            if (errno == ENOENT) break;  // past the last node
+            continue;                    // someone else's
+        }
+        long simd = 0, minor = -1, domain = 0, loc = 0;
+        char name[64];
+        long long val;
+        while (fscanf(fp, "%63s %lld", name, &val) == 2) {
+            if (!strcmp(name, "simd_count")) simd = (long)val;
+            if (!strcmp(name, "drm_render_minor")) minor = (long)val;
+            if (!strcmp(name, "domain")) domain = (long)val;
+            if (!strcmp(name, "location_id")) loc = (long)val;
+        }
+        fclose(fp);
+        if (simd <= 0) continue;  // a CPU node
+        if (minor >= 0) {
+            snprintf(path, sizeof path, "/dev/dri/renderD%ld", minor);
+            if (access(path, R_OK | W_OK) != 0) continue;  // not ours: the runtime skips it too
+        }
+        if (found++ == 0) {
+            snprintf(path, sizeof path, "/sys/bus/pci/devices/%04lx:%02lx:%02lx.%lx/numa_node", domain, (loc >> 8) & 0xff, (loc >> 3) & 0x1f, loc & 7);
+            if ((fp = fopen(path, "r"))) {
+                if (fscanf(fp, "%d", &node_of_first) != 1) node_of_first = -2;
+                fclose(fp);
+            }
+        }
+    }
+    // one GPU: it is device 0 whatever the variables say; several: the first one, unless a variable picks or reorders
+    if (found == 0 || (found > 1 && reordered)) return -2;
+    return node_of_first;
+}
 
 bool bind_to_numa_node(int node)
 {

@@ -132,6 +132,10 @@ extern Pool g_pool;
 // from that node too.  Returns false if the node's CPU list cannot be read or shares no CPU with the current mask.
 // (The helper threads of g_pool are shared by all GPUs' workers and stay unbound.)
 bool bind_to_numa_node(int node);
+// The NUMA node of the first GPU this process may open, from sysfs alone (the KFD topology, the render nodes' permissions, the
+// PCI device's numa_node) -- what rc_device_numa_node says about device 0 once HIP is up, known before it is.  -1: the device
+// has no node (one-node hosts); -2: not known (several GPUs and a *_VISIBLE_DEVICES variable that may reorder them, no KFD topology, ...).
+int first_gpu_numa_node();
 
 template <class F>
 inline void parallel_for(size_t n, F fn)

@@ -161,6 +161,15 @@ void Source::close()
     gz = nullptr;
     fd = -1;
 }
+void Source::rewind()
+{
+    if (is_gz || !seekable) die("rcorrector: internal error: %s cannot be rewound\n", path.c_str());
+    pos = 0;
+    eof = false;
+    left_len = 0;
+    per_line = 0;
+    served = 0;
+}
 // appends up to `want` bytes of the file at dst; sets eof when the file ends first.  Regular
 // files are read by several threads at once (pread into disjoint slices: the copy out of the
 // page cache is what limits a single reader), streams and .gz by this thread alone.

@@ -39,6 +39,8 @@ struct Source {
     bool inflate_whole();
     void open(const std::string &p);
     void close();
+    // back to the first byte (plain seekable files only: what a reader that ran ahead of a decision took is read again)
+    void rewind();
     // appends up to `want` bytes of the file at dst; sets eof when the file ends first.  Regular
     // files are read by several threads at once (pread into disjoint slices: the copy out of the
     // page cache is what limits a single reader), streams and .gz by this thread alone.

@@ -32,7 +32,7 @@ struct HostWave {
     void trace_strong(const unsigned char *, int) {}
     int uni(int x) { return x; }
     uint64_t uni64(uint64_t x) { return x; }
-    long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long stats[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     void stat(int i, int v) { stats[i] += v; }
     template <class F>
     uint64_t ballot64(int base, int n, F pred)
@@ -255,7 +255,7 @@ void hostsim_correct_batch(const rco_params *p, const rco_table *t, rco_batch *b
         st->probes4 = w.gets;
         st->probes1 = 0;
         st->max_stack = w.max_sp;
-        if (getenv("HOSTSIM_STATS")) fprintf(stderr, "keep_run calls=%ld sumR=%ld sum_avail=%ld refills=%ld gap_attempts=%ld gap_probes=%ld pushes=%ld pops=%ld reads=%ld alt_runs=%ld alt_full=%ld gets=%ld\n", w.stats[0], w.stats[1], w.stats[2], w.stats[3], w.stats[4], w.stats[5], w.pushes, w.pops, (long)total, w.stats[6], w.stats[7], w.gets);
+        if (getenv("HOSTSIM_STATS")) fprintf(stderr, "keep_run calls=%ld sumR=%ld sum_avail=%ld refills=%ld gap_attempts=%ld gap_probes=%ld pushes=%ld pops=%ld reads=%ld alt_runs=%ld alt_full=%ld gets=%ld round_probes=%ld alt_rounds=%ld\n", w.stats[0], w.stats[1], w.stats[2], w.stats[3], w.stats[4], w.stats[5], w.pushes, w.pops, (long)total, w.stats[6], w.stats[7], w.gets, w.stats[8], w.stats[9]);
         st->reads = (long)total;
     }
 }

@@ -209,6 +209,36 @@ def test_cli_without_c_reproduces_reference_outputs(name, resident, tmp_path, mo
     gu.assert_same_as_reference(name, tmp_path, p.stderr)
 
 
+@pytest.mark.parametrize("env", [{"RC_HBM_FREE_MB": "1"}, {"RC_NO_READ_AHEAD": "1"}, {"RC_HBM_FREE_MB": "1", "RC_NO_READ_AHEAD": "1"}, {"RC_NUMA": "0"},
+                                 {"RC_NUMA": "0", "RC_HBM_FREE_MB": "1"}])
+@pytest.mark.parametrize("name", ["fx_pe_k23", "fx_se_k23", "fx_il_k23", "fx_k31_mc8"])
+def test_cli_reader_that_runs_ahead_of_the_gpu_runtime(name, env, tmp_path, monkeypatch):
+    """Without -c the reader of a one-pass run starts before the contexts exist (the host's half of the one-pass test has
+    passed; HIP is still coming up).  When the device then has too little memory free (RC_HBM_FREE_MB: as if this much were),
+    what it read is dropped, the sources are rewound and the run takes two passes; RC_NO_READ_AHEAD keeps the reader
+    behind the contexts; RC_NUMA=0: no NUMA node to find first, so the reader always goes ahead.  The reference's bytes and
+    messages in every case, and the timing lines say which way the run went."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    args = open(os.path.join(gu.GOLDEN, name, "cmd.txt")).read().split()
+    i = args.index("-c")
+    del args[i:i + 2]
+    p = gu.run_fixture(CLI, name, tmp_path, args_override=args)
+    gu.assert_same_as_reference(name, tmp_path, p.stderr)
+    monkeypatch.setenv("RC_TIMING", "1")
+    again = tmp_path / "again"
+    again.mkdir()
+    q = gu.run_fixture(CLI, name, again, args_override=args)
+    gu.assert_same_as_reference(name, again, b"", check_stderr=False)
+    went_ahead, started_over = b"the reader starts before" in q.stderr, b"started over" in q.stderr
+    if "RC_NO_READ_AHEAD" in env:
+        assert not went_ahead
+    if "RC_NUMA" in env and "RC_NO_READ_AHEAD" not in env:
+        assert went_ahead
+    assert started_over == (went_ahead and "RC_HBM_FREE_MB" in env)
+    assert (b"(one pass:" in q.stderr) == ("RC_HBM_FREE_MB" not in env)
+
+
 @pytest.mark.parametrize("how", ["resident", "packed"])
 @pytest.mark.parametrize("name", ["fx_pe_k23", "fx_se_k23", "fx_k31_mc8"])
 def test_cli_fix_list_overflow_falls_back_to_the_byte_path(name, how, tmp_path, monkeypatch):
