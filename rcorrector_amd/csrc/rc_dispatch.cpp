@@ -313,6 +313,19 @@ static void format_job(Run &R, Job &J)
     }
 }
 
+// (Run::lane_limit; called with R.mu held) the GPU is what this run waits for: as many batches in flight as there are workers, each in its slot lane
+static void raise_lane_limit(Run &R, const char *why)
+{
+    if (!R.adaptive || R.lane_limit >= R.inflight) return;
+    R.lane_limit = R.inflight;  // (all the way: 25 M reads of the stress preset, loop 3.3-3.4 s one step per three batches, 2.3 s with four from the start)
+    if (!getenv("RC_SLOT_LANES"))
+        for (size_t g = 0; g < R.ctx.size(); ++g) {  // (between two submits of that GPU)
+            std::lock_guard<std::mutex> sk(R.submit_mu[g]);
+            rc_set_slot_lanes(R.ctx[g], 1);
+        }
+    if (g_timing) fprintf(stderr, "[rc timing] %s: %d batches in flight per GPU from now on\n", why, R.lane_limit);
+}
+
 static void worker_body(Run &R, int wk)
 {
     std::vector<ReadFile> &files = R.files, &mates = R.mates;
@@ -606,6 +619,10 @@ static void worker_body(Run &R, int wk)
             if (rc) j->err = rc_last_error(ctx[g]);
             j->done = true;
             --R.active[(size_t)g];
+            // a batch that took the GPU longer than twice what its output takes to write (15 GB/s, 2.2 output bytes per base):
+            // no need to wait for the writer to find out
+            const double out_bytes = 2.2 * ((double)j->a.off[n] + (j->mode == 1 ? (double)j->b.off[n] : 0.0));
+            if (!rc && tf0 - tg0 > 2.0 * out_bytes / 15e9 + 0.005) raise_lane_limit(R, "a batch takes the GPU longer than the writer");
         }
         cv.notify_all();
     }
@@ -670,20 +687,12 @@ for (;;) {
     }
     const double wrote = now_s() - tw0;
     g_t_write += wrote;
-    if (R.adaptive) {  // (see Run::lane_limit) the writer waited for this batch longer than it then took to write it: three in a row
+    if (R.adaptive) {  // (see Run::lane_limit) the writer waited for this batch longer than it then took to write it: twice in a row
         starved = waited > wrote ? starved + 1 : 0;
-        if (starved >= 3) {
+        if (starved >= 2) {
             starved = 0;
             std::lock_guard<std::mutex> lk(mu);
-            if (R.lane_limit < R.inflight) {
-                ++R.lane_limit;
-                if (!getenv("RC_SLOT_LANES"))
-                    for (size_t g = 0; g < R.ctx.size(); ++g) {  // (between two submits of that GPU)
-                        std::lock_guard<std::mutex> sk(R.submit_mu[g]);
-                        rc_set_slot_lanes(R.ctx[g], 1);
-                    }
-                if (g_timing) fprintf(stderr, "[rc timing] the writer waits for the GPU: %d batches in flight per GPU from now on\n", R.lane_limit);
-            }
+            raise_lane_limit(R, "the writer waits for the GPU");
             cv.notify_all();
         }
     }

@@ -48,8 +48,8 @@ struct Run {
     // batch.  With -inflight given the two are the same.  Without it four workers are there and two may work -- what a run
     // bound by its writer wants: more batches in flight only add memory traffic (25 M x 150 bp pairs: 1.67 / 1.78 / 1.85 s at
     // 2 / 3 / 4) -- until the writer turns out to be waiting for the GPU (a data set whose batches are bound by their slowest
-    // reads: 5 % errors, k = 31, 25 M reads: loop 3.7 / 2.7 / 2.6 s at 2 / 3 / 4): then the limit goes up, one step per three
-    // such batches.  Each batch in flight runs in its own slot lane of the GPU's context (rcorrector_amd.h: rc_submit).
+    // reads: 5 % errors, k = 31, 25 M reads: loop 3.7 / 2.7 / 2.6 s at 2 / 3 / 4): then the limit goes up to `inflight`, after two
+    // such batches in a row.  Each batch in flight runs in its own slot lane of the GPU's context (rcorrector_amd.h: rc_submit).
     int lane_limit = 2;
     bool adaptive = false;
     std::vector<int> active;  // per GPU
