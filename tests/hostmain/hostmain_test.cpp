@@ -5,7 +5,7 @@
 // Test infrastructure: links the CLI's host units (rc_pool, rc_reader, rc_format) through their headers.
 #include <unistd.h>
 
-#include "../../rcorrector_amd/csrc/rc_format.h"
+#include "../../rcorrector_amd/csrc/rc_dispatch.h"
 #include <random>
 
 static int fail(const char *what, unsigned seed)
@@ -139,6 +139,73 @@ int main(int argc, char **argv)
         s.close();
         if (at != content.size() || recs != (size_t)n) return fail("big file: size", 0);
         unlink(big.c_str());
+    }
+    {   // the one-pass reader that runs ahead of the GPU runtime (Ingest::start): stopped with blocks in its queue (abort), the
+        // sources rewound as rcorrector's main does, started again and drained by hand -- both mates' blocks, put end to end,
+        // are the files, whole pairs per block, in order (no GPU: consume() is not called)
+        Run run;
+        std::string content[2];
+        const int n = 70001;
+        std::mt19937 rng(7);
+        for (int sd = 0; sd < 2; ++sd) {
+            for (int r = 0; r < n; ++r) {
+                const int sl = 30 + (int)(rng() % 100);
+                std::string sq(sl, 'A'), q(sl, 'I');
+                for (auto &c : sq) c = "ACGT"[rng() % 4];
+                content[sd] += "@p" + std::to_string(r) + "/" + std::to_string(sd + 1) + "\n" + sq + "\n+\n" + q + "\n";
+            }
+            FILE *f = fopen((dir + (sd ? "/ra_2.fq" : "/ra_1.fq")).c_str(), "wb");
+            fwrite(content[sd].data(), 1, content[sd].size(), f);
+            fclose(f);
+        }
+        run.files.emplace_back();
+        run.mates.emplace_back();
+        open_file(run.files.back(), (dir + "/ra_1.fq").c_str(), true, false, dir);
+        open_file(run.mates.back(), (dir + "/ra_2.fq").c_str(), true, false, dir);
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            Ingest I(run, 9000, true);
+            I.depth = attempt ? 3 : 4;
+            I.start();
+            if (attempt == 0) {
+                for (;;) {  // let it get ahead, then change our mind
+                    std::unique_lock<std::mutex> lk(I.mu);
+                    if (I.q.size() >= 3 || I.done) break;
+                    lk.unlock();
+                    usleep(1000);
+                }
+                I.abort();
+                if (!I.q.empty()) return fail("read-ahead: blocks left after abort", 0);
+                for (ReadFile *f : {&run.files[0], &run.mates[0]}) {
+                    f->src.rewind();
+                    f->src.left.need(4096);
+                    f->src.left_len = f->src.fill(f->src.left.p, 4096);
+                }
+                continue;
+            }
+            size_t at[2] = {0, 0}, recs = 0;
+            for (;;) {
+                std::unique_ptr<Retained> B;
+                {
+                    std::unique_lock<std::mutex> lk(I.mu);
+                    I.cv.wait(lk, [&] { return I.done || !I.q.empty(); });
+                    if (I.q.empty()) break;
+                    B = std::move(I.q.front());
+                    I.q.pop_front();
+                    I.cv.notify_all();
+                }
+                if (B->a.records != B->b.records || B->mode != 1) return fail("read-ahead: pairs", (unsigned)recs);
+                for (int sd = 0; sd < 2; ++sd) {
+                    const Block &b = sd ? B->b : B->a;
+                    const size_t end = b.line[b.records * 4];
+                    if (at[sd] + end > content[sd].size() || memcmp(b.text.p, content[sd].data() + at[sd], end) != 0) return fail("read-ahead: block bytes", (unsigned)recs);
+                    at[sd] += end;
+                }
+                recs += B->a.records;
+            }
+            I.reader.join();
+            if (recs != (size_t)n || at[0] != content[0].size() || at[1] != content[1].size()) return fail("read-ahead: size", 0);
+        }
+        for (const char *f : {"/ra_1.fq", "/ra_2.fq", "/ra_1.cor.fq", "/ra_2.cor.fq"}) unlink((dir + f).c_str());
     }
     printf("ok 60 cases\n");
     fflush(stdout);

@@ -7,7 +7,7 @@ import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "rcorrector_amd", "csrc")
-HOST_UNITS = ["rc_pool", "rc_reader", "rc_format"]
+HOST_UNITS = ["rc_pool", "rc_reader", "rc_format", "rc_writer", "rc_dispatch"]
 
 
 def build_host_test(src, exe, flags=("-O2",), objdir=None):
