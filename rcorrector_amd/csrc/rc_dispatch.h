@@ -51,6 +51,7 @@ struct Run {
     // reads: 5 % errors, k = 31, 25 M reads: loop 3.7 / 2.7 / 2.6 s at 2 / 3 / 4): then the limit goes up to `inflight`, after two
     // such batches in a row.  Each batch in flight runs in its own slot lane of the GPU's context (rcorrector_amd.h: rc_submit).
     int lane_limit = 2;
+    int batches_done = 0;
     bool adaptive = false;
     std::vector<int> active;  // per GPU
     uint64_t total_reads = 0, total_cor = 0;  // UpdateSummary, main.cpp:73-79
