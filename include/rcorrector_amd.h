@@ -88,6 +88,15 @@ int rc_table_count_release(rc_ctx *ctx);
  * correct reads whose k-mers another GPU counts (the table arrives by rc_table_replicate): one Store, T workers,
  * main.cpp:294-308,451 -- each worker's reads uploaded once, to the GPU that corrects them. */
 int rc_table_count_park(rc_ctx *ctx);
+/* rc_table_count_finish for reads that are spread over n contexts, one per GPU -- each with a session of its own
+ * (rc_table_count_begin, count_add of the reads THAT GPU will correct): the key space is cut into the slices one GPU would
+ * use, slice p belongs to ctxs[p % n]; every GPU emits a slice's keys from its own arenas and sends them to the owner
+ * (peer to peer where the GPUs can, else through the host), which sorts and reduces them; the entries with count >=
+ * min_count are put end to end in slice order on ctxs[0], where the table is built -- the same entries in the same order
+ * as one GPU holding all the reads would produce (ERROR_RATE and rc_table_write_jfdump depend on the order); the other
+ * contexts get the table by rc_table_replicate.  ctxs[0]'s rc_table_count_keep setting applies to every context (the
+ * arenas stay where they are for rc_submit_resident).  One Store for T workers, main.cpp:294-308, counted by all of them. */
+int rc_table_count_finish_sharded(rc_ctx **ctxs, int n, int min_count, int64_t *n_kmers);
 /* begin + add_device + finish for one arena */
 int rc_table_count_reads_device(rc_ctx *ctx, const uint8_t *d_seq, size_t nbytes, int min_count,
                                 int64_t *n_kmers);

@@ -13,7 +13,7 @@ ABI_SYMBOLS = [
     "rc_create", "rc_destroy", "rc_last_error", "rc_device_numa_node", "rc_device_memory",
     "rc_table_build", "rc_table_build_device", "rc_table_load_jfdump",
     "rc_table_count_begin", "rc_table_count_add", "rc_table_count_add_device", "rc_table_count_finish",
-    "rc_table_count_keep", "rc_table_count_arenas", "rc_table_count_release", "rc_table_count_park", "rc_submit_resident", "rc_wait_resident",
+    "rc_table_count_keep", "rc_table_count_arenas", "rc_table_count_release", "rc_table_count_park", "rc_table_count_finish_sharded", "rc_submit_resident", "rc_wait_resident",
     "rc_table_count_reads_device", "rc_table_write_jfdump", "rc_table_share", "rc_table_replicate", "rc_table_replicate_async", "rc_table_lookup", "rc_table_export", "rc_table_digest", "rc_table_layout", "rc_table_stats",
     "rc_estimate_error_rate", "rc_bad_quality_from_hist", "rc_set_run_params", "rc_set_quality_bits", "rc_pack_quality_bits",
     "rc_correct_batch", "rc_set_slot_lanes", "rc_submit", "rc_wait", "rc_host_alloc", "rc_host_free", "rc_host_register", "rc_host_unregister", "rc_correct_batch_traced", "rc_correct_device", "rc_strong_threshold_device", "rc_probe_device", "rc_sync",
@@ -115,6 +115,7 @@ def load_library():
     L.rc_table_count_arenas.argtypes = [vp, C.POINTER(C.c_size_t), vp, sz]
     L.rc_table_count_release.argtypes = [vp]
     L.rc_table_count_park.argtypes = [vp]
+    L.rc_table_count_finish_sharded.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.POINTER(C.c_int64)]
     L.rc_set_slot_lanes.argtypes = [vp, C.c_int]
     L.rc_submit_resident.argtypes = [vp, C.POINTER(_ResidentBatch), C.c_int]
     L.rc_wait_resident.argtypes = [vp, C.c_int]
@@ -470,6 +471,14 @@ class Context:
     def count_park(self):
         """rc_table_count_park: the arenas added since count_begin become kept arenas; nothing is counted, no table built"""
         self._ck(self._L.rc_table_count_park(self._h))
+
+    def count_finish_sharded(self, others, min_count=2):
+        """rc_table_count_finish_sharded over [self] + others (contexts with open counting sessions, one per GPU): the
+        table is built in this context; returns the number of entries kept"""
+        hs = (C.c_void_p * (1 + len(others)))(self._h, *[o._h for o in others])
+        n = C.c_int64(0)
+        self._ck(self._L.rc_table_count_finish_sharded(hs, 1 + len(others), min_count, C.byref(n)))
+        return n.value
 
     def count_release(self):
         self._ck(self._L.rc_table_count_release(self._h))

@@ -471,6 +471,19 @@ int rc_table_count_finish(rc_ctx *ctx, int min_count, int64_t *n_kmers)
     return rc_count_finish(ctx, min_count, n_kmers);
 }
 
+int rc_table_count_finish_sharded(rc_ctx **ctxs, int n, int min_count, int64_t *n_kmers)
+{
+    if (!ctxs || n < 1 || !ctxs[0]) return RC_ERR_ARG;
+    for (int g = 0; g < n; ++g)
+        if (!ctxs[g]) return RC_ERR_ARG;
+    if (n == 1) return rc_table_count_finish(ctxs[0], min_count, n_kmers);
+    RC_CHECK_HIP(ctxs[0], hipSetDevice(ctxs[0]->device));
+    static_cast<rc_ctx_full *>(ctxs[0])->dump.valid = false;
+    const int rc = rc_count_finish_sharded(ctxs, n, min_count, n_kmers);
+    (void)hipSetDevice(ctxs[0]->device);
+    return rc;
+}
+
 int rc_table_count_park(rc_ctx *ctx)
 {
     if (!ctx) return RC_ERR_ARG;

@@ -99,10 +99,12 @@ void Ingest::consume(int64_t *stored)
         depth = 3;  // (a reader that ran ahead may hold more)
     }
     if (rc_table_count_keep(ctx, keep ? 1 : 0) || rc_table_count_begin(ctx)) die("rcorrector: %s\n", rc_last_error(ctx));
-    // Several GPUs, one pass: the batches are dealt round-robin.  Every arena goes to GPU 0, which counts all of them (one
-    // Store for all workers, main.cpp:294-308), and -- once more -- to the GPU that will correct it, which only keeps it
-    // (rc_table_count_park): the files are read once, and a batch is corrected where its bases already are.
+    // Several GPUs, one pass: the batches are dealt round-robin, each arena uploaded to the GPU that will correct it, and the
+    // GPUs count together (rc_table_count_finish_sharded: every GPU scans its own reads, the key space is shared out; one
+    // Store for all workers, main.cpp:294-308): the files are read once, and a batch is corrected where its bases already
+    // are.  RC_COUNT_SHARDED=0: every arena goes to GPU 0 as well, which counts alone (the others rc_table_count_park).
     const int n_gpus = keep ? R_.gpus : 1;
+    const bool sharded = n_gpus > 1 && !(getenv("RC_COUNT_SHARDED") && !strcmp(getenv("RC_COUNT_SHARDED"), "0"));
     for (int g = 1; g < n_gpus; ++g)
         if (rc_table_count_begin(R_.ctx[(size_t)g])) die("rcorrector: %s\n", rc_last_error(R_.ctx[(size_t)g]));
     PinBuf stage;  // the sequences of one file's share of a batch on their way to HBM
@@ -130,12 +132,19 @@ void Ingest::consume(int64_t *stored)
             stage.need(total + 64);
             pack_sequences(A, stage.data());
             // (an arena without a byte is not kept: cannot happen, every record has at least its NUL)
-            if (rc_table_count_add(ctx, stage.data(), total)) die("rcorrector: %s\n", rc_last_error(ctx));
-            int idx = next_arena[0]++;
-            if (R->gpu != 0) {
+            int idx;
+            if (sharded) {  // to the GPU that will correct it, and nowhere else
                 rc_ctx *cg = R_.ctx[(size_t)R->gpu];
                 if (rc_table_count_add(cg, stage.data(), total)) die("rcorrector: %s\n", rc_last_error(cg));
                 idx = next_arena[(size_t)R->gpu]++;
+            } else {
+                if (rc_table_count_add(ctx, stage.data(), total)) die("rcorrector: %s\n", rc_last_error(ctx));
+                idx = next_arena[0]++;
+                if (R->gpu != 0) {
+                    rc_ctx *cg = R_.ctx[(size_t)R->gpu];
+                    if (rc_table_count_add(cg, stage.data(), total)) die("rcorrector: %s\n", rc_last_error(cg));
+                    idx = next_arena[(size_t)R->gpu]++;
+                }
             }
             (sd ? R->arena_b : R->arena_a) = idx;
             (sd ? R->off_b : R->off_a).swap(A.off);
@@ -151,9 +160,13 @@ void Ingest::consume(int64_t *stored)
     }
     reader.join();
     stamp(keep ? "inputs read, indexed and uploaded" : "inputs read and uploaded for the k-mer count");
-    for (int g = 1; g < n_gpus; ++g)
-        if (rc_table_count_park(R_.ctx[(size_t)g])) die("rcorrector: %s\n", rc_last_error(R_.ctx[(size_t)g]));
-    if (rc_table_count_finish(ctx, 2, stored)) die("rcorrector: %s\n", rc_last_error(ctx));
+    if (sharded) {
+        if (rc_table_count_finish_sharded(R_.ctx.data(), n_gpus, 2, stored)) die("rcorrector: %s\n", rc_last_error(ctx));
+    } else {
+        for (int g = 1; g < n_gpus; ++g)
+            if (rc_table_count_park(R_.ctx[(size_t)g])) die("rcorrector: %s\n", rc_last_error(R_.ctx[(size_t)g]));
+        if (rc_table_count_finish(ctx, 2, stored)) die("rcorrector: %s\n", rc_last_error(ctx));
+    }
     stamp("k-mers counted, table built");
 }
 

@@ -178,6 +178,7 @@ void rc_kept_release(rc_ctx *ctx);
 int rc_count_add(rc_ctx *ctx, const uint8_t *seq, size_t nbytes, bool from_device);
 int rc_count_finish(rc_ctx *ctx, int min_count, int64_t *n_kmers);
 int rc_count_park(rc_ctx *ctx);
+int rc_count_finish_sharded(rc_ctx **cs, int n, int min_count, int64_t *n_kmers);
 int rc_count_reads(rc_ctx *ctx, const uint8_t *d_seq, size_t nbytes, int min_count, int64_t *n_kmers);
 int rc_launch_selftest_bound(rc_ctx *ctx, const int32_t *d_c, size_t n, double e, int32_t *d_oi, double *d_od);
 int rc_launch_export(rc_ctx *ctx, uint64_t *d_codes, int32_t *d_counts, unsigned long long *d_n, size_t cap);

@@ -1471,6 +1471,322 @@ int rc_count_finish(rc_ctx *ctx, int min_count, int64_t *n_kmers)
     return rc;
 }
 
+// n bytes from device memory of one GPU to device memory of another (or the same), queued on `st`, a stream of the destination's
+// device, which is the current one: device to device, peer to peer where the GPUs can, else through the host (synchronous)
+static int rc_copy_across(rc_ctx *ctx, void *dst, int dst_dev, const void *src, int src_dev, size_t n, hipStream_t st)
+{
+    if (n == 0) return RC_OK;
+    const bool force_staged = getenv("RC_REPLICATE_STAGED") != nullptr;  // tests: the path of GPUs without peer access
+    if (dst_dev == src_dev && !force_staged) {
+        RC_CHECK_HIP(ctx, hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, st));
+        return RC_OK;
+    }
+    int can = 0;
+    if (!force_staged && dst_dev != src_dev) {
+        if (hipDeviceCanAccessPeer(&can, dst_dev, src_dev) != hipSuccess) can = 0;
+        if (can) {
+            const hipError_t e = hipDeviceEnablePeerAccess(src_dev, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) can = 0;
+            (void)hipGetLastError();
+        }
+    }
+    if (can) {
+        RC_CHECK_HIP(ctx, hipMemcpyPeerAsync(dst, dst_dev, src, src_dev, n, st));
+        return RC_OK;
+    }
+    const size_t CH = (size_t)64 << 20;
+    char *h = nullptr;
+    RC_CHECK_HIP(ctx, hipHostMalloc((void **)&h, std::min(CH, n), hipHostMallocPortable));
+    hipError_t e = hipSuccess;
+    for (size_t at = 0; at < n && e == hipSuccess; at += CH) {
+        const size_t m = std::min(CH, n - at);
+        e = hipSetDevice(src_dev);
+        if (e == hipSuccess) e = hipMemcpy(h, (const char *)src + at, m, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipSetDevice(dst_dev);
+        if (e == hipSuccess) e = hipMemcpyAsync((char *)dst + at, h, m, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    (void)hipSetDevice(dst_dev);
+    (void)hipHostFree(h);
+    if (e != hipSuccess) {
+        rc_set_error(ctx, "count: copy between GPUs failed: %s", hipGetErrorString(e));
+        return RC_ERR_HIP;
+    }
+    return RC_OK;
+}
+
+// rc_count_finish for reads that are spread over n contexts, one per GPU (`rcorrector -gpus N` in one pass: a batch's bases
+// are uploaded to the GPU that will correct it, and nowhere else).  The key space is cut into the P slices one GPU would
+// use; slice p belongs to GPU p % n: every GPU emits that slice's keys from its own arenas and sends them to the owner,
+// which sorts, run-length encodes and selects them -- so each GPU scans a 1 / n share of the reads P times and sorts a
+// 1 / n share of the keys, and every occurrence crosses xGMI once.  The kept entries are put end to end in slice order on
+// cs[0], where the table is built: the same entries in the same order as rc_count_finish on one GPU holding all the reads
+// (the ERROR_RATE sample and the dump depend on that order).  cs[0]'s min_count / keep settings apply to all.
+int rc_count_finish_sharded(rc_ctx **cs, int n, int min_count, int64_t *n_kmers)
+{
+    rc_ctx *c0 = cs[0];
+    for (int g = 0; g < n; ++g) {
+        if (!cs[g] || !cs[g]->cnt_active) {
+            rc_set_error(c0, "count_finish_sharded: every context needs an open counting session (rc_table_count_begin)");
+            return RC_ERR_STATE;
+        }
+        if (cs[g]->k != c0->k) {
+            rc_set_error(c0, "count_finish_sharded: contexts must have the same k");
+            return RC_ERR_ARG;
+        }
+        for (int h = 0; h < g; ++h)
+            if (cs[h] == cs[g]) {
+                rc_set_error(c0, "count_finish_sharded: a context is listed twice");
+                return RC_ERR_ARG;
+            }
+    }
+    struct release_all {
+        rc_ctx **cs;
+        int n;
+        ~release_all()
+        {
+            for (int g = 0; g < n; ++g) {
+                (void)hipSetDevice(cs[g]->device);
+                cs[g]->cnt_active = false;
+                rc_count_release(cs[g]);  // (success with cnt_keep has moved the arenas out)
+            }
+            (void)hipSetDevice(cs[0]->device);
+        }
+    } guard{cs, n};
+    const int k = c0->k;
+    size_t total = 0;
+    for (int g = 0; g < n; ++g) total += cs[g]->cnt_total;
+    size_t mem = (size_t)24 << 30;
+    if (const char *e = getenv("RC_COUNT_MEM_MB")) mem = (size_t)atoll(e) << 20;
+    uint32_t P = (uint32_t)((double)total * 40.0 * 1.15 / (double)mem) + 1;  // (as rc_count_finish: the entries come out in the same order)
+    if (P > 64) P = 64;
+    auto fail_hip = [&](hipError_t e, const char *what) {
+        rc_set_error(c0, "count_finish_sharded: %s failed: %s", what, hipGetErrorString(e));
+        return RC_ERR_HIP;
+    };
+#define RC_SH_HIP(call, what)                        \
+    do {                                             \
+        const hipError_t e__ = (call);               \
+        if (e__ != hipSuccess) return fail_hip(e__, what); \
+    } while (0)
+    // histograms: occurrences per slice on every GPU
+    std::vector<std::vector<unsigned long long>> hist((size_t)n, std::vector<unsigned long long>(64, 0));
+    {
+        std::vector<rc_dev_tmp> b_hist((size_t)n);
+        for (int g = 0; g < n; ++g) {
+            RC_SH_HIP(hipSetDevice(cs[g]->device), "hipSetDevice");
+            RC_SH_HIP(b_hist[(size_t)g].alloc(64 * 8), "hipMalloc");
+            RC_SH_HIP(hipMemsetAsync(b_hist[(size_t)g].p, 0, 64 * 8, cs[g]->stream), "hipMemsetAsync");
+            for (const auto &a : cs[g]->cnt_arenas) {
+                const unsigned G = (unsigned)((a.bytes + RC_PROBE_TILE - 1) / RC_PROBE_TILE);
+                hipLaunchKernelGGL(k_count_scan<0>, dim3(G), dim3(RC_PROBE_THREADS), 0, cs[g]->stream, (const uint8_t *)a.p, a.bytes, k, P, 0u,
+                                   b_hist[(size_t)g].as<unsigned long long>(), (uint64_t *)nullptr, (unsigned long long *)nullptr);
+            }
+            RC_SH_HIP(hipGetLastError(), "histogram launch");
+            RC_SH_HIP(hipMemcpyAsync(hist[(size_t)g].data(), b_hist[(size_t)g].p, 64 * 8, hipMemcpyDeviceToHost, cs[g]->stream), "hipMemcpyAsync");
+        }
+        for (int g = 0; g < n; ++g) {
+            RC_SH_HIP(hipSetDevice(cs[g]->device), "hipSetDevice");
+            RC_SH_HIP(hipStreamSynchronize(cs[g]->stream), "hipStreamSynchronize");
+        }
+    }
+    std::vector<size_t> slice_total(P, 0);
+    for (uint32_t p = 0; p < P; ++p)
+        for (int g = 0; g < n; ++g) slice_total[p] += (size_t)hist[(size_t)g][p];
+    // per owner: the scratch of its largest slice; per GPU: a staging buffer for the keys it emits for someone else
+    struct Owner {
+        rc_dev_tmp pool, allk, allc;
+        size_t max_slice = 0, tmp_bytes = 0, kept = 0, cap = 0;
+        size_t o_keys_s = 0, o_cnt = 0, o_keep = 0, o_runs = 0, o_tmp = 0;
+    };
+    std::vector<Owner> own((size_t)n);
+    std::vector<rc_dev_tmp> stage((size_t)n), cursor((size_t)n);
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    for (int g = 0; g < n; ++g) {
+        Owner &O = own[(size_t)g];
+        size_t max_emit = 0;
+        for (uint32_t p = 0; p < P; ++p) {
+            if ((int)(p % (uint32_t)n) == g) O.max_slice = std::max(O.max_slice, slice_total[p]);
+            else max_emit = std::max(max_emit, (size_t)hist[(size_t)g][p]);
+        }
+        if (O.max_slice >= (1ull << 32)) {
+            rc_set_error(c0, "count: a pass of %zu k-mer occurrences exceeds 2^32 (lower RC_COUNT_MEM_MB for more passes)", O.max_slice);
+            return RC_ERR_ARG;
+        }
+        RC_SH_HIP(hipSetDevice(cs[g]->device), "hipSetDevice");
+        RC_SH_HIP(cursor[(size_t)g].alloc(8), "hipMalloc");
+        if (max_emit) RC_SH_HIP(stage[(size_t)g].alloc(max_emit * 8), "hipMalloc");
+        if (O.max_slice == 0) continue;
+        size_t ts_sort = 0, ts_rle = 0, ts_sel = 0;
+        RC_SH_HIP(rocprim::radix_sort_keys(nullptr, ts_sort, (uint64_t *)nullptr, (uint64_t *)nullptr, O.max_slice, 0, 2 * k > 64 ? 64 : 2 * k, cs[g]->stream), "sort size");
+        RC_SH_HIP(rocprim::run_length_encode(nullptr, ts_rle, (uint64_t *)nullptr, (unsigned int)O.max_slice, (uint64_t *)nullptr, (uint32_t *)nullptr, (size_t *)nullptr,
+                                             cs[g]->stream), "rle size");
+        RC_SH_HIP(rocprim::select(nullptr, ts_sel, (uint64_t *)nullptr, (uint8_t *)nullptr, (uint64_t *)nullptr, (size_t *)nullptr, O.max_slice, cs[g]->stream), "select size");
+        O.tmp_bytes = std::max(ts_sort, std::max(ts_rle, ts_sel));
+        O.o_keys_s = up(O.max_slice * 8);
+        O.o_cnt = O.o_keys_s + up(O.max_slice * 8);
+        O.o_keep = O.o_cnt + up(O.max_slice * 4);
+        O.o_runs = O.o_keep + up(O.max_slice);
+        O.o_tmp = O.o_runs + 256;
+        RC_SH_HIP(O.pool.alloc(O.o_tmp + up(O.tmp_bytes)), "hipMalloc");
+    }
+    // rounds: in round r GPU o owns slice r n + o
+    struct Piece {
+        int owner;
+        size_t at, n;
+    };
+    std::vector<Piece> pieces(P, Piece{0, 0, 0});  // where slice p's kept entries lie in its owner's arrays
+    for (uint32_t r0 = 0; r0 < P; r0 += (uint32_t)n) {
+        // every GPU emits, for every owner of this round, the slice's keys from its own arenas
+        for (int g = 0; g < n; ++g) {
+            RC_SH_HIP(hipSetDevice(cs[g]->device), "hipSetDevice");
+            for (int o = 0; o < n; ++o) {
+                const uint32_t p = r0 + (uint32_t)o;
+                if (p >= P) break;
+                const size_t m = (size_t)hist[(size_t)g][p];
+                if (m == 0) continue;
+                size_t before = 0;  // this GPU's keys follow those of the GPUs before it
+                for (int h = 0; h < g; ++h) before += (size_t)hist[(size_t)h][p];
+                uint64_t *dst_local = g == o ? own[(size_t)o].pool.as<uint64_t>() + before : stage[(size_t)g].as<uint64_t>();
+                RC_SH_HIP(hipMemsetAsync(cursor[(size_t)g].p, 0, 8, cs[g]->stream), "hipMemsetAsync");
+                for (const auto &a : cs[g]->cnt_arenas) {
+                    const unsigned G = (unsigned)((a.bytes + RC_PROBE_TILE - 1) / RC_PROBE_TILE);
+                    hipLaunchKernelGGL(k_count_scan<1>, dim3(G), dim3(RC_PROBE_THREADS), 0, cs[g]->stream, (const uint8_t *)a.p, a.bytes, k, P, p,
+                                       (unsigned long long *)nullptr, dst_local, cursor[(size_t)g].as<unsigned long long>());
+                }
+                RC_SH_HIP(hipGetLastError(), "emit launch");
+                if (g != o) {  // to the owner (the staging buffer is this stream's: the next emit waits for the copy)
+                    RC_SH_HIP(hipStreamSynchronize(cs[g]->stream), "hipStreamSynchronize");
+                    RC_SH_HIP(hipSetDevice(cs[o]->device), "hipSetDevice");
+                    const int rc = rc_copy_across(c0, own[(size_t)o].pool.as<uint64_t>() + before, cs[o]->device, stage[(size_t)g].p, cs[g]->device, m * 8, cs[o]->stream);
+                    if (rc) return rc;
+                    RC_SH_HIP(hipStreamSynchronize(cs[o]->stream), "hipStreamSynchronize");
+                    RC_SH_HIP(hipSetDevice(cs[g]->device), "hipSetDevice");
+                }
+            }
+        }
+        for (int g = 0; g < n; ++g) {
+            RC_SH_HIP(hipSetDevice(cs[g]->device), "hipSetDevice");
+            RC_SH_HIP(hipStreamSynchronize(cs[g]->stream), "hipStreamSynchronize");
+        }
+        // every owner reduces its slice (the owners' streams run side by side; the host waits for each in turn)
+        std::vector<size_t> runs((size_t)n, 0), nsel((size_t)n, 0);
+        for (int phase = 0; phase < 3; ++phase)
+            for (int o = 0; o < n; ++o) {
+                const uint32_t p = r0 + (uint32_t)o;
+                if (p >= P || slice_total[p] == 0) continue;
+                Owner &O = own[(size_t)o];
+                const size_t m = slice_total[p];
+                char *pool = O.pool.as<char>();
+                uint64_t *keys = (uint64_t *)pool, *keys_s = (uint64_t *)(pool + O.o_keys_s);
+                uint32_t *cnt = (uint32_t *)(pool + O.o_cnt);
+                uint8_t *keep = (uint8_t *)(pool + O.o_keep);
+                size_t *d_runs = (size_t *)(pool + O.o_runs);
+                void *tmp = pool + O.o_tmp;
+                hipStream_t st = cs[o]->stream;
+                RC_SH_HIP(hipSetDevice(cs[o]->device), "hipSetDevice");
+                size_t t1 = O.tmp_bytes;
+                if (phase == 0) {
+                    RC_SH_HIP(rocprim::radix_sort_keys(tmp, t1, keys, keys_s, m, 0, 2 * k > 64 ? 64 : 2 * k, st), "sort");
+                    t1 = O.tmp_bytes;
+                    RC_SH_HIP(rocprim::run_length_encode(tmp, t1, keys_s, (unsigned int)m, keys, cnt, d_runs, st), "run lengths");
+                    RC_SH_HIP(hipMemcpyAsync(&runs[(size_t)o], d_runs, sizeof(size_t), hipMemcpyDeviceToHost, st), "hipMemcpyAsync");
+                } else if (phase == 1) {
+                    RC_SH_HIP(hipStreamSynchronize(st), "hipStreamSynchronize");
+                    if (runs[(size_t)o] == 0) continue;
+                    hipLaunchKernelGGL(k_flag_keep, dim3((unsigned)((runs[(size_t)o] + 255) / 256)), dim3(256), 0, st, keys, cnt, runs[(size_t)o], min_count, keep);
+                    RC_SH_HIP(rocprim::select(tmp, t1, keys, keep, keys_s, d_runs, runs[(size_t)o], st), "select");
+                    RC_SH_HIP(hipMemcpyAsync(&nsel[(size_t)o], d_runs, sizeof(size_t), hipMemcpyDeviceToHost, st), "hipMemcpyAsync");
+                } else {
+                    RC_SH_HIP(hipStreamSynchronize(st), "hipStreamSynchronize");
+                    const size_t ns = runs[(size_t)o] ? nsel[(size_t)o] : 0;
+                    pieces[p] = Piece{o, O.kept, ns};
+                    if (ns == 0) continue;
+                    if (O.kept + ns > O.cap) {  // (sized from what this owner has kept of what it has seen, + 50 %)
+                        size_t seen = 0, todo = 0;
+                        for (uint32_t q = (uint32_t)o; q < P; q += (uint32_t)n) (q <= p ? seen : todo) += slice_total[q];
+                        size_t want = (size_t)((double)(O.kept + ns) * (1.0 + 1.5 * (double)todo / (double)(seen ? seen : 1))) + ((size_t)1 << 16);
+                        static const bool tight = getenv("RC_COUNT_TIGHT") != nullptr;
+                        if (want < O.kept + ns || tight) want = O.kept + ns;
+                        rc_dev_tmp nk, nc;
+                        RC_SH_HIP(nk.alloc((want + 1) * 8), "hipMalloc");
+                        RC_SH_HIP(nc.alloc((want + 1) * 4), "hipMalloc");
+                        if (O.kept) {
+                            RC_SH_HIP(hipMemcpyAsync(nk.p, O.allk.p, O.kept * 8, hipMemcpyDeviceToDevice, st), "hipMemcpyAsync");
+                            RC_SH_HIP(hipMemcpyAsync(nc.p, O.allc.p, O.kept * 4, hipMemcpyDeviceToDevice, st), "hipMemcpyAsync");
+                            RC_SH_HIP(hipStreamSynchronize(st), "hipStreamSynchronize");
+                        }
+                        std::swap(nk.p, O.allk.p);
+                        std::swap(nc.p, O.allc.p);
+                        O.cap = want;
+                    }
+                    RC_SH_HIP(hipMemcpyAsync(O.allk.as<uint64_t>() + O.kept, keys_s, ns * 8, hipMemcpyDeviceToDevice, st), "hipMemcpyAsync");
+                    uint32_t *selc = reinterpret_cast<uint32_t *>(keys_s);  // (keys_s was copied out: the stream orders the reuse)
+                    RC_SH_HIP(rocprim::select(tmp, t1, cnt, keep, selc, d_runs, runs[(size_t)o], st), "select");
+                    hipLaunchKernelGGL(k_u32_to_i32_clamped, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, st, selc, O.allc.as<int32_t>() + O.kept, ns);
+                    RC_SH_HIP(hipGetLastError(), "launch");
+                    O.kept += ns;
+                }
+            }
+        for (int o = 0; o < n; ++o) {
+            RC_SH_HIP(hipSetDevice(cs[o]->device), "hipSetDevice");
+            RC_SH_HIP(hipStreamSynchronize(cs[o]->stream), "hipStreamSynchronize");
+        }
+    }
+    // the kept entries, slice after slice, on cs[0]
+    size_t total_kept = 0;
+    for (uint32_t p = 0; p < P; ++p) total_kept += pieces[p].n;
+    RC_SH_HIP(hipSetDevice(c0->device), "hipSetDevice");
+    rc_dev_tmp b_allk, b_allc;
+    RC_SH_HIP(b_allk.alloc((total_kept + 1) * 8), "hipMalloc");
+    RC_SH_HIP(b_allc.alloc((total_kept + 1) * 4), "hipMalloc");
+    {
+        size_t at = 0;
+        for (uint32_t p = 0; p < P; ++p) {
+            const Piece &pc = pieces[p];
+            if (pc.n == 0) continue;
+            const Owner &O = own[(size_t)pc.owner];
+            int rc = rc_copy_across(c0, b_allk.as<uint64_t>() + at, c0->device, O.allk.as<uint64_t>() + pc.at, cs[pc.owner]->device, pc.n * 8, c0->stream);
+            if (!rc) rc = rc_copy_across(c0, b_allc.as<int32_t>() + at, c0->device, O.allc.as<int32_t>() + pc.at, cs[pc.owner]->device, pc.n * 4, c0->stream);
+            if (rc) return rc;
+            at += pc.n;
+        }
+        RC_SH_HIP(hipStreamSynchronize(c0->stream), "hipStreamSynchronize");
+    }
+    for (int g = 0; g < n; ++g) {  // scratch back to its device; the reads stay where they are for rc_submit_resident, if asked
+        RC_SH_HIP(hipSetDevice(cs[g]->device), "hipSetDevice");
+        own[(size_t)g].pool.reset();
+        own[(size_t)g].allk.reset();
+        own[(size_t)g].allc.reset();
+        stage[(size_t)g].reset();
+        cursor[(size_t)g].reset();
+        cs[g]->cnt_active = false;
+        if (c0->cnt_keep) {
+            cs[g]->kept_arenas.swap(cs[g]->cnt_arenas);
+            cs[g]->kept_chunks.swap(cs[g]->cnt_chunks);
+            cs[g]->cnt_chunk_used = 0;
+            cs[g]->cnt_total = 0;
+        }
+        rc_count_release(cs[g]);
+    }
+    RC_SH_HIP(hipSetDevice(c0->device), "hipSetDevice");
+    int rc = rc_build_table_from_device_pairs(c0, b_allk.as<uint64_t>(), b_allc.as<int32_t>(), total_kept);
+    if (rc != RC_OK)
+        for (int g = 0; g < n; ++g) {
+            (void)hipSetDevice(cs[g]->device);
+            rc_kept_release(cs[g]);
+        }
+    (void)hipSetDevice(c0->device);
+    if (rc == RC_OK && total_kept) {
+        c0->counted_codes = b_allk.p;
+        c0->counted_n = total_kept;
+        b_allk.p = nullptr;
+    }
+    if (n_kmers) *n_kmers = (int64_t)total_kept;
+#undef RC_SH_HIP
+    return rc;
+}
+
 // ends a counting session without counting: the arenas it was given become kept arenas (rc_submit_resident), no table is built
 int rc_count_park(rc_ctx *ctx)
 {

@@ -124,6 +124,53 @@ def test_count_in_bounded_memory_equals_exact_counts(rc, mem_mb, retain_mb, monk
     assert (want_c >= 2).all() and len(want_k) > 5000
 
 
+@pytest.mark.parametrize("n_ctx,mem_mb,staged", [(2, None, False), (3, 1, False), (3, 4, True), (8, 1, False), (2, -1, False)])
+def test_sharded_count_over_several_contexts_equals_one_gpus_count(rc, n_ctx, mem_mb, staged, monkeypatch):
+    """rc_table_count_finish_sharded: the reads are spread over n contexts (one per GPU in `rcorrector -gpus N`; here all on
+    device 0), each scans its own arenas, the key space's slices are shared out, the owners sort and reduce, the entries are
+    put end to end in slice order on the first context.  The table must be the exact counts >= 2 and the same table -- digest,
+    ERROR_RATE estimate -- as one context counting all the reads, with one slice (more contexts than slices), with many
+    (RC_COUNT_MEM_MB), with arrays that regrow at every slice (RC_COUNT_TIGHT) and with the copies between GPUs staged through
+    the host; with rc_table_count_keep every context keeps the arenas it was given."""
+    k = 31
+    s1, _, _, _, _ = synth.make_reads(4200, 9000, 150, n_tx=6, l_tx=900, e=0.03)
+    want_k, want_c = synth.count_kmers([s1], k)
+    if mem_mb == -1:
+        mem_mb = 1
+        monkeypatch.setenv("RC_COUNT_TIGHT", "1")
+    if mem_mb is not None:
+        monkeypatch.setenv("RC_COUNT_MEM_MB", str(mem_mb))
+    if staged:
+        monkeypatch.setenv("RC_REPLICATE_STAGED", "1")
+    rows = [s1[i] for i in range(len(s1))]
+    pieces = [arena_of(rows[lo:lo + 1000]) for lo in range(0, len(rows), 1000)]
+    one = rc.Context(k=k)
+    one.count_begin()
+    for a in pieces:
+        one.count_add(a)
+    n_one = one.count_finish(2)
+    ctxs = [rc.Context(k=k) for _ in range(n_ctx)]
+    ctxs[0].count_keep(True)
+    with pytest.raises(rc.RcorrectorError, match="count_begin"):
+        ctxs[0].count_finish_sharded(ctxs[1:])
+    for c in ctxs:
+        c.count_begin()
+    given = [[] for _ in ctxs]
+    for i, a in enumerate(pieces):   # dealt unevenly: the last context gets nothing when there are many
+        g = (i * 3) % n_ctx if n_ctx < 8 else i % (n_ctx - 1)
+        ctxs[g].count_add(a)
+        given[g].append(len(a))
+    n = ctxs[0].count_finish_sharded(ctxs[1:])
+    got_k, got_c = sorted_pairs(*ctxs[0].table_export())
+    assert n == n_one == len(want_k) and np.array_equal(got_k, want_k) and np.array_equal(got_c, want_c)
+    assert ctxs[0].table_digest() == one.table_digest()
+    assert ctxs[0].estimate_error_rate(0.95) == one.estimate_error_rate(0.95)
+    for c, want in zip(ctxs, given):
+        assert list(c.count_arenas()) == want
+    for c in ctxs + [one]:
+        c.close()
+
+
 def test_count_sequence_errors(rc):
     ctx = rc.Context(k=23)
     with pytest.raises(rc.RcorrectorError):
@@ -267,6 +314,8 @@ def test_cli_without_c_on_several_gpus_reads_the_files_once(name, gpus, inflight
     device 0; batches of 40 reads, so every context gets several."""
     monkeypatch.setenv("RC_SHARED_GPU", "1")
     monkeypatch.setenv("RC_RESIDENT", "40")
+    if gpus == 3:   # the older way: every arena to GPU 0 as well, which counts alone (the others rc_table_count_park)
+        monkeypatch.setenv("RC_COUNT_SHARDED", "0")
     args = open(os.path.join(gu.GOLDEN, name, "cmd.txt")).read().split()
     i = args.index("-c")
     del args[i:i + 2]
