@@ -1601,6 +1601,7 @@ int rc_count_finish_sharded(rc_ctx **cs, int n, int min_count, int64_t *n_kmers)
     };
     std::vector<Owner> own((size_t)n);
     std::vector<rc_dev_tmp> stage((size_t)n), cursor((size_t)n);
+    std::vector<size_t> stage_each((size_t)n, 0);
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     for (int g = 0; g < n; ++g) {
         Owner &O = own[(size_t)g];
@@ -1614,8 +1615,9 @@ int rc_count_finish_sharded(rc_ctx **cs, int n, int min_count, int64_t *n_kmers)
             return RC_ERR_ARG;
         }
         RC_SH_HIP(hipSetDevice(cs[g]->device), "hipSetDevice");
-        RC_SH_HIP(cursor[(size_t)g].alloc(8), "hipMalloc");
-        if (max_emit) RC_SH_HIP(stage[(size_t)g].alloc(max_emit * 8), "hipMalloc");
+        RC_SH_HIP(cursor[(size_t)g].alloc((size_t)n * 8), "hipMalloc");  // one cursor and one staging buffer per owner of a round
+        stage_each[(size_t)g] = max_emit;
+        if (max_emit) RC_SH_HIP(stage[(size_t)g].alloc((size_t)n * max_emit * 8), "hipMalloc");
         if (O.max_slice == 0) continue;
         size_t ts_sort = 0, ts_rle = 0, ts_sel = 0;
         RC_SH_HIP(rocprim::radix_sort_keys(nullptr, ts_sort, (uint64_t *)nullptr, (uint64_t *)nullptr, O.max_slice, 0, 2 * k > 64 ? 64 : 2 * k, cs[g]->stream), "sort size");
@@ -1637,32 +1639,44 @@ int rc_count_finish_sharded(rc_ctx **cs, int n, int min_count, int64_t *n_kmers)
     };
     std::vector<Piece> pieces(P, Piece{0, 0, 0});  // where slice p's kept entries lie in its owner's arrays
     for (uint32_t r0 = 0; r0 < P; r0 += (uint32_t)n) {
-        // every GPU emits, for every owner of this round, the slice's keys from its own arenas
+        // every GPU emits, for every owner of this round, the slice's keys from its own arenas: its own slice straight into its
+        // sort buffer, the others' into a staging buffer each -- all GPUs at once, nothing waits for the host
+        auto before_of = [&](int g, uint32_t p) {  // a GPU's keys follow those of the GPUs before it
+            size_t b = 0;
+            for (int h = 0; h < g; ++h) b += (size_t)hist[(size_t)h][p];
+            return b;
+        };
         for (int g = 0; g < n; ++g) {
             RC_SH_HIP(hipSetDevice(cs[g]->device), "hipSetDevice");
+            RC_SH_HIP(hipMemsetAsync(cursor[(size_t)g].p, 0, (size_t)n * 8, cs[g]->stream), "hipMemsetAsync");
             for (int o = 0; o < n; ++o) {
                 const uint32_t p = r0 + (uint32_t)o;
                 if (p >= P) break;
-                const size_t m = (size_t)hist[(size_t)g][p];
-                if (m == 0) continue;
-                size_t before = 0;  // this GPU's keys follow those of the GPUs before it
-                for (int h = 0; h < g; ++h) before += (size_t)hist[(size_t)h][p];
-                uint64_t *dst_local = g == o ? own[(size_t)o].pool.as<uint64_t>() + before : stage[(size_t)g].as<uint64_t>();
-                RC_SH_HIP(hipMemsetAsync(cursor[(size_t)g].p, 0, 8, cs[g]->stream), "hipMemsetAsync");
+                if (hist[(size_t)g][p] == 0) continue;
+                uint64_t *dst_local = g == o ? own[(size_t)o].pool.as<uint64_t>() + before_of(g, p) : stage[(size_t)g].as<uint64_t>() + (size_t)o * stage_each[(size_t)g];
                 for (const auto &a : cs[g]->cnt_arenas) {
                     const unsigned G = (unsigned)((a.bytes + RC_PROBE_TILE - 1) / RC_PROBE_TILE);
                     hipLaunchKernelGGL(k_count_scan<1>, dim3(G), dim3(RC_PROBE_THREADS), 0, cs[g]->stream, (const uint8_t *)a.p, a.bytes, k, P, p,
-                                       (unsigned long long *)nullptr, dst_local, cursor[(size_t)g].as<unsigned long long>());
+                                       (unsigned long long *)nullptr, dst_local, cursor[(size_t)g].as<unsigned long long>() + o);
                 }
                 RC_SH_HIP(hipGetLastError(), "emit launch");
-                if (g != o) {  // to the owner (the staging buffer is this stream's: the next emit waits for the copy)
-                    RC_SH_HIP(hipStreamSynchronize(cs[g]->stream), "hipStreamSynchronize");
-                    RC_SH_HIP(hipSetDevice(cs[o]->device), "hipSetDevice");
-                    const int rc = rc_copy_across(c0, own[(size_t)o].pool.as<uint64_t>() + before, cs[o]->device, stage[(size_t)g].p, cs[g]->device, m * 8, cs[o]->stream);
-                    if (rc) return rc;
-                    RC_SH_HIP(hipStreamSynchronize(cs[o]->stream), "hipStreamSynchronize");
-                    RC_SH_HIP(hipSetDevice(cs[g]->device), "hipSetDevice");
-                }
+            }
+        }
+        for (int g = 0; g < n; ++g) {
+            RC_SH_HIP(hipSetDevice(cs[g]->device), "hipSetDevice");
+            RC_SH_HIP(hipStreamSynchronize(cs[g]->stream), "hipStreamSynchronize");
+        }
+        // ... and every owner fetches what the others emitted for it (the owners' streams side by side)
+        for (int o = 0; o < n; ++o) {
+            const uint32_t p = r0 + (uint32_t)o;
+            if (p >= P) break;
+            RC_SH_HIP(hipSetDevice(cs[o]->device), "hipSetDevice");
+            for (int g = 0; g < n; ++g) {
+                const size_t m = (size_t)hist[(size_t)g][p];
+                if (g == o || m == 0) continue;
+                const int rc = rc_copy_across(c0, own[(size_t)o].pool.as<uint64_t>() + before_of(g, p), cs[o]->device,
+                                              stage[(size_t)g].as<uint64_t>() + (size_t)o * stage_each[(size_t)g], cs[g]->device, m * 8, cs[o]->stream);
+                if (rc) return rc;
             }
         }
         for (int g = 0; g < n; ++g) {
