@@ -144,6 +144,9 @@ int rc_correct_device_impl(rc_ctx *ctx, const rc_device_batch *b, uint32_t qual_
         if (!fused && (rc = rc_launch_probe_list(ctx, a, (size_t)b->nbytes, (int32_t *)ctx->counts.p))) return rc;
     } else if ((rc = rc_launch_probe(ctx, b->d_seq, (size_t)b->nbytes, (int32_t *)ctx->counts.p)))
         return rc;
+#ifdef RC_EXP_PROBE_ONLY  // dev (with RC_EXP_ADDR_WINDOW, whose counts are wrong by design): nothing behind the probe kernel runs
+    return RC_OK;
+#endif
     // thresholds: mates need each other's before either can be corrected, so paired / interleaved
     // batches always run the threshold kernel first; single-end batches do too when every read fits
     // the four-reads-per-wave kernel (cheaper there than inside k_correct), else k_correct computes them

@@ -191,6 +191,19 @@ __global__ __launch_bounds__(RC_PROBE_THREADS) __attribute__((amdgpu_waves_per_e
         s_lpos[nr] = lp;
     }
     __syncthreads();
+#define RC_FUSED_CUT(n, v)                                                       \
+    do {                                                                         \
+        if constexpr (RC_FUSED_STOP_ == (n)) {                                   \
+            if ((uint32_t)(v) == 0x5bd1e995u && A.strong) A.strong[0] = (int)(v); \
+            return;                                                              \
+        }                                                                        \
+    } while (0)
+#ifdef RC_FUSED_STOP  // dev: see rc_quarter.h
+    constexpr int RC_FUSED_STOP_ = RC_FUSED_STOP;
+#else
+    constexpr int RC_FUSED_STOP_ = -1;
+#endif
+    RC_FUSED_CUT(0, s_lpos[t & 15] ^ s_gpos[t & 15] ^ s_rid[t & 15]);
     for (uint32_t j = (uint32_t)t >> 6; j < nr; j += RC_PROBE_THREADS / 64) {  // copy, aligned dwords, outside bytes masked to NUL
         if (!s_len1[j]) continue;
         const uint32_t g0 = s_gpos[j], lp = s_lpos[j], g1 = g0 + s_len1[j] - 1;
@@ -211,6 +224,7 @@ __global__ __launch_bounds__(RC_PROBE_THREADS) __attribute__((amdgpu_waves_per_e
         }
     }
     __syncthreads();
+    RC_FUSED_CUT(1, s_raw[t]);
     const uint32_t total = s_lpos[nr];
     for (int chunk = t; chunk < RC_FUSED_TILE / 16 + 2; chunk += RC_PROBE_THREADS) {
         const uint4 v = *reinterpret_cast<const uint4 *>(s_raw + 4 * chunk);
@@ -222,6 +236,7 @@ __global__ __launch_bounds__(RC_PROBE_THREADS) __attribute__((amdgpu_waves_per_e
     }
     if (t < 2) s_code[RC_FUSED_TILE / 16 + 2 + t] = 0xFFFFFFFFu;
     __syncthreads();
+    RC_FUSED_CUT(2, s_code[t & 127] ^ s_inv[t & 127] ^ s_nul[t & 127]);
     const uint32_t *m_inv = reinterpret_cast<const uint32_t *>(s_inv);
     const uint32_t *m_nul = reinterpret_cast<const uint32_t *>(s_nul);
 #ifndef RC_PROBE_UNROLL
@@ -243,6 +258,7 @@ __global__ __launch_bounds__(RC_PROBE_THREADS) __attribute__((amdgpu_waves_per_e
         s_cnt[a] = cnt;
     }
     __syncthreads();
+    RC_FUSED_CUT(3, s_cnt[t] ^ s_cnt[t + 256] ^ s_cnt[t + 512] ^ s_cnt[t + 768] ^ s_cnt[t + 1024] ^ s_cnt[t + 1280] ^ s_cnt[t + 1536] ^ s_cnt[t + 1792] ^ s_cnt[t + 2048] ^ s_cnt[t + 2304] ^ s_cnt[t + 2560]);
     // thresholds + classes: 16 reads per pass (one per 16-lane row; the list keeps mates adjacent)
     const uint8_t *raw8 = reinterpret_cast<const uint8_t *>(s_raw);
     for (uint32_t j0 = 0; j0 < nr; j0 += RC_PROBE_THREADS / 16) {
@@ -260,6 +276,7 @@ __global__ __launch_bounds__(RC_PROBE_THREADS) __attribute__((amdgpu_waves_per_e
         }
     }
     __syncthreads();
+    RC_FUSED_CUT(19, s_cls[t & 15]);
     // the counts k_correct will read: those of the reads that still need it, four per lane (a read
     // starts at the same offset modulo 4 here and in the arena; the up to three words in front of its
     // first count and behind its last one belong to NULs and to the last k-1 positions of a read,

@@ -182,6 +182,24 @@ __device__ __forceinline__ uint32_t row_bits(uint64_t ballot, int row)
 
 }  // namespace rcq
 
+// dev (tools/fused_stops.sh): -DRC_FUSED_STOP=<n> cuts the fused probe + threshold kernel off after stage n -- everything computed up to
+// there is folded into one value that a store nobody takes depends on, so the compiler keeps the stages in front of the cut
+// and drops the ones behind it.  Wrong results; what is measured is the kernel's time and instruction count up to the cut.
+#ifdef RC_FUSED_STOP
+#define RCQ_STOP(n, ...)                                                  \
+    do {                                                                  \
+        if constexpr (RC_FUSED_STOP == (n)) {                             \
+            int sink_ = 0;                                                \
+            const int vals_[] = {__VA_ARGS__};                            \
+            for (int v_ : vals_) sink_ = sink_ * 31 + v_;                 \
+            if (sink_ == 0x5bd1e995 && A.strong) A.strong[0] = sink_;     \
+            return 1;                                                     \
+        }                                                                 \
+    } while (0)
+#else
+#define RCQ_STOP(n, ...) do { } while (0)
+#endif
+
 // GetStrongTrustedThreshold + classification of the read held by this lane's 16-lane row (four reads
 // per wave; rows 2j and 2j+1 of a wave hold the two mates of a pair).  base_at(p) = letter of base p,
 // count_at(g) = K1's count of k-mer g; the caller decides where they come from (HBM for
@@ -208,6 +226,8 @@ __device__ __forceinline__ int rcq_threshold_row(const rc_kernel_args &A, uint32
         const int g = e * 16 + l;
         x[e] = g < kcnt ? count_at(g) : 0;
     }
+    RCQ_STOP(10, code[0] ^ code[1] ^ code[2] ^ code[3] ^ code[4] ^ code[E_BASE - 5] ^ code[E_BASE - 4] ^ code[E_BASE - 3] ^ code[E_BASE - 2] ^ code[E_BASE - 1],
+             x[0] ^ x[1] ^ x[2] ^ x[3] ^ x[E_CNT - 4] ^ x[E_CNT - 3] ^ x[E_CNT - 2] ^ x[E_CNT - 1]);
 
     // letter masks of the row's read as 32-bit words (bit p%32 of word p/32 = base p is the letter)
     uint32_t ma[E_BASE / 2 + 1], mt[E_BASE / 2 + 1];
@@ -234,6 +254,8 @@ __device__ __forceinline__ int rcq_threshold_row(const rc_kernel_args &A, uint32
         t_cnt += __popc(mt[j]);
     }
     const bool screened = len < k || n_cnt > 5 || a_cnt > len - k || t_cnt > len - k;  // :1491,1507-1527
+    RCQ_STOP(11, (int)screened, (int)(ma[0] ^ ma[1] ^ ma[2] ^ ma[3] ^ ma[4]), (int)(mt[0] ^ mt[1] ^ mt[2] ^ mt[3] ^ mt[4]),
+             x[0] ^ x[1] ^ x[2] ^ x[3] ^ x[E_CNT - 4] ^ x[E_CNT - 3] ^ x[E_CNT - 2] ^ x[E_CNT - 1]);
 
     // poly-A masked counts (:1530-1541): a window with >= k - max(7, k/2) A's or T's counts as -1;
     // window g = bits [g, g+k) of the mask = one funnel shift of two adjacent words (k <= 32)
@@ -250,6 +272,7 @@ __device__ __forceinline__ int rcq_threshold_row(const rc_kernel_args &A, uint32
         const bool polya = a >= k - thr7 || t >= k - thr7;
         x[e] = g < kcnt ? (polya ? -1 : x[e]) : 2147483647;
     }
+    RCQ_STOP(12, (int)screened, x[0], x[1], x[2], x[3], x[E_CNT - 4], x[E_CNT - 3], x[E_CNT - 2], x[E_CNT - 1]);
 
     int c[4];
 #pragma unroll
@@ -265,6 +288,7 @@ __device__ __forceinline__ int rcq_threshold_row(const rc_kernel_args &A, uint32
         sort_t8(x, c);
     else
         merges<E_CNT, 2>(x, c);
+    RCQ_STOP(13, (int)screened, x[0], x[1], x[2], x[3], x[E_CNT - 4], x[E_CNT - 3], x[E_CNT - 2], x[E_CNT - 1]);
     // sorted element idx, read by every lane of the row: its register (a chain of selects: x[] must stay in registers) and lane
 #define RCQ_SORTED_AT(dst, idx_)                                                                       \
     do {                                                                                               \
@@ -349,6 +373,7 @@ __device__ __forceinline__ int rcq_threshold_row(const rc_kernel_args &A, uint32
         strong = found ? strong : med;
     }
     const int strong_self = screened ? -1 : strong;
+    RCQ_STOP(14, strong_self, prev, (int)found, x[0], x[1], x[2], x[3], x[E_CNT - 4], x[E_CNT - 3], x[E_CNT - 2], x[E_CNT - 1]);
     // Class of the read.  Replay the first threshold iteration of ErrorCorrection (:793-842):
     // `s` = the strong threshold it starts with (its own, lowered to the pair's), `t0` = the weak
     // one ("trust").  If no k-mer of the read lies below t0 (v[0] >= t0 >= 2, which also means
@@ -398,6 +423,7 @@ __device__ __forceinline__ int rcq_threshold_row(const rc_kernel_args &A, uint32
         int n_below = 0;  // k-mers with count < s
 #pragma unroll
         for (int e = 0; e < E_CNT; ++e) n_below += __popc(row_bits(__ballot(x[e] < s), row));
+        RCQ_STOP(15, strong_self, prev, (int)found, s, t0, v0, n_below, x[0], x[1], x[2], x[3], x[E_CNT - 4], x[E_CNT - 3], x[E_CNT - 2], x[E_CNT - 1]);
         // the trusted mask ErrorCorrection builds its islands from (:870-931): counts[g] >= s && !IsPolyA(g, 2), bit g % 16 of
         // word g / 16; `adj` = it has two adjacent 1-bits, i.e. a real island (a run of >= 2 trusted k-mers) exists
         constexpr int NTB = 4 * ((E_CNT + 3) / 4);
@@ -427,6 +453,8 @@ __device__ __forceinline__ int rcq_threshold_row(const rc_kernel_args &A, uint32
         RCQ_SORTED_AT(vm, im);
         RCQ_SORTED_AT(vh, ih);
         if (!screened && n_below < kcnt) cls = n_below >= kcnt - (kcnt >> 3) ? 4 : (n_below >= kcnt - (kcnt >> 2) ? 3 : (n_below >= kcnt - (kcnt >> 1) ? 2 : 1));
+        RCQ_STOP(16, strong_self, prev, (int)found, s, t0, v0, n_below, vm, vh, (int)clean, cls, rmin, rmax, (int)(tb[0] ^ tb[1] ^ tb[2] ^ tb[3] ^ tb[NTB - 4] ^ tb[NTB - 3] ^ tb[NTB - 2] ^ tb[NTB - 1]),
+                 y[0] ^ y[1] ^ y[2] ^ y[3] ^ y[E_CNT - 4] ^ y[E_CNT - 3] ^ y[E_CNT - 2] ^ y[E_CNT - 1], (int)(ma[0] ^ mt[0]));
         // The same on the REAL counts.  The sorted array hides the windows the threshold scan masks as poly-A (:1530-1541:
         // >= k - max(7, k/2) A's or T's -- one read in eight has such a window), so v0 < 0 for a read that is clean in every
         // other respect.  ErrorCorrection itself never looks at that mask (its own, :870-931, asks for >= k - 2): if every
@@ -470,6 +498,8 @@ __device__ __forceinline__ int rcq_threshold_row(const rc_kernel_args &A, uint32
                 }
             }
         }
+        RCQ_STOP(17, strong_self, prev, (int)found, s, t0, v0, vm, vh, (int)clean, (int)clean2, cls, (int)(tb[0] ^ tb[1] ^ tb[2] ^ tb[3] ^ tb[NTB - 4] ^ tb[NTB - 3] ^ tb[NTB - 2] ^ tb[NTB - 1]),
+                 code[0] ^ code[1] ^ code[2] ^ code[3] ^ code[4] ^ code[E_BASE - 5] ^ code[E_BASE - 4] ^ code[E_BASE - 3] ^ code[E_BASE - 2] ^ code[E_BASE - 1]);
         // Candidate for k_single (rc_single.h, condition (2)): every letter ACGT, and the trusted mask -- counts >= s and
         // not poly-A at threshold 2 (:870-931) -- has no 1-run of length one and only 0-runs of exactly k, or of at most k
         // at either end of the read.  k_single checks it again (it needs the runs' positions anyway); this flag only keeps the
@@ -536,6 +566,7 @@ __device__ __forceinline__ int rcq_threshold_row(const rc_kernel_args &A, uint32
             }
             if (live && l == 0) A.cand[r] = cand ? (uint8_t)cand_runs : 0;
         }
+        RCQ_STOP(18, strong_self, prev, (int)found, v0, vm, vh, (int)clean, cls);
         if (clean) {
             cls = 0;
             if (live && l == 0) {
