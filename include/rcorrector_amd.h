@@ -71,7 +71,9 @@ int rc_table_load_jfdump(rc_ctx *ctx, const char *path, int64_t *stored);
  * canonical k-mer counts over any number of arenas of reads (reads separated by NUL bytes, each
  * arena < 2^32 bytes; k-mers holding a letter outside ACGT are skipped), then the table from the
  * entries with count >= min_count.  count_add takes a host arena, count_add_device one already in
- * HBM.  *n_kmers = entries kept (the "Stored %d kmers" value). */
+ * HBM.  *n_kmers = entries kept (the "Stored %d kmers" value).  The kept entries' codes (8 bytes each) stay in HBM behind
+ * the table for rc_estimate_error_rate, which reads them instead of decoding the buckets and frees them; a caller that
+ * never estimates gets the memory back at rc_set_run_params (or with the table). */
 int rc_table_count_begin(rc_ctx *ctx);
 int rc_table_count_add(rc_ctx *ctx, const char *seq, size_t nbytes);
 int rc_table_count_add_device(rc_ctx *ctx, const uint8_t *d_seq, size_t nbytes);
@@ -213,6 +215,15 @@ int rc_correct_batch(rc_ctx *ctx, rc_batch *b);
  * worker threads busy on one context. */
 #define RC_MAX_SLOTS 4
 int rc_set_slot_lanes(rc_ctx *ctx, int on);
+/* The lanes' streams overlap only when the HIP runtime gives them hardware queues of their own: it multiplexes a process's
+ * streams onto GPU_MAX_HW_QUEUES queues, four by default, and two compute streams that share one run one after the other.
+ * That variable is read when the runtime starts, so it is the HOST's to set: export GPU_MAX_HW_QUEUES=16, or call
+ * rc_runtime_prepare(16) -- from one thread, before any thread exists that reads the environment and before the process
+ * first touches HIP (its own use included; torch counts) -- which sets it unless the process has it already.  Returns 1 if it
+ * set the variable, 0 if it was set already (left alone), -1 on a bad argument.  rc_create does not touch the environment
+ * (it did until round 5); a lane created while the variable is unset or below 8 prints one note on stderr (RC_QUIET=1: none).
+ * No reference counterpart: the reference's workers are pthreads on one Store (main.cpp:439-523). */
+int rc_runtime_prepare(int hw_queues);
 int rc_submit(rc_ctx *ctx, const rc_batch *b, int slot);
 int rc_wait(rc_ctx *ctx, int slot);
 int rc_host_alloc(rc_ctx *ctx, size_t bytes, void **out);

@@ -67,13 +67,25 @@ def lib():
         L.rco_get_bound_int.argtypes = [C.POINTER(Params), C.c_int]
         L.rco_get_bound.restype = C.c_double
         L.rco_get_bound.argtypes = [C.POINTER(Params), C.c_int]
+        L.rco_set_chunk.argtypes = [C.c_int]
+        L.rco_set_interleave.restype = C.c_int
+        L.rco_set_interleave.argtypes = [C.c_int]
         _lib = L
     return _lib
 
 
+def set_chunk(units):
+    """units a worker thread takes per visit to the batch's shared counter (1 = the reference's schedule; no effect on results)"""
+    lib().rco_set_chunk(int(units))
+
+
 class Table:
-    def __init__(self, k, expected=1 << 16):
+    def __init__(self, k, expected=1 << 16, interleave=False):
+        """interleave: spread the table's pages over every memory node of the host (a table one thread fills otherwise lives
+        on that thread's node and is probed by the threads of every socket)"""
         self.k = k
+        self.interleave = bool(interleave)
+        self.interleaved = False
         self.h = lib().rco_table_new(k, expected)
 
     def __del__(self):
@@ -93,7 +105,12 @@ class Table:
     def put_many(self, canon_codes, counts):
         cc = np.ascontiguousarray(canon_codes, dtype=np.uint64)
         vv = np.ascontiguousarray(counts, dtype=np.int32)
+        # (pages are placed when they are first written, i.e. here: the policy covers the fill)
+        ok = self.interleave and lib().rco_set_interleave(1) == 0
         lib().rco_table_put_many(self.h, cc.ctypes.data, vv.ctypes.data, len(cc))
+        if ok:
+            lib().rco_set_interleave(0)
+            self.interleaved = True
 
     def size(self):
         return lib().rco_table_size(self.h)

@@ -962,18 +962,53 @@ static void correct_one(const rco_params *p, const rco_table *t, char *seq, cons
     *h = hh;
 }
 
+/* Units a worker takes per visit to the counter.  The reference takes one (:87-90); the results do not depend on who
+ * corrects which unit, and with one unit per visit 64 threads on a two-socket host write neighbouring reads' results -- 4-byte
+ * ret / l / m / h entries and 151-byte reads of the same cache lines -- at the same time.  rco_set_chunk(1) is the
+ * reference's schedule. */
+static int g_chunk = 64;
+void rco_set_chunk(int units) { g_chunk = units > 0 ? units : 1; }
+
+/* MPOL_INTERLEAVE over every memory node for the allocations that follow (on = 1; the table of a 78 M-k-mer run is 1.6 GB
+ * that one thread fills, i.e. one node's memory, probed by the threads of both sockets), MPOL_DEFAULT again with on = 0.
+ * Raw system call (no libnuma in the image); a host that refuses it keeps its policy.  Returns 0 on success. */
+#include <sys/syscall.h>
+#include <unistd.h>
+int rco_set_interleave(int on)
+{
+#ifdef SYS_set_mempolicy
+    unsigned long mask[16];
+    memset(mask, 0, sizeof mask);
+    if (!on) return (int)syscall(SYS_set_mempolicy, 0 /* MPOL_DEFAULT */, NULL, 0);
+    FILE *f = fopen("/sys/devices/system/node/online", "r");
+    int lo = 0, hi = 0;
+    if (f) {
+        if (fscanf(f, "%d-%d", &lo, &hi) < 2) hi = lo;
+        fclose(f);
+    }
+    for (int n = lo; n <= hi && n < 1024; ++n) mask[n / (8 * sizeof(long))] |= 1ul << (n % (8 * sizeof(long)));
+    return (int)syscall(SYS_set_mempolicy, 3 /* MPOL_INTERLEAVE */, mask, 1024 + 1);
+#else
+    (void)on;
+    return -1;
+#endif
+}
+
 static void *worker_main(void *argp)
 {
     worker_arg *a = (worker_arg *)argp;
     rco_batch *b = a->b;
     size_t inc = b->mode == 2 ? 2 : 1;
     for (;;) {
-        size_t ind;
+        size_t ind0, ind1;
         pthread_mutex_lock(&a->lock);
-        ind = a->used;
-        a->used += inc;
+        ind0 = a->used;
+        a->used += inc * (size_t)g_chunk;
         pthread_mutex_unlock(&a->lock);
-        if (ind >= b->n) break;
+        if (ind0 >= b->n) break;
+        ind1 = ind0 + inc * (size_t)g_chunk;
+        if (ind1 > b->n) ind1 = b->n;
+      for (size_t ind = ind0; ind < ind1; ind += inc) {
         int tt = -1;
         if (b->mode == 1) {
             int t1 = rco_strong_trusted_threshold(a->p, a->t, b->seq + b->off[ind]);
@@ -994,6 +1029,7 @@ static void *worker_main(void *argp)
             correct_one(a->p, a->t, b->seq + b->off[ind + 1], b->qual + b->off[ind + 1], tt,
                         &b->ret[ind + 1], &b->l[ind + 1], &b->m[ind + 1], &b->h[ind + 1]);
         }
+      }
     }
     return NULL;
 }

@@ -7,7 +7,7 @@ a thin ctypes binding over that ABI used by the test-suite and ``bench.py``; it 
 algorithm and no CPU fallback -- if the library or a GPU is missing, it raises.
 """
 from .binding import (Context, RcorrectorError, build_library, library_path, load_library,  # noqa: F401
-                      pack_reads, unpack_reads, ABI_SYMBOLS)
+                      pack_reads, unpack_reads, runtime_prepare, ABI_SYMBOLS)
 
 __all__ = ["Context", "RcorrectorError", "build_library", "library_path", "load_library",
-           "pack_reads", "unpack_reads", "ABI_SYMBOLS"]
+           "pack_reads", "unpack_reads", "runtime_prepare", "ABI_SYMBOLS"]

@@ -16,7 +16,7 @@ ABI_SYMBOLS = [
     "rc_table_count_keep", "rc_table_count_arenas", "rc_table_count_release", "rc_table_count_park", "rc_table_count_finish_sharded", "rc_submit_resident", "rc_wait_resident",
     "rc_table_count_reads_device", "rc_table_write_jfdump", "rc_table_share", "rc_table_replicate", "rc_table_replicate_async", "rc_table_lookup", "rc_table_export", "rc_table_digest", "rc_table_layout", "rc_table_stats",
     "rc_estimate_error_rate", "rc_bad_quality_from_hist", "rc_set_run_params", "rc_set_quality_bits", "rc_pack_quality_bits",
-    "rc_correct_batch", "rc_set_slot_lanes", "rc_submit", "rc_wait", "rc_host_alloc", "rc_host_free", "rc_host_register", "rc_host_unregister", "rc_correct_batch_traced", "rc_correct_device", "rc_strong_threshold_device", "rc_probe_device", "rc_sync",
+    "rc_correct_batch", "rc_set_slot_lanes", "rc_runtime_prepare", "rc_submit", "rc_wait", "rc_host_alloc", "rc_host_free", "rc_host_register", "rc_host_unregister", "rc_correct_batch_traced", "rc_correct_device", "rc_strong_threshold_device", "rc_probe_device", "rc_sync",
     "rc_strong_threshold_read", "rc_correct_read", "rc_kmer_info_read",
     "rc_pack_bases", "rc_submit_packed", "rc_wait_packed", "rc_apply_fixes",
     "rc_profile_enable", "rc_profile_get", "rc_profile_reset", "rc_profile_correct_counters", "rc_profile_read_rounds", "rc_selftest_get_bound", "rc_summary",
@@ -117,6 +117,7 @@ def load_library():
     L.rc_table_count_park.argtypes = [vp]
     L.rc_table_count_finish_sharded.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.POINTER(C.c_int64)]
     L.rc_set_slot_lanes.argtypes = [vp, C.c_int]
+    L.rc_runtime_prepare.argtypes = [C.c_int]
     L.rc_submit_resident.argtypes = [vp, C.POINTER(_ResidentBatch), C.c_int]
     L.rc_wait_resident.argtypes = [vp, C.c_int]
     L.rc_table_write_jfdump.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64)]
@@ -163,6 +164,12 @@ def load_library():
     L.rc_summary.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     _lib = L
     return L
+
+
+def runtime_prepare(hw_queues=16):
+    """rc_runtime_prepare: ask the HIP runtime for hardware queues for the slot lanes' streams (GPU_MAX_HW_QUEUES unless the process
+    has it already).  Before the process first touches HIP -- before torch does; one thread.  1 = set, 0 = was set already."""
+    return load_library().rc_runtime_prepare(int(hw_queues))
 
 
 def pack_reads(seqs):

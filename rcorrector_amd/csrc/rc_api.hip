@@ -3,6 +3,7 @@
 // per-read computation happens in the kernels of rc_table.hip / rc_correct.hip.  There is no CPU
 // fallback anywhere in this library.
 #include "rc_api_internal.h"
+#include <mutex>
 
 static thread_local char g_create_err[512];
 
@@ -31,6 +32,17 @@ int rc_dbuf_reserve(rc_ctx *ctx, rc_dbuf *b, size_t bytes)
 
 void rc_table_release(rc_ctx *ctx)
 {
+    // a slot lane may still be probing the table it borrowed (streams of its own): wait for it and take the loan back before
+    // the buckets go -- the next batch of that slot gets the new table with its refresh (rc_slot_lane)
+    if (ctx->d_buckets && !ctx->buckets_borrowed) {
+        for (rc_ctx *ln : ctx->lane) {
+            if (!ln || ln->d_buckets != ctx->d_buckets) continue;
+            (void)hipStreamSynchronize(ln->stream);
+            ln->d_buckets = nullptr;
+            ln->buckets_borrowed = false;
+            ln->n_entries = 0;
+        }
+    }
     if (ctx->d_buckets && !ctx->buckets_borrowed) (void)hipFree(reinterpret_cast<char *>(ctx->d_buckets) - RC_TABLE_PREFIX_BYTES);
     ctx->d_buckets = nullptr;
     ctx->buckets_borrowed = false;
@@ -91,6 +103,16 @@ rc_ctx *rc_slot_lane(rc_ctx *ctx, int slot, bool create, bool refresh)
     }
     rc_ctx *&ln = ctx->lane[slot];
     if (!ln) {
+        // lanes only overlap when their streams land on different hardware queues: say so, once, if the runtime has few
+        static std::once_flag warned;
+        std::call_once(warned, [] {
+            const char *q = getenv("GPU_MAX_HW_QUEUES");
+            if ((!q || atoi(q) < 8) && !getenv("RC_QUIET"))
+                fprintf(stderr, "[rcorrector_amd] note: batches in slots > 0 run in lanes with streams of their own, but GPU_MAX_HW_QUEUES is %s: the HIP "
+                                "runtime will put them on 4 hardware queues and some will run one after the other. Export GPU_MAX_HW_QUEUES=16 (or call "
+                                "rc_runtime_prepare) before the process first touches HIP, or switch the lanes off (rc_set_slot_lanes / RC_SLOT_LANES=0).\n",
+                        q ? q : "not set");
+        });
         rc_config cfg = {ctx->device, ctx->k, ctx->P.max_fix_per_k};
         char err[256];
         ln = rc_create(&cfg, err, sizeof err);
@@ -116,9 +138,22 @@ rc_ctx *rc_slot_lane(rc_ctx *ctx, int slot, bool create, bool refresh)
         ln->params_set = ctx->params_set;
         ln->qual_bits = ctx->qual_bits;
         ln->kept_arenas = ctx->kept_arenas;  // (descriptors only: the chunks stay the parent's)
+        ln->profile = ctx->profile;          // measurement follows the batch into its lane (rc_profile_get adds the lanes up)
+        ln->phase_prof = ctx->phase_prof;
+        ln->phase_prof_print = ctx->phase_prof_print;
+        ln->rounds_out = ctx->rounds_out;
     }
     ctx->slot_home[slot] = ln;
     return ln;
+}
+
+int rc_runtime_prepare(int hw_queues)
+{
+    if (hw_queues < 1) return -1;
+    if (getenv("GPU_MAX_HW_QUEUES")) return 0;
+    char v[16];
+    snprintf(v, sizeof v, "%d", hw_queues);
+    return setenv("GPU_MAX_HW_QUEUES", v, 0) == 0 ? 1 : -1;
 }
 
 rc_ctx *rc_create(const rc_config *cfg, char *errbuf, size_t errbuf_len)
@@ -128,10 +163,8 @@ rc_ctx *rc_create(const rc_config *cfg, char *errbuf, size_t errbuf_len)
         return nullptr;
     };
     if (!cfg) return fail("rc_create: null config");
-    // Slot lanes (rc_internal.h) want their streams on hardware queues of their own: the runtime multiplexes a process's
-    // streams onto GPU_MAX_HW_QUEUES queues (4 by default), and two compute streams that share one run one after the other --
-    // which is what made "two contexts" slower than one in round 4.  Only a process that has not initialised HIP yet takes it.
-    setenv("GPU_MAX_HW_QUEUES", "16", 0);
+    // (Slot lanes want their streams on hardware queues of their own -- GPU_MAX_HW_QUEUES, the host's to export before HIP
+    // starts: rc_runtime_prepare / rcorrector_amd.h.  The library does not touch its host's environment from here.)
     if (cfg->k < 1 || cfg->k > 32) return fail("rc_create: k must be in 1..32 (run_rcorrector.pl:225-228)");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -149,6 +182,7 @@ rc_ctx *rc_create(const rc_config *cfg, char *errbuf, size_t errbuf_len)
     ctx->P.bad_qual = 0;
     memset(ctx->P.bs, 0, sizeof ctx->P.bs);
     ctx->P.bs_ext = nullptr;
+    ctx->P.bound_small = nullptr;
     ctx->P.flags = 0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
@@ -273,14 +307,26 @@ int rc_profile_enable(rc_ctx *ctx, int on)
     if (!ctx) return RC_ERR_ARG;
     ctx->profile = on != 0;
     if (!ctx->phase_prof_print) ctx->phase_prof = on == 2;
+    for (rc_ctx *ln : ctx->lane) {  // (and a lane that exists already; new ones copy the flags when they take a batch)
+        if (!ln) continue;
+        ln->profile = ctx->profile;
+        ln->phase_prof = ctx->phase_prof;
+    }
     return RC_OK;
 }
 
 int rc_profile_get(rc_ctx *ctx, int kernel, double *total_ms, uint64_t *launches)
 {
     if (!ctx || kernel < 0 || kernel >= RC_T_COUNT) return RC_ERR_ARG;
-    if (total_ms) *total_ms = ctx->timers[kernel].ms;
-    if (launches) *launches = ctx->timers[kernel].launches;
+    double ms = ctx->timers[kernel].ms;
+    uint64_t n = ctx->timers[kernel].launches;
+    for (rc_ctx *ln : ctx->lane) {  // (the batches of slots > 0 ran in lane contexts)
+        if (!ln) continue;
+        ms += ln->timers[kernel].ms;
+        n += ln->timers[kernel].launches;
+    }
+    if (total_ms) *total_ms = ms;
+    if (launches) *launches = n;
     return RC_OK;
 }
 
@@ -289,15 +335,27 @@ int rc_profile_reset(rc_ctx *ctx)
     if (!ctx) return RC_ERR_ARG;
     for (auto &t : ctx->timers) t = rc_kernel_timer();
     ctx->k3_listed = ctx->k3_rounds = ctx->k3_requests = 0;
+    for (rc_ctx *ln : ctx->lane) {
+        if (!ln) continue;
+        for (auto &t : ln->timers) t = rc_kernel_timer();
+        ln->k3_listed = ln->k3_rounds = ln->k3_requests = 0;
+    }
     return RC_OK;
 }
 
 int rc_profile_correct_counters(rc_ctx *ctx, uint64_t *reads_listed, uint64_t *gather_rounds, uint64_t *bucket_requests)
 {
     if (!ctx) return RC_ERR_ARG;
-    if (reads_listed) *reads_listed = ctx->k3_listed;
-    if (gather_rounds) *gather_rounds = ctx->k3_rounds;
-    if (bucket_requests) *bucket_requests = ctx->k3_requests;
+    uint64_t a = ctx->k3_listed, b = ctx->k3_rounds, c = ctx->k3_requests;
+    for (rc_ctx *ln : ctx->lane) {
+        if (!ln) continue;
+        a += ln->k3_listed;
+        b += ln->k3_rounds;
+        c += ln->k3_requests;
+    }
+    if (reads_listed) *reads_listed = a;
+    if (gather_rounds) *gather_rounds = b;
+    if (bucket_requests) *bucket_requests = c;
     return RC_OK;
 }
 
@@ -305,6 +363,8 @@ int rc_profile_read_rounds(rc_ctx *ctx, int32_t *d_rounds)
 {
     if (!ctx) return RC_ERR_ARG;
     ctx->rounds_out = d_rounds;
+    for (rc_ctx *ln : ctx->lane)
+        if (ln) ln->rounds_out = d_rounds;
     return RC_OK;
 }
 

@@ -444,6 +444,11 @@ int rc_table_count_release(rc_ctx *ctx)
     if (!ctx) return RC_ERR_ARG;
     RC_CHECK_HIP(ctx, hipSetDevice(ctx->device));
     RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (a batch still reading them)
+    for (rc_ctx *ln : ctx->lane) {  // the slot lanes hold copies of the descriptors and run on streams of their own
+        if (!ln) continue;
+        RC_CHECK_HIP(ctx, hipStreamSynchronize(ln->stream));
+        ln->kept_arenas.clear();
+    }
     rc_kept_release(ctx);
     return RC_OK;
 }
@@ -745,6 +750,15 @@ char rc_bad_quality_from_hist(const int32_t first_hist[300], const int32_t last_
 int rc_set_run_params(rc_ctx *ctx, double error_rate, char bad_quality)
 {
     if (!ctx) return RC_ERR_ARG;
+    // the codes a counted table was built from wait for rc_estimate_error_rate (which takes them); a caller that sets the
+    // parameters itself does not need them: 8 bytes per entry of HBM back (rcorrector_amd.h: rc_table_count_finish)
+    if (ctx->counted_codes) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(ctx->counted_codes);
+        ctx->counted_codes = nullptr;
+        ctx->counted_n = 0;
+    }
     ctx->P.error_rate = error_rate;
     ctx->P.bad_qual = (int)(signed char)bad_quality;
     // the first integer steps of GetBound at this rate (rc_common.h), computed here with the host's -- the
@@ -756,11 +770,19 @@ int rc_set_run_params(rc_ctx *ctx, double error_rate, char bad_quality)
     // ... and the whole table stays in device memory for the thresholds beyond those
     RC_CHECK_HIP(ctx, hipSetDevice(ctx->device));
     const size_t steps_bytes = (size_t)RC_BOUND_STEPS * sizeof(uint32_t);
-    int rc = rc_dbuf_reserve(ctx, &ctx->bs_dev, steps_bytes);
+    int rc = rc_dbuf_reserve(ctx, &ctx->bs_dev, steps_bytes + RC_BOUND_SMALL);
     if (rc) return rc;
+    // ... and behind it the bound itself for small counts (rc_run_params::bound_small), again the host's arithmetic
+    uint8_t small[RC_BOUND_SMALL];
+    for (int c = 0; c < RC_BOUND_SMALL; ++c) {
+        const int v = rc_bound_i(c, error_rate);
+        small[c] = v >= 0 && v < 255 ? (uint8_t)v : (uint8_t)255;
+    }
     RC_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (a batch in flight may still read the old table)
     RC_CHECK_HIP(ctx, hipMemcpy(ctx->bs_dev.p, steps, steps_bytes, hipMemcpyHostToDevice));
+    RC_CHECK_HIP(ctx, hipMemcpy((char *)ctx->bs_dev.p + steps_bytes, small, RC_BOUND_SMALL, hipMemcpyHostToDevice));
     ctx->P.bs_ext = getenv("RC_NO_BS_EXT") ? nullptr : (const uint32_t *)ctx->bs_dev.p;
+    ctx->P.bound_small = getenv("RC_NO_BS_EXT") ? nullptr : (const uint8_t *)ctx->bs_dev.p + steps_bytes;
     ctx->P.flags = ctx->env_no_alt ? RC_PF_NO_ALT : 0;
     ctx->params_set = true;
     return RC_OK;

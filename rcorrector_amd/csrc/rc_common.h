@@ -122,6 +122,59 @@ RC_HD uint64_t rc_brev64(uint64_t x)
 #endif
 }
 
+// ---- 16 arena bytes -> 2-bit codes + letter masks, four bytes per operation (the fused probe kernel's staging) ----------
+// rc_pack16m: the 2-bit codes of 16 bytes (first byte in the most significant bits, A C G T = 0 1 2 3, anything else -- the
+// NUL behind a read and the padding between reads included -- as 3) and three 16-bit masks, bit j = byte j: is an A, is a T,
+// is none of ACGT.  Bit arrays made of the masks (bit p % 32 of word p / 32 = arena byte p) give a k-mer window's "has a
+// letter outside ACGT" as one funnel shift (k <= 32) and a read's letter masks (rc_quarter.h: rcq_lds_masks) as five.
+// Per 32-bit word of four letters: ((c >> 1) ^ (c >> 2)) & 3 is the code of an ACGT letter; the letter that code stands for is
+// 0x41 + 2 a + 6 b + 11 ab (a, b = the code's bits), and a byte that differs from it is not one of ACGT; the four 2-bit
+// fields (and the four flags) are gathered into a byte by a multiply whose partial products do not overlap
+// (rc_correct_core.h: rc_pack_read uses the same one).  tests/hostmath/pack16m.cpp: every byte value in every position.
+RC_HD uint32_t rc_compress_even16(uint32_t x)  // bits 0, 2, 4, .. 30 of x -> bits 0 .. 15
+{
+    x &= 0x55555555u;
+    x = (x | (x >> 1)) & 0x33333333u;
+    x = (x | (x >> 2)) & 0x0F0F0F0Fu;
+    x = (x | (x >> 4)) & 0x00FF00FFu;
+    x = (x | (x >> 8)) & 0x0000FFFFu;
+    return x;
+}
+RC_HD uint32_t rc_brev32(uint32_t x)
+{
+#if defined(__clang__)
+    return __builtin_bitreverse32(x);
+#else
+    x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+    x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+    x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
+    x = ((x >> 8) & 0x00FF00FFu) | ((x & 0x00FF00FFu) << 8);
+    return (x >> 16) | (x << 16);
+#endif
+}
+RC_HD void rc_pack16m(const uint32_t (&w)[4], uint32_t &code, uint32_t &am, uint32_t &tm, uint32_t &bad)
+{
+    uint32_t cw = 0, bw = 0;  // codes / "not ACGT" flags (low bit of the field), 2 bits per byte, first byte in the top bits
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t x = w[q];
+        uint32_t c2 = ((x >> 1) ^ (x >> 2)) & 0x03030303u;
+        const uint32_t a = c2 & 0x01010101u, b = (c2 >> 1) & 0x01010101u, ab = a & b;
+        const uint32_t e = 0x41414141u + (a << 1) + (b << 2) + (b << 1) + (ab << 3) + (ab << 1) + ab;  // the letter of the code
+        const uint32_t d = x ^ e;
+        const uint32_t nz = ((((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d) >> 7) & 0x01010101u;  // 1 per byte that is not its code's letter
+        c2 |= nz | (nz << 1);
+        cw = (cw << 8) | ((c2 * 0x40100401u) >> 24);
+        bw = (bw << 8) | ((nz * 0x40100401u) >> 24);
+    }
+    code = cw;
+    // byte j's field sits at bits 31 - 2j, 30 - 2j: reversed, at 2j (the field's HIGH bit) and 2j + 1 (its low bit)
+    const uint32_t r = rc_brev32(cw), rb = rc_brev32(bw);
+    bad = rc_compress_even16(rb >> 1);
+    tm = rc_compress_even16(r & (r >> 1)) & ~bad;
+    am = rc_compress_even16(~(r | (r >> 1)));
+}
+
 // reverse complement of a k-mer code (first base in the most significant 2 bits, as the
 // reference's KmerCode): reverse the 2-bit groups, complement, drop the unused low bits.
 RC_HD uint64_t rc_revcomp(uint64_t code, int k)

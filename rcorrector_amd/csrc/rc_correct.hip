@@ -150,8 +150,8 @@ __global__ __launch_bounds__(RC_PROBE_THREADS) __attribute__((amdgpu_waves_per_e
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_raw[(RC_FUSED_TILE + 64) / 4];
     __shared__ uint32_t s_code[RC_FUSED_TILE / 16 + 4];
-    __shared__ uint16_t s_inv[RC_FUSED_TILE / 16 + 4];
-    __shared__ uint16_t s_nul[RC_FUSED_TILE / 16 + 4];
+    // letter masks of the arena, bit p % 32 of word p / 32 = arena byte p (rc_pack16m): not one of ACGT / an A / a T
+    __shared__ __attribute__((aligned(4))) uint16_t s_bad[RC_FUSED_TILE / 16 + 20], s_am[RC_FUSED_TILE / 16 + 20], s_tm[RC_FUSED_TILE / 16 + 20];
     __shared__ uint32_t s_lpos[RC_PLIST_MAX_READS + 1], s_gpos[RC_PLIST_MAX_READS], s_len1[RC_PLIST_MAX_READS], s_rid[RC_PLIST_MAX_READS];
     __shared__ __attribute__((aligned(16))) int32_t s_cnt[RC_FUSED_TILE + 64];
     __shared__ uint8_t s_cls[RC_PLIST_MAX_READS];
@@ -228,32 +228,36 @@ __global__ __launch_bounds__(RC_PROBE_THREADS) __attribute__((amdgpu_waves_per_e
     const uint32_t total = s_lpos[nr];
     for (int chunk = t; chunk < RC_FUSED_TILE / 16 + 2; chunk += RC_PROBE_THREADS) {
         const uint4 v = *reinterpret_cast<const uint4 *>(s_raw + 4 * chunk);
-        uint32_t code, inv, nul;
-        rc_pack16(v, code, inv, nul);
+        uint32_t code, am, tm, bad;
+        const uint32_t vw[4] = {v.x, v.y, v.z, v.w};
+        rc_pack16m(vw, code, am, tm, bad);
         s_code[chunk] = code;
-        s_inv[chunk ^ 1] = (uint16_t)inv;
-        s_nul[chunk ^ 1] = (uint16_t)nul;
+        s_bad[chunk] = (uint16_t)bad;
+        s_am[chunk] = (uint16_t)am;
+        s_tm[chunk] = (uint16_t)tm;
     }
     if (t < 2) s_code[RC_FUSED_TILE / 16 + 2 + t] = 0xFFFFFFFFu;
+    if (t < 18) {  // (the rows read whole words up to 160 bases behind a read's start)
+        s_bad[RC_FUSED_TILE / 16 + 2 + t] = 0xFFFFu;
+        s_am[RC_FUSED_TILE / 16 + 2 + t] = 0;
+        s_tm[RC_FUSED_TILE / 16 + 2 + t] = 0;
+    }
     __syncthreads();
-    RC_FUSED_CUT(2, s_code[t & 127] ^ s_inv[t & 127] ^ s_nul[t & 127]);
-    const uint32_t *m_inv = reinterpret_cast<const uint32_t *>(s_inv);
-    const uint32_t *m_nul = reinterpret_cast<const uint32_t *>(s_nul);
+    RC_FUSED_CUT(2, s_code[t & 127] ^ s_bad[t & 127] ^ s_am[t & 127] ^ s_tm[t & 127]);
+    const uint32_t *m_bad = reinterpret_cast<const uint32_t *>(s_bad);
+    const uint32_t kmask = k >= 32 ? 0xffffffffu : ((1u << k) - 1u);
 #ifndef RC_PROBE_UNROLL
 #define RC_PROBE_UNROLL 2
 #endif
 #pragma unroll RC_PROBE_UNROLL
     for (uint32_t a = 4 + (uint32_t)t; a + (uint32_t)k <= total; a += RC_PROBE_THREADS) {  // probe: counts stay in LDS
-        const int mw = a >> 5, ms = a & 31;
-        const uint64_t nulw = (((uint64_t)m_nul[mw] << 32) | m_nul[mw + 1]) << ms;
-        if (nulw >> (64 - k)) continue;
-        const uint64_t invw = (((uint64_t)m_inv[mw] << 32) | m_inv[mw + 1]) << ms;
+        // a window with a letter outside ACGT -- the NUL behind a read included: a position that is no k-mer of any read -- counts 0
+        const int mw = a >> 5;
         int cnt = 0;
-        if (!(invw >> (64 - k))) {
-            const int cw = a >> 4, cs = 2 * (a & 15);
-            uint64_t x = ((uint64_t)s_code[cw] << 32) | s_code[cw + 1];
-            if (cs) x = (x << cs) | ((uint64_t)s_code[cw + 2] >> (32 - cs));
-            cnt = rc_table_lookup<EXT>(A.T, rc_canonical(x >> (64 - 2 * k), k));
+        if (!(__builtin_amdgcn_alignbit(m_bad[mw + 1], m_bad[mw], (uint32_t)a & 31u) & kmask)) {
+            const int cw = a >> 4, cs = 2 * (a & 15);  // the 64 bits from base a on: two words shifted up, the third fills in (no branch on cs)
+            const uint64_t x = ((((uint64_t)s_code[cw] << 32) | s_code[cw + 1]) << cs) | (((uint64_t)s_code[cw + 2] << cs) >> 32);
+            cnt = rc_table_lookup<EXT>(A.T, rc_canonical_dev(x >> (64 - 2 * k), k));
         }
         s_cnt[a] = cnt;
     }
@@ -266,8 +270,9 @@ __global__ __launch_bounds__(RC_PROBE_THREADS) __attribute__((amdgpu_waves_per_e
         const bool live = j < nr && s_len1[j] != 0;
         const uint32_t lp = live ? s_lpos[j] : 0;
         const int len = live ? (int)s_len1[j] - 1 : 0;
+        const rcq_lds_masks msrc = {reinterpret_cast<const uint32_t *>(s_am), reinterpret_cast<const uint32_t *>(s_tm), m_bad, lp};
         const int cls = rcq_threshold_row<EC, 10>(
-            A, live ? s_rid[j] : 0, live, len, [&](int p) { return (uint32_t)raw8[lp + p]; }, [&](int g) { return s_cnt[lp + g]; });
+            A, live ? s_rid[j] : 0, live, len, [&](int p) { return (uint32_t)raw8[lp + p]; }, [&](int g) { return s_cnt[lp + g]; }, msrc);
         if (live && (t & 15) == 0) s_cls[j] = (uint8_t)cls;
         if (j < nr && !live && (t & 15) == 0) {  // another tier's read
             s_cls[j] = 0;

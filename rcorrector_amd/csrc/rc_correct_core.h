@@ -46,7 +46,13 @@ struct rc_run_params {
     // the whole table (RC_BOUND_STEPS entries, in device memory for the kernels): thresholds of RC_BS_INLINE and more --
     // reads of transcripts covered thousands of times -- take one load per read from here (nullptr: none)
     const uint32_t *bs_ext;
+    // (int)GetBound(c) itself for the counts c < RC_BOUND_SMALL, one byte each, 255 = "evaluate it" (the value does not fit, or
+    // would not be the host's): what the threshold rows and k_single turn a read's strong threshold into its weak one with
+    // (ErrorCorrection.cpp:793-842) -- one load instead of a double-precision multiply / square root / add chain per read.
+    // Device memory, behind bs_ext's entries (nullptr: none)
+    const uint8_t *bound_small;
 };
+#define RC_BOUND_SMALL 4096
 // the smallest count whose bound reaches t (t >= 2), or 0 if that is not known (no table, t beyond it, never reached)
 RC_HD uint32_t rc_bs_lookup(const rc_run_params &P, int t)
 {

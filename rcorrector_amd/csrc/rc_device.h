@@ -56,26 +56,34 @@ __device__ __forceinline__ int rc_table_lookup_o(const rc_table_view &T, uint64_
             }
         }
         const uint32_t cmask = RC_PACKED_COUNT_MASK >> ext;  // (uniform)
-        const uint64_t mask = ((uint64_t)(0x7FFFFFFFu & ~cmask) << 32) | 0xFFFFFFFFull;
+        const uint32_t mhi = 0x7FFFFFFFu & ~cmask;
         const uint32_t xhi = xrem << (27 - ext);
         for (uint32_t disp = 0;; ++disp, ++b) {
             const uint4 *p = reinterpret_cast<const uint4 *>(T.buckets + (size_t)b * RC_BUCKET_DWORDS);
-            uint64_t d[RC_PACKED_SLOTS];
+            uint32_t dlo[RC_PACKED_SLOTS], dhi[RC_PACKED_SLOTS];
             if (n_req) ++*n_req;
 #pragma unroll
             for (int q = 0; q < RC_BUCKET_DWORDS / 4; ++q) {
                 const uint4 v = p[q];
-                d[2 * q + 0] = ((uint64_t)v.y << 32) | v.x;
-                d[2 * q + 1] = ((uint64_t)v.w << 32) | v.z;
+                dlo[2 * q + 0] = v.x;
+                dhi[2 * q + 0] = v.y;
+                dlo[2 * q + 1] = v.z;
+                dhi[2 * q + 1] = v.w;
             }
-            // an empty slot carries displacement 15, which no entry has: rem and displacement decide
-            const uint64_t want = ((uint64_t)((disp << 27) | xhi) << 32) | rem;
-            int r = 0;
+            // an empty slot carries displacement 15, which no entry has: rem and displacement decide.  A slot matches iff
+            // ((hi ^ whi) & mhi) | (lo ^ rem) is zero: two three-input bit operations (v_bitop3_b32: 0x28 = (a ^ b) & c,
+            // 0xF6 = a | (b ^ c)), a compare and a select per slot -- the count is masked out of the selected word once, behind
+            // the chain (round 6: the 64-bit compare of round 2 cost five instructions a slot, a register copy among them)
+            const uint32_t whi = (disp << 27) | xhi;
+            uint32_t rh = 0;
 #pragma unroll
-            for (int s2 = RC_PACKED_SLOTS - 1; s2 >= 0; --s2)
-                r = (d[s2] & mask) == want ? (int)((uint32_t)(d[s2] >> 32) & cmask) : r;
-            if (r != 0 || !(d[RC_PACKED_SLOTS - 1] >> 63) || disp == RC_PACKED_MAX_DISP) {
-                if (r == (int)cmask) r = rc_packed_overflow_count(T, canon);
+            for (int s2 = RC_PACKED_SLOTS - 1; s2 >= 0; --s2) {
+                const uint32_t t = __builtin_amdgcn_bitop3_b32(__builtin_amdgcn_bitop3_b32(dhi[s2], whi, mhi, 0x28), dlo[s2], rem, 0xF6);
+                rh = t == 0 ? dhi[s2] : rh;
+            }
+            const int r = (int)(rh & cmask);
+            if (r != 0 || !(dhi[RC_PACKED_SLOTS - 1] >> 31) || disp == RC_PACKED_MAX_DISP) {
+                if (r == (int)cmask) return rc_packed_overflow_count(T, canon);
                 return r;
             }
         }
@@ -109,6 +117,20 @@ template <bool EXT = true>
 __device__ __forceinline__ int rc_table_lookup(const rc_table_view &T, uint64_t canon, uint32_t *n_req = nullptr)
 {
     return rc_table_lookup_o<EXT>(T, canon, canon, n_req);
+}
+
+// rc_canonical (rc_common.h: KmerCode::GetCanonicalKmerCode, KmerCode.h:58-71) in 32-bit halves for the probe loops, which are
+// bound by vector-instruction issue: reversing 64 bits is two v_bfrev_b32 with the halves exchanged, and "swap the two bits
+// of every base, complement" is one three-input bit operation per half on y << 1 and y >> 1 (0x27 = ~((a & ~c) | (b & c)),
+// c = 0x55555555) -- 12 instructions instead of 19.
+__device__ __forceinline__ uint64_t rc_canonical_dev(uint64_t code, int k)
+{
+    const uint32_t xl = (uint32_t)code, xh = (uint32_t)(code >> 32);
+    const uint32_t yh = __builtin_bitreverse32(xl), yl = __builtin_bitreverse32(xh);
+    const uint32_t zh = __builtin_amdgcn_bitop3_b32(yh << 1, yh >> 1, 0x55555555u, 0x27);
+    const uint32_t zl = __builtin_amdgcn_bitop3_b32(yl << 1, yl >> 1, 0x55555555u, 0x27);
+    const uint64_t rc = (((uint64_t)zh << 32) | zl) >> (64 - 2 * k);
+    return rc < code ? rc : code;
 }
 
 // ---- pieces of the probe kernels (K1) shared by rc_table.hip and rc_correct.hip ----------------------

@@ -191,7 +191,7 @@ int main(int argc, char **argv)
     const bool shared_gpu = run.shared_gpu = getenv("RC_SHARED_GPU") != nullptr;
     const bool numa_on = run.numa_on = !(getenv("RC_NUMA") && !strcmp(getenv("RC_NUMA"), "0"));
     const bool lanes_env = getenv("RC_SLOT_LANES") != nullptr;
-    setenv("GPU_MAX_HW_QUEUES", "16", 0);  // (rc_create would: here no other thread reads the environment yet)
+    rc_runtime_prepare(16);  // hardware queues for the slot lanes' streams: no thread exists yet, HIP has not started
     // The GPU runtime takes 0.08-0.25 s to come up (tools/mb/hipinit.hip): the contexts are created on a thread of their own,
     // and what needs no GPU goes ahead -- the test whether this is a one-pass run, as far as the host can say, and its reader.
     std::string ctx_err;
@@ -306,8 +306,15 @@ int main(int argc, char **argv)
         // HBM: the bases stay with the counter through the table build (about half of a FASTQ file's bytes), next to its
         // sort scratch (RC_COUNT_MEM_MB, 24 GiB by default) and the table itself, which the bases bound from above for
         // anything but a tiny input -- against what the device has free right now (another process may share it)
-        uint64_t hbm_free = 0;
-        if (rc_device_memory(ctx[0], &hbm_free, nullptr)) hbm_free = 0;
+        // Several GPUs: every one of them holds its share of the bases, a sort scratch of its own and the staging of the
+        // sharded count (rc_table_count_finish_sharded) -- priced as if each held everything, against the GPU with the
+        // least free memory (a GPU another process shares must not run out in the middle of the count)
+        uint64_t hbm_free = ~(uint64_t)0;
+        for (int g = 0; g < gpus; ++g) {
+            uint64_t f = 0;
+            if (rc_device_memory(ctx[g], &f, nullptr)) f = 0;
+            hbm_free = std::min(hbm_free, f);
+        }
         if (const char *hf = getenv("RC_HBM_FREE_MB")) hbm_free = (uint64_t)atoll(hf) << 20;  // tests: as if this much were free
         const bool fits_hbm = text_bytes + count_mem + ((uint64_t)1 << 30) <= hbm_free;
         resident = plain && (res_env ? atoi(res_env) != 0 : (host_fits && fits_hbm));

@@ -206,39 +206,92 @@ __device__ __forceinline__ uint32_t row_bits(uint64_t ballot, int row)
 // k_threshold_q, the workgroup's LDS for the fused probe kernel).  Writes strong / info / cls and, for
 // reads it can finish, ret / l / m / h of read r; returns the class (1 = k_correct has work to do).
 // KT: the k the caller is compiled for (0: A.P.k)
-template <int E_CNT, int E_BASE, int KT = 0, class FB, class FC>
-__device__ __forceinline__ int rcq_threshold_row(const rc_kernel_args &A, uint32_t r, bool live, int len, FB base_at, FC count_at)
+// (int)GetBound(c, ERROR_RATE) of a row's threshold: a byte of the host's table (rc_run_params::bound_small) where it holds
+// the value, the double-precision chain of rc_common.h where it does not (counts of RC_BOUND_SMALL and more, screened reads'
+// -1, no table).  Call in wave-uniform control flow.
+__device__ __forceinline__ int rcq_bound(const rc_kernel_args &A, int c)
+{
+    int v = 255;
+    if (A.P.bound_small && (uint32_t)c < (uint32_t)RC_BOUND_SMALL) v = A.P.bound_small[c];
+    if (__ballot(v == 255)) {
+        const int slow = rc_bound_i(c, A.P.error_rate);
+        v = v == 255 ? slow : v;
+    }
+    return v;
+}
+
+// MS = where the letter masks come from: rcq_no_masks -- built here from base_at(), a compare chain and three ballots per
+// base (the batch in HBM: k_threshold_q) -- or rcq_lds_masks: the fused probe kernel has packed its arena's letters into
+// bit arrays already (rc_pack16m: bit p % 32 of word p / 32 = arena byte p is an A / is a T / is neither of ACGT), and a row's
+// words are five funnel shifts of them (round 6: the compare chains were 230 of the 1 516 vector instructions of a row pass).
+struct rcq_no_masks {
+    static constexpr bool present = false;
+};
+struct rcq_lds_masks {
+    static constexpr bool present = true;
+    const uint32_t *am, *tm, *bad;  // LDS
+    uint32_t lp;                    // the row's first base in the arena
+};
+template <int E_CNT, int E_BASE, int KT = 0, class FB, class FC, class MS = rcq_no_masks>
+__device__ __forceinline__ int rcq_threshold_row(const rc_kernel_args &A, uint32_t r, bool live, int len, FB base_at, FC count_at, MS msrc = MS())
 {
     using namespace rcq;
     const int lane = threadIdx.x & 63, row = lane >> 4, l = lane & 15;
     const int k = KT ? KT : A.P.k;
     const int kcnt = len >= k ? len - k + 1 : 0;
 
-    // bases (as letter codes) and K1's counts, element g in register g/16 of lane g%16
-    int code[E_BASE], x[E_CNT];
-#pragma unroll
-    for (int e = 0; e < E_BASE; ++e) {
-        const int p = e * 16 + l;
-        code[e] = p < len ? rc_base_code(base_at(p)) : 7;
-    }
+    // K1's counts, element g in register g/16 of lane g%16
+    int x[E_CNT];
 #pragma unroll
     for (int e = 0; e < E_CNT; ++e) {
         const int g = e * 16 + l;
         x[e] = g < kcnt ? count_at(g) : 0;
     }
-    RCQ_STOP(10, code[0] ^ code[1] ^ code[2] ^ code[3] ^ code[4] ^ code[E_BASE - 5] ^ code[E_BASE - 4] ^ code[E_BASE - 3] ^ code[E_BASE - 2] ^ code[E_BASE - 1],
-             x[0] ^ x[1] ^ x[2] ^ x[3] ^ x[E_CNT - 4] ^ x[E_CNT - 3] ^ x[E_CNT - 2] ^ x[E_CNT - 1]);
 
-    // letter masks of the row's read as 32-bit words (bit p%32 of word p/32 = base p is the letter)
+    // letter masks of the row's read as 32-bit words (bit p%32 of word p/32 = base p is the letter); `other` != 0: the read has
+    // a letter outside ACGT
     uint32_t ma[E_BASE / 2 + 1], mt[E_BASE / 2 + 1];
+    uint32_t other = 0;
     int n_cnt = 0;
-    {
+    if constexpr (MS::present) {
+        const uint32_t w0 = msrc.lp >> 5, sh = msrc.lp & 31u;
+        uint32_t wa[E_BASE / 2 + 1], wt[E_BASE / 2 + 1], wb[E_BASE / 2 + 1];
+#pragma unroll
+        for (int j = 0; j <= E_BASE / 2; ++j) {
+            wa[j] = msrc.am[w0 + j];
+            wt[j] = msrc.tm[w0 + j];
+            wb[j] = msrc.bad[w0 + j];
+        }
+#pragma unroll
+        for (int j = 0; j < E_BASE / 2; ++j) {
+            const int left = len - 32 * j;  // bases of the read from bit 0 of this word on
+            const uint32_t lm = left >= 32 ? 0xffffffffu : (left > 0 ? (1u << left) - 1u : 0u);
+            ma[j] = __builtin_amdgcn_alignbit(wa[j + 1], wa[j], sh) & lm;
+            mt[j] = __builtin_amdgcn_alignbit(wt[j + 1], wt[j], sh) & lm;
+            other |= __builtin_amdgcn_alignbit(wb[j + 1], wb[j], sh) & lm;
+        }
+        ma[E_BASE / 2] = mt[E_BASE / 2] = 0;
+        if (__ballot(other != 0)) {  // (wave-uniform, rare) how many of them are N's   :1507-1510
+#pragma unroll
+            for (int e = 0; e < E_BASE; ++e) {
+                const int p = e * 16 + l;
+                n_cnt += __popc(row_bits(__ballot(p < len && base_at(p) == (uint32_t)'N'), row));
+            }
+        }
+    } else {
+        int code[E_BASE];
+#pragma unroll
+        for (int e = 0; e < E_BASE; ++e) {
+            const int p = e * 16 + l;
+            code[e] = p < len ? rc_base_code(base_at(p)) : 7;
+        }
         uint32_t fa[E_BASE], ft[E_BASE];
 #pragma unroll
         for (int e = 0; e < E_BASE; ++e) {
             fa[e] = row_bits(__ballot(code[e] == 0), row);
             ft[e] = row_bits(__ballot(code[e] == 3), row);
             n_cnt += __popc(row_bits(__ballot(code[e] == 4), row));
+            other |= row_bits(__ballot(code[e] >= 4 && e * 16 + l < len), row);
         }
 #pragma unroll
         for (int j = 0; j < E_BASE / 2; ++j) {
@@ -247,6 +300,7 @@ __device__ __forceinline__ int rcq_threshold_row(const rc_kernel_args &A, uint32
         }
         ma[E_BASE / 2] = mt[E_BASE / 2] = 0;
     }
+    RCQ_STOP(10, (int)other, n_cnt, x[0] ^ x[1] ^ x[2] ^ x[3] ^ x[E_CNT - 4] ^ x[E_CNT - 3] ^ x[E_CNT - 2] ^ x[E_CNT - 1]);
     int a_cnt = 0, t_cnt = 0;
 #pragma unroll
     for (int j = 0; j < E_BASE / 2; ++j) {
@@ -262,6 +316,7 @@ __device__ __forceinline__ int rcq_threshold_row(const rc_kernel_args &A, uint32
     int thr7 = 7;
     if (k / 2 > thr7) thr7 = k / 2;
     const uint32_t kmask = k >= 32 ? 0xffffffffu : ((1u << k) - 1u);
+    uint32_t not_polya2 = 0;  // bit e: window e * 16 + l has fewer than k - 2 A's and fewer than k - 2 T's (IsPolyA(.., 2) of the island code, :870-931)
 #pragma unroll
     for (int e = 0; e < E_CNT; ++e) {
         const int g = e * 16 + l;
@@ -269,7 +324,9 @@ __device__ __forceinline__ int rcq_threshold_row(const rc_kernel_args &A, uint32
         const uint32_t sh = (uint32_t)((e & 1) * 16 + l);
         const int a = __popc(__builtin_amdgcn_alignbit(ma[w + 1], ma[w], sh) & kmask);
         const int t = __popc(__builtin_amdgcn_alignbit(mt[w + 1], mt[w], sh) & kmask);
-        const bool polya = a >= k - thr7 || t >= k - thr7;
+        const int at = a > t ? a : t;
+        const bool polya = at >= k - thr7;
+        not_polya2 |= (at < k - 2 ? 1u : 0u) << e;
         x[e] = g < kcnt ? (polya ? -1 : x[e]) : 2147483647;
     }
     RCQ_STOP(12, (int)screened, x[0], x[1], x[2], x[3], x[E_CNT - 4], x[E_CNT - 3], x[E_CNT - 2], x[E_CNT - 1]);
@@ -404,17 +461,18 @@ __device__ __forceinline__ int rcq_threshold_row(const rc_kernel_args &A, uint32
     int cls = 1;
     if (A.cls) {
         int s = strong_self;
-        int t0 = rc_bound_i(s, A.P.error_rate);
+        int t0 = rcq_bound(A, s);
         bool flag = false;
         if (found && s >= 20 && prev == 2 && t0 < 3) {
             flag = true;
             t0 = 3;
         }
-        if (A.mode != 0) {
+        if (A.mode != 0) {  // (uniform)
             const int mate = __builtin_amdgcn_ds_bpermute((lane ^ 16) << 2, strong_self);
             const int pair_t = strong_self < mate ? strong_self : mate;
+            const int tp = rcq_bound(A, pair_t);
             if (pair_t >= 1 && s > pair_t) {
-                if (!flag || pair_t < 20) t0 = rc_bound_i(pair_t, A.P.error_rate);
+                if (!flag || pair_t < 20) t0 = tp;
                 s = pair_t;
             }
         }
@@ -436,13 +494,10 @@ __device__ __forceinline__ int rcq_threshold_row(const rc_kernel_args &A, uint32
 #pragma unroll
         for (int e = 0; e < E_CNT; ++e) {
             const int g = e * 16 + l;
-            const uint32_t shf = (uint32_t)((e & 1) * 16 + l);
-            const int na = __popc(__builtin_amdgcn_alignbit(ma[(e >> 1) + 1], ma[e >> 1], shf) & kmask);
-            const int nt = __popc(__builtin_amdgcn_alignbit(mt[(e >> 1) + 1], mt[e >> 1], shf) & kmask);
             y[e] = g < kcnt ? count_at(g) : 2147483647;
             rmin = y[e] < rmin ? y[e] : rmin;
             rmax = g < kcnt && y[e] > rmax ? y[e] : rmax;
-            tb[e] = row_bits(__ballot(g < kcnt && y[e] >= s && na < k - 2 && nt < k - 2), row);
+            tb[e] = row_bits(__ballot(g < kcnt && y[e] >= s && ((not_polya2 >> e) & 1u)), row);
             adj_bits |= tb[e] & (tb[e] >> 1);
             if (e > 0) adj_bits |= (tb[e - 1] >> 15) & tb[e];
         }
@@ -499,7 +554,7 @@ __device__ __forceinline__ int rcq_threshold_row(const rc_kernel_args &A, uint32
             }
         }
         RCQ_STOP(17, strong_self, prev, (int)found, s, t0, v0, vm, vh, (int)clean, (int)clean2, cls, (int)(tb[0] ^ tb[1] ^ tb[2] ^ tb[3] ^ tb[NTB - 4] ^ tb[NTB - 3] ^ tb[NTB - 2] ^ tb[NTB - 1]),
-                 code[0] ^ code[1] ^ code[2] ^ code[3] ^ code[4] ^ code[E_BASE - 5] ^ code[E_BASE - 4] ^ code[E_BASE - 3] ^ code[E_BASE - 2] ^ code[E_BASE - 1]);
+                 (int)other);
         // Candidate for k_single (rc_single.h, condition (2)): every letter ACGT, and the trusted mask -- counts >= s and
         // not poly-A at threshold 2 (:870-931) -- has no 1-run of length one and only 0-runs of exactly k, or of at most k
         // at either end of the read.  k_single checks it again (it needs the runs' positions anyway); this flag only keeps the
@@ -510,9 +565,6 @@ __device__ __forceinline__ int rcq_threshold_row(const rc_kernel_args &A, uint32
             if constexpr (E_CNT <= 12) {
                 constexpr int NW = (E_CNT + 3) / 4;  // 64-bit words of the mask
                 static_assert(4 * NW == NTB, "the trusted mask above");
-                uint32_t other = 0;
-#pragma unroll
-                for (int e = 0; e < E_BASE; ++e) other |= row_bits(__ballot(code[e] >= 4 && e * 16 + l < len), row);
                 if (!clean && !clean2 && !screened && other == 0 && kcnt >= 5) {
                     // T = the trusted mask, Z = its zero bits inside [0, kcnt); shifts run over the NW-word number
                     uint64_t T[NW], Z[NW], S[NW], E[NW];
@@ -536,29 +588,41 @@ __device__ __forceinline__ int rcq_threshold_row(const rc_kernel_args &A, uint32
                         nruns += __popcll(S[q]);
                     }
                     bool shape = any != 0 && iso == 0 && nruns >= 1 && nruns <= 3;
-                    uint32_t rr[3] = {0, 0, 0};  // per run: first k-mer | length << 8 (what k_single walks)
+                    // The runs' first and last k-mers: the (q + 1)-th set bit of S and of E, q < 3.  Every lane of the row holds
+                    // the same words, so the six extractions are dealt out to six lanes -- lane q takes run q's start, lane 4 + q
+                    // its end (clear the lowest set bit q times, then find the lowest) -- instead of every lane walking all six
+                    // (round 6: the walk was 190 of the row pass's 1 516 vector instructions).
+                    const int q = l & 3;
+                    uint64_t M[NW];
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        if (shape && q < nruns) {
-                            int z0 = 0, z1 = 0;
-                            bool got0 = false, got1 = false;
+                    for (int v = 0; v < NW; ++v) M[v] = (l & 4) ? E[v] : S[v];
 #pragma unroll
-                            for (int v = 0; v < NW; ++v) {
-                                if (!got0 && S[v]) {
-                                    z0 = 64 * v + __ffsll((long long)S[v]) - 1;
-                                    S[v] &= S[v] - 1;
-                                    got0 = true;
-                                }
-                                if (!got1 && E[v]) {
-                                    z1 = 64 * v + __ffsll((long long)E[v]) - 1;
-                                    E[v] &= E[v] - 1;
-                                    got1 = true;
-                                }
-                            }
-                            shape = z1 - z0 + 1 == k || ((z0 == 0 || z1 == kcnt - 1) && z1 - z0 + 1 < k);
-                            rr[q] = (uint32_t)z0 | ((uint32_t)(z1 - z0 + 1) << 8);
+                    for (int i = 0; i < 2; ++i) {
+                        bool done = i >= q;
+#pragma unroll
+                        for (int v = 0; v < NW; ++v) {
+                            const bool here = !done && M[v] != 0;
+                            M[v] = here ? (M[v] & (M[v] - 1)) : M[v];
+                            done = done || here;
                         }
                     }
+                    int z = 0;
+                    {
+                        bool got = false;
+#pragma unroll
+                        for (int v = 0; v < NW; ++v) {
+                            const bool here = !got && M[v] != 0;
+                            z = here ? 64 * v + __ffsll((long long)M[v]) - 1 : z;
+                            got = got || here;
+                        }
+                    }
+                    const int z0 = z, z1 = dpp<0x104>(z);  // row_shl:4 -- lane q reads lane q + 4
+                    const int rl = z1 - z0 + 1;
+                    const bool mine = q < nruns && l < 3;
+                    const bool good = rl == k || ((z0 == 0 || z1 == kcnt - 1) && rl < k);
+                    shape = shape && row_bits(__ballot(mine && !good), row) == 0;
+                    const int rrq = mine ? (int)((uint32_t)z0 | ((uint32_t)rl << 8)) : 0;  // per run: first k-mer | length << 8 (what k_single walks)
+                    const uint32_t rr[3] = {(uint32_t)rrq, (uint32_t)dpp<0x101>(rrq), (uint32_t)dpp<0x102>(rrq)};  // (lane 0: its own, lane 1's, lane 2's)
                     cand = shape;
                     cand_runs = nruns;
                     if (cand && live && l == 0) A.runs[r] = make_uint2(rr[0] | (rr[1] << 16), rr[2] | ((uint32_t)nruns << 16));

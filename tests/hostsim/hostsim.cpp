@@ -203,6 +203,7 @@ void hostsim_correct_batch(const rco_params *p, const rco_table *t, rco_batch *b
     rc_bound_steps_build(P.error_rate, bsteps.data());
     for (int v = 0; v < RC_BS_INLINE; ++v) P.bs[v] = bsteps[v];
     P.bs_ext = getenv("HOSTSIM_NO_BS_EXT") ? nullptr : bsteps.data();
+    P.bound_small = nullptr;
     P.flags = getenv("HOSTSIM_NO_ALT") ? RC_PF_NO_ALT : 0;
     Buffers B(RC_MAX_READ_LENGTH + 64);
     HostWave w;

@@ -363,9 +363,10 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("config", [1, 3, 4])
+@pytest.mark.parametrize("config", [1, 2, 3, 4])
 def test_full_size_presets_match_the_oracle_on_a_sample(config):
-    """BASELINE.json configs[1], [3] and [4] at FULL size (configs[2] is the driver's default bench run): 10 M x 100 bp,
+    """BASELINE.json configs[1] to [4] at FULL size (configs[2], the headline shard of 25 M x 150 bp pairs, also has the
+    exhaustive test below): 10 M x 100 bp,
     50 M x 150 bp with the skewed spectrum, 100 M x 150 bp at k = 31 / maxcorK 8 / 5 % errors over the 871 M-k-mer table
     counted from all of them -- one timed step each through bench.py, then the oracle with the same table on three strata of
     the whole shard (bench.py: parity_strata): the first 100 000 reads, 100 000 drawn across every device arena by a seeded
@@ -383,7 +384,7 @@ def test_full_size_presets_match_the_oracle_on_a_sample(config):
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["config"]["preset"] == config and d["n_gpus"] == 1
-    assert d["config"]["reads_per_gpu"] == {1: 10_000_000, 3: 50_000_000, 4: 100_000_000}[config]
+    assert d["config"]["reads_per_gpu"] == {1: 10_000_000, 2: 25_000_000, 3: 50_000_000, 4: 100_000_000}[config]
     cb = d["cpu_baseline"]
     assert cb["gpu_matches_oracle_on_sample"] is True, cb
     st = cb["strata"]
@@ -391,6 +392,48 @@ def test_full_size_presets_match_the_oracle_on_a_sample(config):
     assert st["first"]["reads"] == 100_000 and abs(st["stride"]["reads"] - 100_000) < 200
     assert st["heavy"]["reads"] >= 1000 and st["heavy"]["max_gather_rounds"] == cb["worst_read_gather_rounds"] > st["first"]["max_gather_rounds"] - 1
     assert cb["instrumented_build_same_ret"] is True and "seeded stride" in cb["sample"] and d["config"]["reads_corrected_frac"] > 0.2
+
+
+@pytest.mark.gpu
+def test_every_read_of_the_headline_shard_matches_the_oracle():
+    """The workload the bench line is quoted on, exhaustively: all 25 000 000 reads of the headline shard (BASELINE.json
+    configs[2]: 150 bp pairs, k = 23) through the kernels the bench times, then the oracle -- all host cores, the same table --
+    on every one of them: return values, l / m / h and corrected bases (`bench.py --parity-only --parity-full`)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--config", "2", "--steps", "1", "--warmup", "0",
+           "--parity-only", "--parity-full", "--cpu-sample", "200000"]
+    p = subprocess.run(cmd, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    d = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][0])
+    cb = d["cpu_baseline"]
+    assert d["config"]["preset"] == 2 and d["config"]["reads_per_gpu"] == 25_000_000
+    assert cb["whole_shard"] is True and cb["strata"]["first"]["reads"] == 25_000_000, cb
+    assert cb["gpu_matches_oracle_on_sample"] is True and all(v["identical"] for v in cb["strata"].values()), cb
+    assert cb["instrumented_build_same_ret"] is True and cb["strata"]["first"]["corrected_reads"] > 5_000_000
+
+
+@pytest.mark.gpu
+def test_bench_without_a_launcher_runs_the_ranks_it_was_asked_for():
+    """`python bench.py --gpus 2` with no launcher in front (round-5 review: it used to measure ONE GPU and print n_gpus 1):
+    the process re-launches itself under torch.distributed.run -- here with both ranks on GPU 0 (RC_BENCH_SHARED_GPU=1) --
+    and the one line that comes out is the two-rank one."""
+    args = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--reads", "400000", "--n-tx", "2000", "--cpu-sample", "0"]
+    env = {kk: v for kk, v in os.environ.items() if kk not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, cwd=root, env=dict(env, RC_BENCH_SHARED_GPU="1"),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["multi_gpu"]["world_size_seen"] == 2 and len(d["multi_gpu"]["ranks"]) == 2
+    assert "x2" in d["config"]["parallelism"] and b"re-running as" in p.stderr
 
 
 @pytest.mark.gpu

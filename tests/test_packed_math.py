@@ -25,3 +25,15 @@ def test_bound_steps_table_equals_bisection(tmp_path):
     p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     out = p.stdout.decode()
     assert p.returncode == 0 and out.rstrip().endswith("ok") and " 0 differences" in out, out
+
+
+def test_pack16m_swar_equals_its_definition(tmp_path):
+    """rc_pack16m (the fused probe kernel's staging: 16 arena bytes -> 2-bit codes + A / T / not-ACGT masks, four bytes per
+    operation) against the per-byte definition: every byte value in every position in front of seven backgrounds, and
+    two million random blocks"""
+    exe = str(tmp_path / "pack16m")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "rcorrector_amd", "csrc"),
+                    os.path.join(ROOT, "tests", "hostmath", "pack16m.cpp"), "-o", exe], check=True)
+    p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+    out = p.stdout.decode()
+    assert p.returncode == 0 and out.startswith("ok "), out
