@@ -144,10 +144,23 @@ int rc_launch_kmer_info(rc_ctx *ctx, const rc_device_batch_args &a);
 // EC = count registers per lane of the threshold rows (rc_quarter.h): 8 for reads of up to 128 k-mers, 9 for 144 (151-base
 // reads at k = 23), 10 for every read of up to 160 bases.  A read the tier of this launch does not hold (rc_kernel_args::
 // tier_lo / tier_hi: a longer read, or the mate of one) is left out -- no bases copied, no counts, cls = 0.
-template <int RC_FUSED_TILE, int WAVES, bool EXT, int EC = 8>
+// DEDUP = slots of the workgroup's k-mer set (0: none).  The list puts reads that share their minimal m-mer next to each other,
+// so the 16 reads of a tile overlap: 73 % of a tile's probes ask for a k-mer another position of the tile asks for as well
+// (tools/exp/tile_duplicates.py), and the probe loop is bound by requests -- to the L2, whose channels a tile's 2 048 random
+// buckets keep busy even when every line is there (19 of its 28 ms with a table that fits the L2), and behind it to the fabric
+// (0.45 misses per probe: a tile's working set is 128 KB, six tiles a CU, 4 MB of L2 an XCD).  So every position first enters
+// its canonical k-mer into an open-addressed set in LDS (a 64-bit compare-and-swap: the first to arrive owns the slot), the
+// owners' k-mers -- a compact list -- are looked up, one bucket read per distinct k-mer of the tile, and every position takes
+// its count from its slot.  A k-mer that finds no slot within four steps is looked up on the spot.
+template <int RC_FUSED_TILE, int WAVES, bool EXT, int EC = 8, int DEDUP = 0>
 __global__ __launch_bounds__(RC_PROBE_THREADS) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_probe_threshold_list(rc_kernel_args A, size_t nbytes, const uint32_t *__restrict__ list,
                                                                            uint32_t reads_per_block, int32_t *__restrict__ counts)
 {
+    constexpr int NS = DEDUP ? DEDUP : 1;
+    __shared__ unsigned long long s_key[NS];
+    __shared__ int32_t s_val[NS];
+    __shared__ uint16_t s_own[NS];
+    __shared__ uint32_t s_nown;
     __shared__ __attribute__((aligned(16))) uint32_t s_raw[(RC_FUSED_TILE + 64) / 4];
     __shared__ uint32_t s_code[RC_FUSED_TILE / 16 + 4];
     // letter masks of the arena, bit p % 32 of word p / 32 = arena byte p (rc_pack16m): not one of ACGT / an A / a T
@@ -160,6 +173,10 @@ __global__ __launch_bounds__(RC_PROBE_THREADS) __attribute__((amdgpu_waves_per_e
     const uint32_t i0 = blockIdx.x * reads_per_block;
     const uint32_t nr = A.n - i0 < reads_per_block ? A.n - i0 : reads_per_block;
     for (int c = t; c < (RC_FUSED_TILE + 64) / 4; c += RC_PROBE_THREADS) s_raw[c] = 0;
+    if constexpr (DEDUP != 0) {
+        for (int c = t; c < NS; c += RC_PROBE_THREADS) s_key[c] = ~0ull;  // (no canonical code is all ones: TT..T is the larger strand of AA..A)
+        if (t == 0) s_nown = 0;
+    }
     if ((uint32_t)t < nr) {
         const uint32_t r = list[i0 + t], g0 = A.off[r];
         s_rid[t] = r;
@@ -249,6 +266,45 @@ __global__ __launch_bounds__(RC_PROBE_THREADS) __attribute__((amdgpu_waves_per_e
 #ifndef RC_PROBE_UNROLL
 #define RC_PROBE_UNROLL 2
 #endif
+    if constexpr (DEDUP != 0) {
+        for (uint32_t a = 4 + (uint32_t)t; a + (uint32_t)k <= total; a += RC_PROBE_THREADS) {  // every position enters its k-mer into the set
+            const int mw = a >> 5;
+            int cnt = 0;
+            if (!(__builtin_amdgcn_alignbit(m_bad[mw + 1], m_bad[mw], (uint32_t)a & 31u) & kmask)) {
+                const int cw = a >> 4, cs = 2 * (a & 15);
+                const uint64_t x = ((((uint64_t)s_code[cw] << 32) | s_code[cw + 1]) << cs) | (((uint64_t)s_code[cw + 2] << cs) >> 32);
+                const uint64_t canon = rc_canonical_dev(x >> (64 - 2 * k), k);
+                uint32_t h = (((uint32_t)canon * 0x9E3779B1u) ^ ((uint32_t)(canon >> 32) * 0x85EBCA77u)) >> (32 - rcq::ilog2(NS));
+                int slot = -1;
+                bool own = false;
+#pragma unroll 1
+                for (int tr = 0; tr < 4; ++tr) {
+                    const unsigned long long old = atomicCAS(&s_key[h], ~0ull, (unsigned long long)canon);
+                    if (old == ~0ull || old == canon) {
+                        own = old == ~0ull;
+                        slot = (int)h;
+                        break;
+                    }
+                    h = (h + 1u) & (uint32_t)(NS - 1);
+                }
+                if (own) s_own[atomicAdd(&s_nown, 1u)] = (uint16_t)slot;
+                cnt = slot >= 0 ? -1 - slot : rc_table_lookup<EXT>(A.T, canon);  // (no slot within four steps: a crowded set)
+            }
+            s_cnt[a] = cnt;
+        }
+        __syncthreads();
+        const uint32_t nown = s_nown;
+#pragma unroll RC_PROBE_UNROLL
+        for (uint32_t i = (uint32_t)t; i < nown; i += RC_PROBE_THREADS) {  // one bucket read per distinct k-mer of the tile
+            const uint32_t slot = s_own[i];
+            s_val[slot] = rc_table_lookup<EXT>(A.T, (uint64_t)s_key[slot]);
+        }
+        __syncthreads();
+        for (uint32_t a = 4 + (uint32_t)t; a + (uint32_t)k <= total; a += RC_PROBE_THREADS) {
+            const int v = s_cnt[a];
+            if (v < 0) s_cnt[a] = s_val[-1 - v];
+        }
+    } else {
 #pragma unroll RC_PROBE_UNROLL
     for (uint32_t a = 4 + (uint32_t)t; a + (uint32_t)k <= total; a += RC_PROBE_THREADS) {  // probe: counts stay in LDS
         // a window with a letter outside ACGT -- the NUL behind a read included: a position that is no k-mer of any read -- counts 0
@@ -260,6 +316,7 @@ __global__ __launch_bounds__(RC_PROBE_THREADS) __attribute__((amdgpu_waves_per_e
             cnt = rc_table_lookup<EXT>(A.T, rc_canonical_dev(x >> (64 - 2 * k), k));
         }
         s_cnt[a] = cnt;
+    }
     }
     __syncthreads();
     RC_FUSED_CUT(3, s_cnt[t] ^ s_cnt[t + 256] ^ s_cnt[t + 512] ^ s_cnt[t + 768] ^ s_cnt[t + 1024] ^ s_cnt[t + 1280] ^ s_cnt[t + 1536] ^ s_cnt[t + 1792] ^ s_cnt[t + 2048] ^ s_cnt[t + 2304] ^ s_cnt[t + 2560]);
@@ -480,13 +537,20 @@ int rc_launch_probe_threshold_list(rc_ctx *ctx, const rc_device_batch_args &a, s
     const dim3 grid((a.n + rpb - 1) / rpb), block(RC_PROBE_THREADS);
     const uint32_t *list = (const uint32_t *)ctx->loc_list.p;
     int32_t *counts = (int32_t *)ctx->counts.p;
-#define RC_FUSED_LAUNCH(TILE, WAVES, EXT, EC) \
-    hipLaunchKernelGGL((k_probe_threshold_list<TILE, WAVES, EXT, EC>), grid, block, 0, ctx->stream, A, nbytes, list, rpb, counts)
-    if (large) {  // (reads of up to 119 bases: at most 116 k-mers)
+    // the tile's k-mer set (DEDUP): 1 024 slots = 14 KB of LDS more, five workgroups a CU; RC_FUSED_DEDUP=0 probes every position
+    const bool dedup = !ctx->env_no_dedup;
+#define RC_FUSED_LAUNCH(TILE, WAVES, EXT, EC)                                                                                                        \
+    do {                                                                                                                                             \
+        if (dedup)                                                                                                                                   \
+            hipLaunchKernelGGL((k_probe_threshold_list<TILE, 5, EXT, EC, 1024>), grid, block, 0, ctx->stream, A, nbytes, list, rpb, counts);         \
+        else                                                                                                                                         \
+            hipLaunchKernelGGL((k_probe_threshold_list<TILE, WAVES, EXT, EC, 0>), grid, block, 0, ctx->stream, A, nbytes, list, rpb, counts);        \
+    } while (0)
+    if (large) {  // (reads of up to 119 bases: at most 116 k-mers; 32 reads a tile: their k-mers would want a set of 2 048 slots -- not built)
         if (ctx->ext)
-            RC_FUSED_LAUNCH(4096, 6, true, 8);
+            hipLaunchKernelGGL((k_probe_threshold_list<4096, 6, true, 8, 0>), grid, block, 0, ctx->stream, A, nbytes, list, rpb, counts);
         else
-            RC_FUSED_LAUNCH(4096, 6, false, 8);
+            hipLaunchKernelGGL((k_probe_threshold_list<4096, 6, false, 8, 0>), grid, block, 0, ctx->stream, A, nbytes, list, rpb, counts);
     } else if (ec == 8) {
         if (ctx->ext)
             RC_FUSED_LAUNCH(2816, RC_FUSED_SMALL_WAVES, true, 8);

@@ -136,6 +136,7 @@ struct rc_ctx {
     rc_dbuf loc_a, loc_list;  // locality order of a batch (rc_launch_locality_order)
     rc_dbuf tier_flag, tier_list;  // mixed-length batches: the reads of the middle / long tier in locality order (rc_launch_tier_lists)
     size_t tier_stride = 0;        // uint32 entries between the two sections of tier_list
+    bool env_no_dedup = false;  // RC_FUSED_DEDUP=0 (dev / tests): the fused probe kernel looks every position up, no per-tile k-mer set
     bool env_no_fuse = false;  // RC_NO_FUSE=1 (dev): separate probe and threshold kernels in locality order too
     int env_force_ec = 0;      // RC_FORCE_EC=9|10 (dev / tests): at least this many count registers per lane in the 160-base instances
     bool env_no_tier = false;  // RC_NO_TIER=1 (dev / tests): no length tiers, the longest read of a batch decides every kernel
