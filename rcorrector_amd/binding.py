@@ -117,7 +117,8 @@ def load_library():
     L.rc_table_count_park.argtypes = [vp]
     L.rc_table_count_finish_sharded.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.POINTER(C.c_int64)]
     L.rc_set_slot_lanes.argtypes = [vp, C.c_int]
-    L.rc_runtime_prepare.argtypes = [C.c_int]
+    if hasattr(L, "rc_runtime_prepare"):   # (RC_LIB may name a library of an earlier round: tools/ab.sh)
+        L.rc_runtime_prepare.argtypes = [C.c_int]
     L.rc_submit_resident.argtypes = [vp, C.POINTER(_ResidentBatch), C.c_int]
     L.rc_wait_resident.argtypes = [vp, C.c_int]
     L.rc_table_write_jfdump.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64)]

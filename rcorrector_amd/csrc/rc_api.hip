@@ -204,7 +204,10 @@ rc_ctx *rc_create(const rc_config *cfg, char *errbuf, size_t errbuf_len)
     ctx->env_no_classify = getenv("RC_NO_CLASSIFY") != nullptr;            // dev: every read goes through k_correct
     ctx->env_timing = getenv("RC_TIMING") != nullptr;
     ctx->env_no_fuse = getenv("RC_NO_FUSE") != nullptr;
-    if (const char *dd = getenv("RC_FUSED_DEDUP")) ctx->env_no_dedup = atoi(dd) == 0;
+    if (const char *dd = getenv("RC_FUSED_DEDUP")) ctx->env_dedup = atoi(dd) != 0 ? 1 : 0;
+    if (const char *xo = getenv("RC_FUSED_XCD")) ctx->env_fused_xcd = atoi(xo) != 0;
+    if (const char *qd = getenv("RC_PROBE_QUAD")) ctx->env_quad = atoi(qd) != 0 ? 1 : 0;
+    if (const char *kl = getenv("RC_K3_LOCAL")) ctx->env_k3_local = atoi(kl) != 0;
     ctx->env_no_tier = getenv("RC_NO_TIER") != nullptr;
     if (const char *e = getenv("RC_FORCE_EC")) {
         const int v = atoi(e);

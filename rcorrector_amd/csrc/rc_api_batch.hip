@@ -62,6 +62,7 @@ int rc_correct_device_impl(rc_ctx *ctx, const rc_device_batch *b, uint32_t qual_
     a.max_len = b->max_read_len;
     // the reads the threshold kernel could not finish, as a work list; isolated substitutions are finished four reads to
     // a wave first (rc_single.h: it clears their cls), what is left is k_correct's list
+    bool loc_order_valid = false;  // ctx->loc_list holds this batch's locality order (every read once) and no length tiers are in play
     auto single_and_compact = [&](const rc_device_batch_args &at) -> int {
         if (!ctx->cls_ready) return RC_OK;
         ctx->work_stride = ((size_t)at.n + 63) & ~(size_t)63;
@@ -69,6 +70,9 @@ int rc_correct_device_impl(rc_ctx *ctx, const rc_device_batch *b, uint32_t qual_
         if ((e = rc_dbuf_reserve(ctx, &ctx->worklist, ctx->work_stride * RC_WORK_CLASSES * 4 + 256))) return e;
         bool ran = false;
         if ((e = rc_launch_single(ctx, at, &ran))) return e;
+        if (ctx->env_k3_local && loc_order_valid)
+            return rc_launch_compact_local(ctx, (const uint8_t *)ctx->cls.p, at.n, (uint32_t *)ctx->worklist.p, ctx->work_stride,
+                                           (uint32_t *)((char *)ctx->work.p + RC_WORK_NWORK_OFF));
         return rc_launch_compact(ctx, (const uint8_t *)ctx->cls.p, at.n, (uint32_t *)ctx->worklist.p, ctx->work_stride,
                                  (uint32_t *)((char *)ctx->work.p + RC_WORK_NWORK_OFF));
     };
@@ -139,6 +143,7 @@ int rc_correct_device_impl(rc_ctx *ctx, const rc_device_batch *b, uint32_t qual_
     }
     if (locality) {
         if ((rc = rc_launch_locality_order(ctx, a, (size_t)b->nbytes))) return rc;
+        loc_order_valid = true;
         // probe + threshold + classification in one kernel where the reads fit it
         if ((rc = rc_launch_probe_threshold_list(ctx, a, (size_t)b->nbytes, &fused))) return rc;
         if (!fused && (rc = rc_launch_probe_list(ctx, a, (size_t)b->nbytes, (int32_t *)ctx->counts.p))) return rc;

@@ -152,9 +152,10 @@ int rc_launch_kmer_info(rc_ctx *ctx, const rc_device_batch_args &a);
 // its canonical k-mer into an open-addressed set in LDS (a 64-bit compare-and-swap: the first to arrive owns the slot), the
 // owners' k-mers -- a compact list -- are looked up, one bucket read per distinct k-mer of the tile, and every position takes
 // its count from its slot.  A k-mer that finds no slot within four steps is looked up on the spot.
-template <int RC_FUSED_TILE, int WAVES, bool EXT, int EC = 8, int DEDUP = 0>
+// QUAD: the probes go through rc_table_lookup_quad (rc_device.h: four lanes read a bucket together)
+template <int RC_FUSED_TILE, int WAVES, bool EXT, int EC = 8, int DEDUP = 0, bool QUAD = false>
 __global__ __launch_bounds__(RC_PROBE_THREADS) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_probe_threshold_list(rc_kernel_args A, size_t nbytes, const uint32_t *__restrict__ list,
-                                                                           uint32_t reads_per_block, int32_t *__restrict__ counts)
+                                                                           uint32_t reads_per_block, int32_t *__restrict__ counts, uint32_t tiles_per_xcd)
 {
     constexpr int NS = DEDUP ? DEDUP : 1;
     __shared__ unsigned long long s_key[NS];
@@ -170,7 +171,11 @@ __global__ __launch_bounds__(RC_PROBE_THREADS) __attribute__((amdgpu_waves_per_e
     __shared__ uint8_t s_cls[RC_PLIST_MAX_READS];
     const int t = threadIdx.x, k = A.P.k;  // (an instance compiled for k = 23 was measured and dropped: 46.0 vs 41.9 ms)
     const uint8_t *seq = A.seq;
-    const uint32_t i0 = blockIdx.x * reads_per_block;
+    // tiles_per_xcd != 0 (RC_FUSED_XCD=1): workgroup b runs on XCD b % 8, so tile (b % 8) * tiles_per_xcd + b / 8 hands each XCD's L2
+    // one contiguous stretch of the locality list (neighbouring tiles share most of their k-mers)
+    const uint32_t tile = tiles_per_xcd ? (blockIdx.x & 7u) * tiles_per_xcd + (blockIdx.x >> 3) : blockIdx.x;
+    if ((uint64_t)tile * reads_per_block >= A.n) return;  // (uniform: the last XCD's stretch may be short)
+    const uint32_t i0 = tile * reads_per_block;
     const uint32_t nr = A.n - i0 < reads_per_block ? A.n - i0 : reads_per_block;
     for (int c = t; c < (RC_FUSED_TILE + 64) / 4; c += RC_PROBE_THREADS) s_raw[c] = 0;
     if constexpr (DEDUP != 0) {
@@ -198,14 +203,21 @@ __global__ __launch_bounds__(RC_PROBE_THREADS) __attribute__((amdgpu_waves_per_e
         if (other) s_len1[t] = 0;  // 0 = not a read of this launch
         __syncthreads();
     }
-    if (t == 0) {  // local start of each read: same alignment modulo 4 as in memory, a NUL in front
-        uint32_t lp = 4;
-        for (uint32_t j = 0; j < nr; ++j) {
-            lp = ((lp + 3u) & ~3u) + (s_gpos[j] & 3u);
-            s_lpos[j] = lp;
-            lp += s_len1[j];
+    // local start of each read: same alignment modulo 4 as in memory, a NUL in front.  Read j starts at base_j + (gpos_j & 3) with
+    // base_0 = 4 and base_{j+1} = base_j + (((gpos_j & 3) + len1_j + 3) & ~3): a prefix sum, done by the first wave (round 6: one
+    // thread used to walk the reads while 255 waited at the barrier)
+    if (t < 64) {
+        const bool in = (uint32_t)t < nr;
+        const uint32_t sj = in ? (s_gpos[t] & 3u) + s_len1[t] : 0u;
+        uint32_t inc = (sj + 3u) & ~3u;  // inclusive scan over the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(inc, o, 64);
+            inc += t >= o ? up : 0u;
         }
-        s_lpos[nr] = lp;
+        const uint32_t base = 4u + inc - ((sj + 3u) & ~3u);
+        if (in) s_lpos[t] = base + (s_gpos[t] & 3u);
+        if ((uint32_t)t + 1 == nr) s_lpos[nr] = base + sj;  // the end of the last read
     }
     __syncthreads();
 #define RC_FUSED_CUT(n, v)                                                       \
@@ -303,6 +315,22 @@ __global__ __launch_bounds__(RC_PROBE_THREADS) __attribute__((amdgpu_waves_per_e
         for (uint32_t a = 4 + (uint32_t)t; a + (uint32_t)k <= total; a += RC_PROBE_THREADS) {
             const int v = s_cnt[a];
             if (v < 0) s_cnt[a] = s_val[-1 - v];
+        }
+    } else if (QUAD) {
+        // probe, the four lanes of a quad reading each bucket together (rc_table_lookup_quad): the loop's trip count is the
+        // wavefront's, not the lane's -- a lane past the end of the arena still lends its loads
+#pragma unroll RC_PROBE_UNROLL
+        for (uint32_t a0 = 4 + ((uint32_t)t & ~63u); a0 + (uint32_t)k <= total; a0 += RC_PROBE_THREADS) {
+            const uint32_t a = a0 + ((uint32_t)t & 63u);
+            const bool inside = a + (uint32_t)k <= total;
+            const uint32_t ac = inside ? a : 4u;  // (keeps the LDS reads of a lane past the end inside the arrays)
+            const int mw = ac >> 5;
+            // a window with a letter outside ACGT -- the NUL behind a read included: a position that is no k-mer of any read -- counts 0
+            const bool valid = inside && !(__builtin_amdgcn_alignbit(m_bad[mw + 1], m_bad[mw], ac & 31u) & kmask);
+            const int cw = ac >> 4, cs = 2 * (ac & 15);
+            const uint64_t x = ((((uint64_t)s_code[cw] << 32) | s_code[cw + 1]) << cs) | (((uint64_t)s_code[cw + 2] << cs) >> 32);
+            const int cnt = rc_table_lookup_quad<EXT>(A.T, rc_canonical_dev(x >> (64 - 2 * k), k), valid);
+            if (inside) s_cnt[a] = cnt;
         }
     } else {
 #pragma unroll RC_PROBE_UNROLL
@@ -534,23 +562,35 @@ int rc_launch_probe_threshold_list(rc_ctx *ctx, const rc_device_batch_args &a, s
     const uint32_t rpb = large ? fit(4096) : fit(2816);
     if (rpb == 0) return RC_OK;  // (not reached: 16 reads of 160 bases fit)
     rc_timer_begin(ctx);
-    const dim3 grid((a.n + rpb - 1) / rpb), block(RC_PROBE_THREADS);
+    const uint32_t n_tiles = (a.n + rpb - 1) / rpb;
+    const uint32_t txcd = ctx->env_fused_xcd ? (n_tiles + 7) / 8 : 0;
+    const dim3 grid(txcd ? txcd * 8 : n_tiles), block(RC_PROBE_THREADS);
     const uint32_t *list = (const uint32_t *)ctx->loc_list.p;
     int32_t *counts = (int32_t *)ctx->counts.p;
-    // the tile's k-mer set (DEDUP): 1 024 slots = 14 KB of LDS more, five workgroups a CU; RC_FUSED_DEDUP=0 probes every position
-    const bool dedup = !ctx->env_no_dedup;
+    // Three ways of cutting the probes' requests were built and measured in round 6 (profiles/r6_fused_where_the_time_goes.txt);
+    // none pays on the bench presets, all are parity-green and stay behind their switches (tests: knob matrix):
+    //  * RC_FUSED_DEDUP=1, the tile's k-mer set: L2 requests -47 %, fabric requests -18 % -- and config 2 41.4 -> 46.9 ms, config 3
+    //    62.5 -> 71.0 (two barriers, an LDS compare-and-swap per position, five workgroups a CU instead of six); config 4 411.7 ->
+    //    366.8 ms in one call, 413.0 -> 411.7 in another;
+    //  * RC_FUSED_XCD=1, tiles in XCD-contiguous order: fabric requests -37 % (1.42 -> 0.91 G), the kernel's time unchanged;
+    //  * RC_PROBE_QUAD=1, a quad of lanes per bucket (rc_table_lookup_quad): +23 % on L2 hits and 2.1 x beyond the TLB's reach in
+    //    tools/microbench_bucket.hip, but 57 more vector instructions per probe here: config 2 41.2 -> 47.0 ms, config 3 62.5 -> 77.4.
+    const bool dedup = ctx->env_dedup > 0;
+    const bool quad = ctx->env_quad > 0;
 #define RC_FUSED_LAUNCH(TILE, WAVES, EXT, EC)                                                                                                        \
     do {                                                                                                                                             \
         if (dedup)                                                                                                                                   \
-            hipLaunchKernelGGL((k_probe_threshold_list<TILE, 5, EXT, EC, 1024>), grid, block, 0, ctx->stream, A, nbytes, list, rpb, counts);         \
+            hipLaunchKernelGGL((k_probe_threshold_list<TILE, 5, EXT, EC, 1024>), grid, block, 0, ctx->stream, A, nbytes, list, rpb, counts, txcd);         \
+        else if (quad)                                                                                                                               \
+            hipLaunchKernelGGL((k_probe_threshold_list<TILE, WAVES, EXT, EC, 0, true>), grid, block, 0, ctx->stream, A, nbytes, list, rpb, counts, txcd);  \
         else                                                                                                                                         \
-            hipLaunchKernelGGL((k_probe_threshold_list<TILE, WAVES, EXT, EC, 0>), grid, block, 0, ctx->stream, A, nbytes, list, rpb, counts);        \
+            hipLaunchKernelGGL((k_probe_threshold_list<TILE, WAVES, EXT, EC, 0>), grid, block, 0, ctx->stream, A, nbytes, list, rpb, counts, txcd);        \
     } while (0)
     if (large) {  // (reads of up to 119 bases: at most 116 k-mers; 32 reads a tile: their k-mers would want a set of 2 048 slots -- not built)
         if (ctx->ext)
-            hipLaunchKernelGGL((k_probe_threshold_list<4096, 6, true, 8, 0>), grid, block, 0, ctx->stream, A, nbytes, list, rpb, counts);
+            hipLaunchKernelGGL((k_probe_threshold_list<4096, 6, true, 8, 0>), grid, block, 0, ctx->stream, A, nbytes, list, rpb, counts, txcd);
         else
-            hipLaunchKernelGGL((k_probe_threshold_list<4096, 6, false, 8, 0>), grid, block, 0, ctx->stream, A, nbytes, list, rpb, counts);
+            hipLaunchKernelGGL((k_probe_threshold_list<4096, 6, false, 8, 0>), grid, block, 0, ctx->stream, A, nbytes, list, rpb, counts, txcd);
     } else if (ec == 8) {
         if (ctx->ext)
             RC_FUSED_LAUNCH(2816, RC_FUSED_SMALL_WAVES, true, 8);

@@ -32,8 +32,10 @@ __device__ inline int rc_packed_overflow_count(const rc_table_view &T, uint64_t 
 // both ways: the masks become constants and the extra multiply of rc_packed_addr disappears)
 // orient: canon or its reverse complement -- the orientation in which the caller's neighbours differ in the LAST base (a
 // search node's four extensions), for the "core" filter of rc_common.h; callers without such neighbours pass canon
+// disp0 (PACKED, rc_table_lookup_quad's straggler path): the walk starts at the disp0-th bucket behind the home bucket -- the ones
+// in front of it have been looked at, and so has the filter
 template <bool EXT = true, bool SEARCH = false>
-__device__ __forceinline__ int rc_table_lookup_o(const rc_table_view &T, uint64_t canon, uint64_t orient, uint32_t *n_req = nullptr)
+__device__ __forceinline__ int rc_table_lookup_o(const rc_table_view &T, uint64_t canon, uint64_t orient, uint32_t *n_req = nullptr, uint32_t disp0 = 0)
 {
     // The slots are compared as 64-bit words, from the last slot to the first, so that the first slot in
     // probe order is assigned last and wins without a test (two instructions per slot: the probe
@@ -45,7 +47,8 @@ __device__ __forceinline__ int rc_table_lookup_o(const rc_table_view &T, uint64_
 #ifdef RC_EXP_ADDR_WINDOW  // dev (tools/exp/addr_window.md): every probe lands in the first RC_EXP_ADDR_WINDOW buckets -- WRONG counts; what
         b &= (RC_EXP_ADDR_WINDOW - 1);  // the probe kernel would cost if the table's lines were always in the L2 / Infinity Cache
 #endif
-        if (T.filter && (SEARCH || T.filter_all)) {  // (wave-uniform) most misses end at one word of the filter
+        b += disp0;
+        if (disp0 == 0 && T.filter && (SEARCH || T.filter_all)) {  // (wave-uniform) most misses end at one word of the filter
             if (T.filter_kind) {
                 uint32_t fw, fm;
                 rc_filter_core_addr(orient, T.filter_words, &fw, &fm);
@@ -58,13 +61,17 @@ __device__ __forceinline__ int rc_table_lookup_o(const rc_table_view &T, uint64_
         const uint32_t cmask = RC_PACKED_COUNT_MASK >> ext;  // (uniform)
         const uint32_t mhi = 0x7FFFFFFFu & ~cmask;
         const uint32_t xhi = xrem << (27 - ext);
-        for (uint32_t disp = 0;; ++disp, ++b) {
+        for (uint32_t disp = disp0;; ++disp, ++b) {
             const uint4 *p = reinterpret_cast<const uint4 *>(T.buckets + (size_t)b * RC_BUCKET_DWORDS);
             uint32_t dlo[RC_PACKED_SLOTS], dhi[RC_PACKED_SLOTS];
             if (n_req) ++*n_req;
 #pragma unroll
             for (int q = 0; q < RC_BUCKET_DWORDS / 4; ++q) {
+#ifdef RC_EXP_BUCKET_LOADS  // dev (WRONG counts): only the first RC_EXP_BUCKET_LOADS of a bucket's four 16-byte loads are issued -- what do the
+                const uint4 v = q < RC_EXP_BUCKET_LOADS ? p[q] : make_uint4(0, 0x78000000u, 0, 0x78000000u);  // vector L1's address / tag stages cost the probe kernels?
+#else
                 const uint4 v = p[q];
+#endif
                 dlo[2 * q + 0] = v.x;
                 dhi[2 * q + 0] = v.y;
                 dlo[2 * q + 1] = v.z;
@@ -131,6 +138,75 @@ __device__ __forceinline__ uint64_t rc_canonical_dev(uint64_t code, int k)
     const uint32_t zl = __builtin_amdgcn_bitop3_b32(yl << 1, yl >> 1, 0x55555555u, 0x27);
     const uint64_t rc = (((uint64_t)zh << 32) | zl) >> (64 - 2 * k);
     return rc < code ? rc : code;
+}
+
+// Store::GetCount (Store.h:59-66) for the 64 k-mers of a wavefront, one per lane, the four lanes of a QUAD reading a bucket
+// together: in round r the quad looks at the home bucket of its lane r -- lane q loads the 16 bytes with slots 2q and 2q + 1,
+// compares them, and the first match in slot order is passed round the quad (two DPP steps) -- so a load instruction touches 16
+// lines, 64 contiguous bytes a quad, instead of 64 lines 16 bytes each, and a bucket costs one translation and one pass
+// through the vector L1's address stage instead of four.  tools/microbench_bucket.hip (round 6, 2^30 random buckets, the same
+// slot compare both ways): 217 -> 266 G buckets/s out of a table the L2 holds, 58 -> 56 G/s out of 128 MB - 1 GB (the
+// fabric's request rate either way), 24 -> 51 G/s out of 4 GB, beyond the reach of the TLB.  The rare k-mer whose home
+// bucket is full and says "continue" finishes the walk by itself (rc_table_lookup_o from the second bucket on).
+// PACKED tables only (wave-uniform test; WIDE: the per-lane lookup).  `valid` = false: no lookup for this lane, result 0.
+// MUST be called with every lane of the wavefront active (the lanes lend each other their loads).
+template <int CTRL>
+__device__ __forceinline__ uint32_t rc_dpp_u32(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+template <bool EXT = true>
+__device__ __forceinline__ int rc_table_lookup_quad(const rc_table_view &T, uint64_t canon, bool valid)
+{
+    if (!T.layout) return valid ? rc_table_lookup<EXT>(T, canon) : 0;
+    const int ql = threadIdx.x & 3;
+    const int ext = EXT ? T.ext : 0;
+    uint32_t b, rem, xrem, top;
+    rc_packed_addr(canon, T.k, T.nb_home, ext, &b, &rem, &xrem, &top);
+    if (T.filter && T.filter_all) {  // (wave-uniform) the absence filter first: a miss that ends there never touches the buckets
+        bool pass = false;
+        if (valid) {
+            if (T.filter_kind) {
+                uint32_t fw, fm;
+                rc_filter_core_addr(canon, T.filter_words, &fw, &fm);
+                pass = (T.filter[fw] & fm) == fm;
+            } else {
+                const uint32_t fm = rc_filter_mask(rem);
+                pass = (T.filter[rc_mulhi32(top, T.filter_words)] & fm) == fm;
+            }
+        }
+        valid = pass;
+    }
+    const uint32_t cmask = RC_PACKED_COUNT_MASK >> ext;  // (uniform)
+    const uint32_t mhi = 0x7FFFFFFFu & ~cmask;
+    const uint32_t xhi = xrem << (27 - ext);
+    // what the quad needs to know about a lane's k-mer: bucket, remainder, the high word's wanted bits (displacement 0) -- and
+    // whether there is anything to look up (bit 31 of the wanted bits, which no entry has: bit 31 is the continue flag, masked out)
+    const uint32_t want = xhi | (valid ? 0u : 0x80000000u);
+    uint32_t mine = 0, more = 0;
+    auto round = [&](uint32_t bb, uint32_t rr, uint32_t ww, bool me) {
+        uint4 v = make_uint4(0, RC_PACKED_EMPTY_WORD, 0, RC_PACKED_EMPTY_WORD);
+        if (!(ww >> 31)) v = reinterpret_cast<const uint4 *>(T.buckets + (size_t)bb * RC_BUCKET_DWORDS)[ql];
+        const uint32_t t0 = __builtin_amdgcn_bitop3_b32(__builtin_amdgcn_bitop3_b32(v.y, ww, mhi, 0x28), v.x, rr, 0xF6);
+        const uint32_t t1 = __builtin_amdgcn_bitop3_b32(__builtin_amdgcn_bitop3_b32(v.w, ww, mhi, 0x28), v.z, rr, 0xF6);
+        uint32_t x = t1 == 0 ? v.w : 0u;
+        x = t0 == 0 ? v.y : x;                       // the first of the lane's two slots wins
+        const uint32_t y = rc_dpp_u32<0xB1>(x);      // quad_perm [1,0,3,2]
+        const uint32_t p01 = (ql & 1) ? (y ? y : x) : (x ? x : y);
+        const uint32_t z = rc_dpp_u32<0x4E>(p01);    // quad_perm [2,3,0,1]
+        const uint32_t r = (ql & 2) ? (z ? z : p01) : (p01 ? p01 : z);  // the first match in slot order, in every lane of the quad
+        const uint32_t cont = rc_dpp_u32<0xFF>(v.w) >> 31;  // the bucket's last slot (lane 3 of the quad) carries the continue flag
+        mine = me ? r : mine;
+        more = me ? cont : more;
+    };
+    round(rc_dpp_u32<0x00>(b), rc_dpp_u32<0x00>(rem), rc_dpp_u32<0x00>(want), ql == 0);
+    round(rc_dpp_u32<0x55>(b), rc_dpp_u32<0x55>(rem), rc_dpp_u32<0x55>(want), ql == 1);
+    round(rc_dpp_u32<0xAA>(b), rc_dpp_u32<0xAA>(rem), rc_dpp_u32<0xAA>(want), ql == 2);
+    round(rc_dpp_u32<0xFF>(b), rc_dpp_u32<0xFF>(rem), rc_dpp_u32<0xFF>(want), ql == 3);
+    int r = (int)(mine & cmask);
+    if (valid && r == 0 && more) r = rc_table_lookup_o<EXT>(T, canon, canon, nullptr, 1);  // (rare: the home bucket is full and the walk goes on)
+    else if (r == (int)cmask) r = rc_packed_overflow_count(T, canon);
+    return valid ? r : 0;
 }
 
 // ---- pieces of the probe kernels (K1) shared by rc_table.hip and rc_correct.hip ----------------------

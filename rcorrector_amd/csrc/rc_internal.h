@@ -136,7 +136,10 @@ struct rc_ctx {
     rc_dbuf loc_a, loc_list;  // locality order of a batch (rc_launch_locality_order)
     rc_dbuf tier_flag, tier_list;  // mixed-length batches: the reads of the middle / long tier in locality order (rc_launch_tier_lists)
     size_t tier_stride = 0;        // uint32 entries between the two sections of tier_list
-    bool env_no_dedup = false;  // RC_FUSED_DEDUP=0 (dev / tests): the fused probe kernel looks every position up, no per-tile k-mer set
+    bool env_fused_xcd = false;  // RC_FUSED_XCD=1 (dev): the fused probe kernel's tiles in XCD-contiguous order
+    bool env_k3_local = false;  // RC_K3_LOCAL=1 (dev): k_correct's work list in the batch's locality order (non-tiered batches)
+    int env_quad = -1;   // RC_PROBE_QUAD=0 / 1 (dev / tests): bucket reads by the lane / by the quad (rc_table_lookup_quad); -1: the default
+    int env_dedup = -1;  // RC_FUSED_DEDUP=0 / 1 (dev / tests): the fused probe kernel without / with its per-tile k-mer set; -1: the table decides (rc_launch_probe_threshold_list)
     bool env_no_fuse = false;  // RC_NO_FUSE=1 (dev): separate probe and threshold kernels in locality order too
     int env_force_ec = 0;      // RC_FORCE_EC=9|10 (dev / tests): at least this many count registers per lane in the 160-base instances
     bool env_no_tier = false;  // RC_NO_TIER=1 (dev / tests): no length tiers, the longest read of a batch decides every kernel
@@ -194,6 +197,7 @@ int rc_launch_tier_lists(rc_ctx *ctx, const struct rc_device_batch_args &a, int 
 // K1 over section `section` (0: middle tier, 1: long tier) of ctx->tier_list; a.max_len = the longest read of that tier
 int rc_launch_probe_tier(rc_ctx *ctx, const struct rc_device_batch_args &a, size_t nbytes, int32_t *d_counts, int section);
 int rc_launch_compact(rc_ctx *ctx, const uint8_t *d_cls, uint32_t n, uint32_t *d_list, size_t stride, uint32_t *d_count);
+int rc_launch_compact_local(rc_ctx *ctx, const uint8_t *d_cls, uint32_t n, uint32_t *d_list, size_t stride, uint32_t *d_count);
 int rc_launch_compact_flag(rc_ctx *ctx, const uint8_t *d_flag, uint32_t n, uint32_t *d_list, size_t stride, uint32_t *d_count);
 
 // rc_correct.hip

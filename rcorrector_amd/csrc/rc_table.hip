@@ -694,6 +694,21 @@ int rc_launch_compact(rc_ctx *ctx, const uint8_t *d_cls, uint32_t n, uint32_t *d
     return rc_compact_sections<RC_WORK_CLASSES>(ctx, d_cls, n, RC_WORK_CLASSES, -1, d_list, stride, d_count);
 }
 
+// the same with every section in the batch's locality order (RC_K3_LOCAL=1, dev): the classes are gathered through the order
+// (ctx->loc_list: every read once) and the compaction hands out the list's entries instead of positions
+__global__ __launch_bounds__(256) void k_gather_u8(const uint8_t *__restrict__ src, const uint32_t *__restrict__ idx, uint32_t n, uint8_t *__restrict__ dst)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+int rc_launch_compact_local(rc_ctx *ctx, const uint8_t *d_cls, uint32_t n, uint32_t *d_list, size_t stride, uint32_t *d_count)
+{
+    int rc = rc_dbuf_reserve(ctx, &ctx->tier_flag, (size_t)n + 256);  // (the tiers' flag array: free at this point of a pass)
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_gather_u8, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_cls, (const uint32_t *)ctx->loc_list.p, n, (uint8_t *)ctx->tier_flag.p);
+    return rc_compact_sections<RC_WORK_CLASSES>(ctx, (const uint8_t *)ctx->tier_flag.p, n, RC_WORK_CLASSES, -1, d_list, stride, d_count, (const uint32_t *)ctx->loc_list.p);
+}
+
 // section v - 1 (v = 1 .. 3) of d_list = the reads with d_flag[i] == v (k_single's list: by number of untrusted stretches)
 int rc_launch_compact_flag(rc_ctx *ctx, const uint8_t *d_flag, uint32_t n, uint32_t *d_list, size_t stride, uint32_t *d_count)
 {

@@ -136,3 +136,23 @@ def test_pack_bases_and_apply_fixes_are_plain_host_code(built):
     w = a.copy()
     w[fp] = fc
     assert np.array_equal(b, w)
+
+
+def test_build_provenance_matches_the_tree(built):
+    """profiles/r6_build.json (tools/build_provenance.py) records the sha256 of the shipped binaries and of every source they
+    are built from: while the sources in the tree are the recorded ones, the binaries must be the recorded ones too -- i.e. the
+    library a GPU box loads is the one the profiles were measured with, checkable without a rebuild."""
+    import importlib.util
+    import json
+    path = os.path.join(ROOT, "profiles", "r6_build.json")
+    if not os.path.exists(path):
+        pytest.skip("no provenance record yet (written after the last build of a round)")
+    rec = json.load(open(path))
+    spec = importlib.util.spec_from_file_location("build_provenance", os.path.join(ROOT, "tools", "build_provenance.py"))
+    bp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bp)
+    src, bins = bp.snapshot()
+    assert rec["sources"] and rec["binaries"]
+    if src != rec["sources"]:
+        pytest.skip("the sources have changed since the record was written")
+    assert bins["rcorrector_amd/librcorrector_amd.so"]["sha256"] == rec["binaries"]["rcorrector_amd/librcorrector_amd.so"]["sha256"]
