@@ -61,10 +61,23 @@ __device__ __forceinline__ int rc_table_lookup_o(const rc_table_view &T, uint64_
         const uint32_t cmask = RC_PACKED_COUNT_MASK >> ext;  // (uniform)
         const uint32_t mhi = 0x7FFFFFFFu & ~cmask;
         const uint32_t xhi = xrem << (27 - ext);
+        // A slot matches iff ((hi ^ whi) & mhi) | (lo ^ rem) is zero (an empty slot carries displacement 15, which no entry has): two
+        // three-input bit operations (v_bitop3_b32: 0x28 = (a ^ b) & c, 0xF6 = a | (b ^ c)), a compare and a select per slot; the
+        // count is masked out of the selected word once, behind the chain (round 6: the 64-bit compare of round 2 cost five
+        // instructions a slot, a register copy among them).
+        // The bucket is read HALF BY HALF (round 6).  The build fills a bucket's slots from the first on (k_scatter: positions in
+        // home order, rc_table.hip), so an empty fourth slot says that the second half is empty too -- and that the bucket does not
+        // say "continue", which takes a full one: the lanes that found their k-mer in slots 0-3, or whose bucket ends there, are
+        // done after two 16-byte loads.  At load 0.4 (3.2 entries a bucket) that is 89 % of the k-mers that are in the table and
+        // 60 % of those that are not; each of a probe's loads is a pass through the vector L1's address stage, which the probe
+        // kernels are bound by as much as by anything (`RC_EXP_BUCKET_LOADS`: 42.0 / 38.1 / 36.9 / 33.0 ms with 4 / 3 / 2 / 1 of them).
+        // -DRC_LOOKUP_WHOLE_BUCKET: all four loads up front, as until round 5 (A/B builds).
         for (uint32_t disp = disp0;; ++disp, ++b) {
             const uint4 *p = reinterpret_cast<const uint4 *>(T.buckets + (size_t)b * RC_BUCKET_DWORDS);
-            uint32_t dlo[RC_PACKED_SLOTS], dhi[RC_PACKED_SLOTS];
             if (n_req) ++*n_req;
+            const uint32_t whi = (disp << 27) | xhi;
+#ifdef RC_LOOKUP_WHOLE_BUCKET
+            uint32_t dlo[RC_PACKED_SLOTS], dhi[RC_PACKED_SLOTS];
 #pragma unroll
             for (int q = 0; q < RC_BUCKET_DWORDS / 4; ++q) {
 #ifdef RC_EXP_BUCKET_LOADS  // dev (WRONG counts): only the first RC_EXP_BUCKET_LOADS of a bucket's four 16-byte loads are issued -- what do the
@@ -77,19 +90,37 @@ __device__ __forceinline__ int rc_table_lookup_o(const rc_table_view &T, uint64_
                 dlo[2 * q + 1] = v.z;
                 dhi[2 * q + 1] = v.w;
             }
-            // an empty slot carries displacement 15, which no entry has: rem and displacement decide.  A slot matches iff
-            // ((hi ^ whi) & mhi) | (lo ^ rem) is zero: two three-input bit operations (v_bitop3_b32: 0x28 = (a ^ b) & c,
-            // 0xF6 = a | (b ^ c)), a compare and a select per slot -- the count is masked out of the selected word once, behind
-            // the chain (round 6: the 64-bit compare of round 2 cost five instructions a slot, a register copy among them)
-            const uint32_t whi = (disp << 27) | xhi;
             uint32_t rh = 0;
 #pragma unroll
             for (int s2 = RC_PACKED_SLOTS - 1; s2 >= 0; --s2) {
                 const uint32_t t = __builtin_amdgcn_bitop3_b32(__builtin_amdgcn_bitop3_b32(dhi[s2], whi, mhi, 0x28), dlo[s2], rem, 0xF6);
                 rh = t == 0 ? dhi[s2] : rh;
             }
+            const uint32_t last = dhi[RC_PACKED_SLOTS - 1];
+#else
+            uint32_t rh = 0, last = 0;
+            {
+                const uint4 v0 = p[0], v1 = p[1];
+                const uint32_t lo[4] = {v0.x, v0.z, v1.x, v1.z}, hi[4] = {v0.y, v0.w, v1.y, v1.w};
+#pragma unroll
+                for (int s2 = 3; s2 >= 0; --s2) {
+                    const uint32_t t = __builtin_amdgcn_bitop3_b32(__builtin_amdgcn_bitop3_b32(hi[s2], whi, mhi, 0x28), lo[s2], rem, 0xF6);
+                    rh = t == 0 ? hi[s2] : rh;
+                }
+                if (rh == 0 && (hi[3] & RC_PACKED_EMPTY_WORD) != RC_PACKED_EMPTY_WORD) {  // not found yet and the first half is full
+                    const uint4 v2 = p[2], v3 = p[3];
+                    const uint32_t lo2[4] = {v2.x, v2.z, v3.x, v3.z}, hi2[4] = {v2.y, v2.w, v3.y, v3.w};
+#pragma unroll
+                    for (int s2 = 3; s2 >= 0; --s2) {
+                        const uint32_t t = __builtin_amdgcn_bitop3_b32(__builtin_amdgcn_bitop3_b32(hi2[s2], whi, mhi, 0x28), lo2[s2], rem, 0xF6);
+                        rh = t == 0 ? hi2[s2] : rh;
+                    }
+                    last = hi2[3];
+                }
+            }
+#endif
             const int r = (int)(rh & cmask);
-            if (r != 0 || !(dhi[RC_PACKED_SLOTS - 1] >> 31) || disp == RC_PACKED_MAX_DISP) {
+            if (r != 0 || !(last >> 31) || disp == RC_PACKED_MAX_DISP) {
                 if (r == (int)cmask) return rc_packed_overflow_count(T, canon);
                 return r;
             }

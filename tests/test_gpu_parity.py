@@ -1295,7 +1295,14 @@ KNOBS = [{"RC_TABLE_LAYOUT": "wide"}, {"RC_TABLE_LOAD": "0.85"}, {"RC_TABLE_LOAD
          {"RC_TABLE_FILTER": "force", "RC_TABLE_FILTER_KIND": "core", "RC_K3_GENERIC": "1", "RC_NO_ALT": "1"},
          {"RC_TABLE_FILTER": "search"}, {"RC_TABLE_FILTER": "search", "RC_K3_GENERIC": "1"}, {"RC_TABLE_FILTER": "search", "RC_TABLE_LOAD": "0.85", "RC_NO_SINGLE": "1"},
          {"RC_NO_SINGLE": "1"}, {"RC_NO_SINGLE": "1", "RC_NO_ALT": "1"}, {"RC_NO_BS_EXT": "1"}, {"RC_NO_TIER": "1"},
-         {"RC_NO_TIER": "1", "RC_LOCALITY": "force"}]
+         {"RC_NO_TIER": "1", "RC_LOCALITY": "force"},
+         # round 6: the fused probe kernel's switches (the tile's k-mer set, XCD-contiguous tiles, a quad of lanes per bucket) and
+         # k_correct's list in locality order -- with the layouts / filters / loads that change what a bucket read finds
+         {"RC_LOCALITY": "force", "RC_FUSED_DEDUP": "1"}, {"RC_LOCALITY": "force", "RC_FUSED_DEDUP": "1", "RC_FUSED_XCD": "1", "RC_TABLE_LOAD": "0.85"},
+         {"RC_LOCALITY": "force", "RC_FUSED_XCD": "1", "RC_K3_LOCAL": "1"}, {"RC_LOCALITY": "force", "RC_PROBE_QUAD": "1"},
+         {"RC_LOCALITY": "force", "RC_PROBE_QUAD": "1", "RC_TABLE_LOAD": "0.85", "RC_TABLE_FILTER": "force", "RC_TABLE_FILTER_KIND": "core"},
+         {"RC_LOCALITY": "force", "RC_PROBE_QUAD": "1", "RC_TABLE_LAYOUT": "wide"},
+         {"RC_LOCALITY": "force", "RC_FUSED_DEDUP": "1", "RC_TABLE_FILTER": "force", "RC_TABLE_FILTER_KIND": "plain", "RC_K3_LOCAL": "1"}]
 
 
 @pytest.mark.gpu
