@@ -65,18 +65,19 @@ __device__ __forceinline__ int rc_table_lookup_o(const rc_table_view &T, uint64_
         // three-input bit operations (v_bitop3_b32: 0x28 = (a ^ b) & c, 0xF6 = a | (b ^ c)), a compare and a select per slot; the
         // count is masked out of the selected word once, behind the chain (round 6: the 64-bit compare of round 2 cost five
         // instructions a slot, a register copy among them).
-        // The bucket is read HALF BY HALF (round 6).  The build fills a bucket's slots from the first on (k_scatter: positions in
-        // home order, rc_table.hip), so an empty fourth slot says that the second half is empty too -- and that the bucket does not
-        // say "continue", which takes a full one: the lanes that found their k-mer in slots 0-3, or whose bucket ends there, are
-        // done after two 16-byte loads.  At load 0.4 (3.2 entries a bucket) that is 89 % of the k-mers that are in the table and
-        // 60 % of those that are not; each of a probe's loads is a pass through the vector L1's address stage, which the probe
-        // kernels are bound by as much as by anything (`RC_EXP_BUCKET_LOADS`: 42.0 / 38.1 / 36.9 / 33.0 ms with 4 / 3 / 2 / 1 of them).
-        // -DRC_LOOKUP_WHOLE_BUCKET: all four loads up front, as until round 5 (A/B builds).
+        // -DRC_LOOKUP_HALF_BUCKET (round 6, measured and left out): the bucket read HALF BY HALF.  The build fills a bucket's slots from
+        // the first on (k_scatter: positions in home order, rc_table.hip), so an empty fourth slot says that the second half is empty
+        // too -- and that the bucket does not say "continue", which takes a full one: the lanes that found their k-mer in slots 0-3,
+        // or whose bucket ends there (at load 0.4: 89 % of the k-mers that are in the table, 60 % of those that are not), are done
+        // after two 16-byte loads.  Each of a probe's loads is a pass through the vector L1's address stage, which the probe kernels
+        // feel (`RC_EXP_BUCKET_LOADS`: 42.0 / 38.1 / 36.9 / 33.0 ms with 4 / 3 / 2 / 1 of them) -- but the second half's loads still
+        // issue for the wave whenever one lane wants them, now behind a dependent compare: config 1 10.76 -> 11.39 ms, config 2 41.3 ->
+        // 42.3, config 3 62.0 -> 64.2, K2s and K3 + 2-3 % (profiles/r6_half_bucket_ab.txt; parity-green on 404 GPU tests).
         for (uint32_t disp = disp0;; ++disp, ++b) {
             const uint4 *p = reinterpret_cast<const uint4 *>(T.buckets + (size_t)b * RC_BUCKET_DWORDS);
             if (n_req) ++*n_req;
             const uint32_t whi = (disp << 27) | xhi;
-#ifdef RC_LOOKUP_WHOLE_BUCKET
+#ifndef RC_LOOKUP_HALF_BUCKET
             uint32_t dlo[RC_PACKED_SLOTS], dhi[RC_PACKED_SLOTS];
 #pragma unroll
             for (int q = 0; q < RC_BUCKET_DWORDS / 4; ++q) {
