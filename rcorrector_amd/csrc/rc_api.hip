@@ -208,6 +208,7 @@ rc_ctx *rc_create(const rc_config *cfg, char *errbuf, size_t errbuf_len)
     if (const char *xo = getenv("RC_FUSED_XCD")) ctx->env_fused_xcd = atoi(xo) != 0;
     if (const char *qd = getenv("RC_PROBE_QUAD")) ctx->env_quad = atoi(qd) != 0 ? 1 : 0;
     if (const char *kl = getenv("RC_K3_LOCAL")) ctx->env_k3_local = atoi(kl) != 0;
+    if (const char *wt = getenv("RC_FUSED_WAVE_TILES")) ctx->env_wave_tiles = atoi(wt) != 0;
     ctx->env_no_tier = getenv("RC_NO_TIER") != nullptr;
     if (const char *e = getenv("RC_FORCE_EC")) {
         const int v = atoi(e);

@@ -153,8 +153,10 @@ int rc_launch_kmer_info(rc_ctx *ctx, const rc_device_batch_args &a);
 // owners' k-mers -- a compact list -- are looked up, one bucket read per distinct k-mer of the tile, and every position takes
 // its count from its slot.  A k-mer that finds no slot within four steps is looked up on the spot.
 // QUAD: the probes go through rc_table_lookup_quad (rc_device.h: four lanes read a bucket together)
-template <int RC_FUSED_TILE, int WAVES, bool EXT, int EC = 8, int DEDUP = 0, bool QUAD = false>
-__global__ __launch_bounds__(RC_PROBE_THREADS) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_probe_threshold_list(rc_kernel_args A, size_t nbytes, const uint32_t *__restrict__ list,
+// NT: threads of the workgroup -- 256 (16 reads a tile), or 64 (RC_FUSED_WAVE_TILES=1, dev: a wavefront is a workgroup of its own with
+// four reads, so no wave ever waits at a barrier for another)
+template <int RC_FUSED_TILE, int WAVES, bool EXT, int EC = 8, int DEDUP = 0, bool QUAD = false, int NT = RC_PROBE_THREADS>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_probe_threshold_list(rc_kernel_args A, size_t nbytes, const uint32_t *__restrict__ list,
                                                                            uint32_t reads_per_block, int32_t *__restrict__ counts, uint32_t tiles_per_xcd)
 {
     constexpr int NS = DEDUP ? DEDUP : 1;
@@ -177,9 +179,9 @@ __global__ __launch_bounds__(RC_PROBE_THREADS) __attribute__((amdgpu_waves_per_e
     if ((uint64_t)tile * reads_per_block >= A.n) return;  // (uniform: the last XCD's stretch may be short)
     const uint32_t i0 = tile * reads_per_block;
     const uint32_t nr = A.n - i0 < reads_per_block ? A.n - i0 : reads_per_block;
-    for (int c = t; c < (RC_FUSED_TILE + 64) / 4; c += RC_PROBE_THREADS) s_raw[c] = 0;
+    for (int c = t; c < (RC_FUSED_TILE + 64) / 4; c += NT) s_raw[c] = 0;
     if constexpr (DEDUP != 0) {
-        for (int c = t; c < NS; c += RC_PROBE_THREADS) s_key[c] = ~0ull;  // (no canonical code is all ones: TT..T is the larger strand of AA..A)
+        for (int c = t; c < NS; c += NT) s_key[c] = ~0ull;  // (no canonical code is all ones: TT..T is the larger strand of AA..A)
         if (t == 0) s_nown = 0;
     }
     if ((uint32_t)t < nr) {
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(RC_PROBE_THREADS) __attribute__((amdgpu_waves_per_e
     constexpr int RC_FUSED_STOP_ = -1;
 #endif
     RC_FUSED_CUT(0, s_lpos[t & 15] ^ s_gpos[t & 15] ^ s_rid[t & 15]);
-    for (uint32_t j = (uint32_t)t >> 6; j < nr; j += RC_PROBE_THREADS / 64) {  // copy, aligned dwords, outside bytes masked to NUL
+    for (uint32_t j = (uint32_t)t >> 6; j < nr; j += NT / 64) {  // copy, aligned dwords, outside bytes masked to NUL
         if (!s_len1[j]) continue;
         const uint32_t g0 = s_gpos[j], lp = s_lpos[j], g1 = g0 + s_len1[j] - 1;
         const uint32_t w0 = g0 >> 2, w1 = (g1 + 3) >> 2;
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(RC_PROBE_THREADS) __attribute__((amdgpu_waves_per_e
     __syncthreads();
     RC_FUSED_CUT(1, s_raw[t]);
     const uint32_t total = s_lpos[nr];
-    for (int chunk = t; chunk < RC_FUSED_TILE / 16 + 2; chunk += RC_PROBE_THREADS) {
+    for (int chunk = t; chunk < RC_FUSED_TILE / 16 + 2; chunk += NT) {
         const uint4 v = *reinterpret_cast<const uint4 *>(s_raw + 4 * chunk);
         uint32_t code, am, tm, bad;
         const uint32_t vw[4] = {v.x, v.y, v.z, v.w};
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(RC_PROBE_THREADS) __attribute__((amdgpu_waves_per_e
 #define RC_PROBE_UNROLL 2
 #endif
     if constexpr (DEDUP != 0) {
-        for (uint32_t a = 4 + (uint32_t)t; a + (uint32_t)k <= total; a += RC_PROBE_THREADS) {  // every position enters its k-mer into the set
+        for (uint32_t a = 4 + (uint32_t)t; a + (uint32_t)k <= total; a += NT) {  // every position enters its k-mer into the set
             const int mw = a >> 5;
             int cnt = 0;
             if (!(__builtin_amdgcn_alignbit(m_bad[mw + 1], m_bad[mw], (uint32_t)a & 31u) & kmask)) {
@@ -307,12 +309,12 @@ __global__ __launch_bounds__(RC_PROBE_THREADS) __attribute__((amdgpu_waves_per_e
         __syncthreads();
         const uint32_t nown = s_nown;
 #pragma unroll RC_PROBE_UNROLL
-        for (uint32_t i = (uint32_t)t; i < nown; i += RC_PROBE_THREADS) {  // one bucket read per distinct k-mer of the tile
+        for (uint32_t i = (uint32_t)t; i < nown; i += NT) {  // one bucket read per distinct k-mer of the tile
             const uint32_t slot = s_own[i];
             s_val[slot] = rc_table_lookup<EXT>(A.T, (uint64_t)s_key[slot]);
         }
         __syncthreads();
-        for (uint32_t a = 4 + (uint32_t)t; a + (uint32_t)k <= total; a += RC_PROBE_THREADS) {
+        for (uint32_t a = 4 + (uint32_t)t; a + (uint32_t)k <= total; a += NT) {
             const int v = s_cnt[a];
             if (v < 0) s_cnt[a] = s_val[-1 - v];
         }
@@ -320,7 +322,7 @@ __global__ __launch_bounds__(RC_PROBE_THREADS) __attribute__((amdgpu_waves_per_e
         // probe, the four lanes of a quad reading each bucket together (rc_table_lookup_quad): the loop's trip count is the
         // wavefront's, not the lane's -- a lane past the end of the arena still lends its loads
 #pragma unroll RC_PROBE_UNROLL
-        for (uint32_t a0 = 4 + ((uint32_t)t & ~63u); a0 + (uint32_t)k <= total; a0 += RC_PROBE_THREADS) {
+        for (uint32_t a0 = 4 + ((uint32_t)t & ~63u); a0 + (uint32_t)k <= total; a0 += NT) {
             const uint32_t a = a0 + ((uint32_t)t & 63u);
             const bool inside = a + (uint32_t)k <= total;
             const uint32_t ac = inside ? a : 4u;  // (keeps the LDS reads of a lane past the end inside the arrays)
@@ -334,7 +336,7 @@ __global__ __launch_bounds__(RC_PROBE_THREADS) __attribute__((amdgpu_waves_per_e
         }
     } else {
 #pragma unroll RC_PROBE_UNROLL
-    for (uint32_t a = 4 + (uint32_t)t; a + (uint32_t)k <= total; a += RC_PROBE_THREADS) {  // probe: counts stay in LDS
+    for (uint32_t a = 4 + (uint32_t)t; a + (uint32_t)k <= total; a += NT) {  // probe: counts stay in LDS
         // a window with a letter outside ACGT -- the NUL behind a read included: a position that is no k-mer of any read -- counts 0
         const int mw = a >> 5;
         int cnt = 0;
@@ -350,7 +352,7 @@ __global__ __launch_bounds__(RC_PROBE_THREADS) __attribute__((amdgpu_waves_per_e
     RC_FUSED_CUT(3, s_cnt[t] ^ s_cnt[t + 256] ^ s_cnt[t + 512] ^ s_cnt[t + 768] ^ s_cnt[t + 1024] ^ s_cnt[t + 1280] ^ s_cnt[t + 1536] ^ s_cnt[t + 1792] ^ s_cnt[t + 2048] ^ s_cnt[t + 2304] ^ s_cnt[t + 2560]);
     // thresholds + classes: 16 reads per pass (one per 16-lane row; the list keeps mates adjacent)
     const uint8_t *raw8 = reinterpret_cast<const uint8_t *>(s_raw);
-    for (uint32_t j0 = 0; j0 < nr; j0 += RC_PROBE_THREADS / 16) {
+    for (uint32_t j0 = 0; j0 < nr; j0 += NT / 16) {
         const uint32_t j = j0 + ((uint32_t)t >> 4);
         const bool live = j < nr && s_len1[j] != 0;
         const uint32_t lp = live ? s_lpos[j] : 0;
@@ -371,7 +373,7 @@ __global__ __launch_bounds__(RC_PROBE_THREADS) __attribute__((amdgpu_waves_per_e
     // starts at the same offset modulo 4 here and in the arena; the up to three words in front of its
     // first count and behind its last one belong to NULs and to the last k-1 positions of a read,
     // which hold no count -- k >= 4, rc_launch_probe_threshold_list)
-    for (uint32_t j = (uint32_t)t >> 6; j < nr; j += RC_PROBE_THREADS / 64) {
+    for (uint32_t j = (uint32_t)t >> 6; j < nr; j += NT / 64) {
         if (!s_len1[j] || (A.cls && !s_cls[j])) continue;
         const int kcnt = (int)s_len1[j] - 1 - k + 1;
         const uint32_t lp = s_lpos[j], g0 = s_gpos[j], head = lp & 3u;
@@ -577,6 +579,17 @@ int rc_launch_probe_threshold_list(rc_ctx *ctx, const rc_device_batch_args &a, s
     //    tools/microbench_bucket.hip, but 57 more vector instructions per probe here: config 2 41.2 -> 47.0 ms, config 3 62.5 -> 77.4.
     const bool dedup = ctx->env_dedup > 0;
     const bool quad = ctx->env_quad > 0;
+    if (ctx->env_wave_tiles && ec == 8 && !ctx->ext) {  // dev: one wavefront, four reads, no inter-wave barrier (k <= 23-ish tables without extension bits)
+        const uint32_t rpw = 4;
+        const uint32_t nt = (a.n + rpw - 1) / rpw, tx = ctx->env_fused_xcd ? (nt + 7) / 8 : 0;
+        rc_timer_begin(ctx);
+        hipLaunchKernelGGL((k_probe_threshold_list<704, 6, false, 8, 0, false, 64>), dim3(tx ? tx * 8 : nt), dim3(64), 0, ctx->stream, A, nbytes,
+                           (const uint32_t *)ctx->loc_list.p, rpw, (int32_t *)ctx->counts.p, tx);
+        rc_timer_end(ctx, RC_T_PROBE);
+        RC_CHECK_HIP(ctx, hipGetLastError());
+        *done = true;
+        return RC_OK;
+    }
 #define RC_FUSED_LAUNCH(TILE, WAVES, EXT, EC)                                                                                                        \
     do {                                                                                                                                             \
         if (dedup)                                                                                                                                   \

@@ -137,6 +137,7 @@ struct rc_ctx {
     rc_dbuf tier_flag, tier_list;  // mixed-length batches: the reads of the middle / long tier in locality order (rc_launch_tier_lists)
     size_t tier_stride = 0;        // uint32 entries between the two sections of tier_list
     bool env_fused_xcd = false;  // RC_FUSED_XCD=1 (dev): the fused probe kernel's tiles in XCD-contiguous order
+    bool env_wave_tiles = false;  // RC_FUSED_WAVE_TILES=1 (dev): the fused probe kernel with one wavefront (four reads) per workgroup
     bool env_k3_local = false;  // RC_K3_LOCAL=1 (dev): k_correct's work list in the batch's locality order (non-tiered batches)
     int env_quad = -1;   // RC_PROBE_QUAD=0 / 1 (dev / tests): bucket reads by the lane / by the quad (rc_table_lookup_quad); -1: the default
     int env_dedup = -1;  // RC_FUSED_DEDUP=0 / 1 (dev / tests): the fused probe kernel without / with its per-tile k-mer set; -1: the table decides (rc_launch_probe_threshold_list)

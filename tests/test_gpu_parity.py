@@ -1302,6 +1302,7 @@ KNOBS = [{"RC_TABLE_LAYOUT": "wide"}, {"RC_TABLE_LOAD": "0.85"}, {"RC_TABLE_LOAD
          {"RC_LOCALITY": "force", "RC_FUSED_XCD": "1", "RC_K3_LOCAL": "1"}, {"RC_LOCALITY": "force", "RC_PROBE_QUAD": "1"},
          {"RC_LOCALITY": "force", "RC_PROBE_QUAD": "1", "RC_TABLE_LOAD": "0.85", "RC_TABLE_FILTER": "force", "RC_TABLE_FILTER_KIND": "core"},
          {"RC_LOCALITY": "force", "RC_PROBE_QUAD": "1", "RC_TABLE_LAYOUT": "wide"},
+         {"RC_LOCALITY": "force", "RC_FUSED_WAVE_TILES": "1"}, {"RC_LOCALITY": "force", "RC_FUSED_WAVE_TILES": "1", "RC_FUSED_XCD": "1", "RC_TABLE_LOAD": "0.85"},
          {"RC_LOCALITY": "force", "RC_FUSED_DEDUP": "1", "RC_TABLE_FILTER": "force", "RC_TABLE_FILTER_KIND": "plain", "RC_K3_LOCAL": "1"}]
 
 

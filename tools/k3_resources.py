@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Register / spill figures of the k_correct instances as the compiler reports them (hipcc -Rpass-analysis=kernel-resource-usage,
-cross-compiled: no GPU needed) -> profiles/r5_k3_resources.json, which bench.py attaches to config.k_correct."""
+cross-compiled: no GPU needed) -> profiles/r6_k3_resources.json, which bench.py attaches to config.k_correct."""
 import json, os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "rcorrector_amd", "csrc")
@@ -21,6 +21,6 @@ for f in ("rc_correct.hip", "rc_correct_k23.hip", "rc_correct_k25.hip", "rc_corr
         m = re.search(r"remark:\s+(TotalSGPRs|VGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|SGPRs Spill|VGPRs Spill|LDS Size \[bytes/block\]): (\d+)", ln)
         if m and cur:
             out[cur][m.group(1)] = int(m.group(2))
-json.dump(out, open(os.path.join(ROOT, "profiles", "r5_k3_resources.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "profiles", "r6_k3_resources.json"), "w"), indent=1)
 for k, v in out.items():
     print(k, v)
