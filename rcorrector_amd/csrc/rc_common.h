@@ -27,11 +27,17 @@
 #define RC_INF 1000000000        // utils.h:10
 #define RC_INT_MIN (-2147483647 - 1)
 
-// ---- table buckets: 64 B, one HBM sector per probe; two slot layouts -------------------------
-// WIDE   (layout 0): 5 x {key_lo, key_hi, count} + 1 meta dword.  count == 0 marks an empty slot
+// ---- table buckets: 32 B (round 6; 64 B until round 5), two slot layouts ---------------------
+// Why 32: a lane reads a bucket 16 bytes at a time, and each of those loads is a pass of 64 scattered addresses through the
+// vector L1's address / tag stage -- what the probe kernels are bound by as much as by anything (profiles/
+// r6_fused_where_the_time_goes.txt).  Two loads a probe instead of four: config 1 / 2 / 3 / 4 fused kernel 11.0 -> 10.0, 42.3 ->
+// 38.2, 62.8 -> 56.6, 396 -> 375 ms, once the k-mers that must look at a second bucket (2.4 % at load 0.4, four slots a bucket;
+// 0.6 % with eight) are finished apart from the main loop (rc_table_lookup_o: `more`).  Half a sector: two buckets share the
+// 64 bytes HBM moves at least; the L2 fetches 128-byte lines either way.  -DRC_BUCKET_DWORDS=16 / 4 build 64- / 16-byte buckets.
+// WIDE   (layout 0): (RC_BUCKET_DWORDS - 1) / 3 x {key_lo, key_hi, count} + 1 meta dword.  count == 0 marks an empty slot
 //   (stored counts are >= 2 by construction, main.cpp:299); meta bit0 = "some key whose home is <=
 //   this bucket lives in a later bucket" (probe goes on).  Any k, any count.
-// PACKED (layout 1): 8 x {rem, word}.  The canonical code goes through a bijection of the 2k-bit
+// PACKED (layout 1): RC_BUCKET_DWORDS / 2 x {rem, word}.  The canonical code goes through a bijection of the 2k-bit
 //   key space; the home bucket is the top of (mixed * nb_home) and `rem` the next 32 bits of that
 //   product, which together identify the code as long as nb_home >= 2^(2k-32) (rc_packed_addr).
 //   word = count (27 bits) | displacement bucket - home (4 bits, 0..14; 15 = empty slot) | bit 31: the
@@ -40,10 +46,12 @@
 //   Where nb_home < 2^(2k-32) (k >= 28 for tables of ordinary size) the remainder takes `ext` more
 //   bits, the next ones of the same product, at the top of the count field: word = count (27-ext
 //   bits) | remainder bits 32..32+ext (ext bits) | displacement | flag, for counts below 2^(27-ext).
-#define RC_BUCKET_DWORDS 16
-#define RC_BUCKET_BYTES 64
-#define RC_WIDE_SLOTS 5
-#define RC_PACKED_SLOTS 8
+#ifndef RC_BUCKET_DWORDS
+#define RC_BUCKET_DWORDS 8
+#endif
+#define RC_BUCKET_BYTES (4 * RC_BUCKET_DWORDS)
+#define RC_WIDE_SLOTS ((RC_BUCKET_DWORDS - 1) / 3)
+#define RC_PACKED_SLOTS (RC_BUCKET_DWORDS / 2)
 #define RC_PACKED_COUNT_MASK 0x07FFFFFFu
 #define RC_PACKED_MAX_DISP 14            // displacement 15 marks an empty slot
 #define RC_PACKED_EMPTY_WORD 0x78000000u

@@ -164,6 +164,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
     __shared__ int32_t s_val[NS];
     __shared__ uint16_t s_own[NS];
     __shared__ uint32_t s_nown;
+    constexpr uint32_t RC_LATE_CAP = 64;                 // k-mers per wavefront whose walk goes on behind the home bucket (the probe loop)
+    __shared__ uint16_t s_late[NT / 64][RC_LATE_CAP];
+    __shared__ uint32_t s_nlate[NT / 64];
     __shared__ __attribute__((aligned(16))) uint32_t s_raw[(RC_FUSED_TILE + 64) / 4];
     __shared__ uint32_t s_code[RC_FUSED_TILE / 16 + 4];
     // letter masks of the arena, bit p % 32 of word p / 32 = arena byte p (rc_pack16m): not one of ACGT / an A / a T
@@ -335,17 +338,45 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
             if (inside) s_cnt[a] = cnt;
         }
     } else {
+    // probe: counts stay in LDS.  A k-mer that is not in its home bucket while the bucket says "continue" (a full bucket: 0.6 % of the
+    // probes at load 0.4) is NOT followed here -- one such lane would send its whole wavefront through a second bucket read, a third
+    // of all loop iterations -- but noted in the wavefront's list and finished below, the stragglers of a wavefront side by side.
+    const int wv = t >> 6;
+    if ((t & 63) == 0) s_nlate[wv] = 0;
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll RC_PROBE_UNROLL
-    for (uint32_t a = 4 + (uint32_t)t; a + (uint32_t)k <= total; a += NT) {  // probe: counts stay in LDS
+    for (uint32_t a = 4 + (uint32_t)t; a + (uint32_t)k <= total; a += NT) {
         // a window with a letter outside ACGT -- the NUL behind a read included: a position that is no k-mer of any read -- counts 0
         const int mw = a >> 5;
         int cnt = 0;
         if (!(__builtin_amdgcn_alignbit(m_bad[mw + 1], m_bad[mw], (uint32_t)a & 31u) & kmask)) {
             const int cw = a >> 4, cs = 2 * (a & 15);  // the 64 bits from base a on: two words shifted up, the third fills in (no branch on cs)
             const uint64_t x = ((((uint64_t)s_code[cw] << 32) | s_code[cw + 1]) << cs) | (((uint64_t)s_code[cw + 2] << cs) >> 32);
-            cnt = rc_table_lookup<EXT>(A.T, rc_canonical_dev(x >> (64 - 2 * k), k));
+            const uint64_t canon = rc_canonical_dev(x >> (64 - 2 * k), k);
+            bool more = false;
+            cnt = rc_table_lookup_o<EXT>(A.T, canon, canon, nullptr, 0, &more);
+            if (more) {
+                const uint32_t slot = atomicAdd(&s_nlate[wv], 1u);
+                if (slot < RC_LATE_CAP)
+                    s_late[wv][slot] = (uint16_t)a;
+                else
+                    cnt = rc_table_lookup_o<EXT>(A.T, canon, canon, nullptr, 1);  // (a crowded list: on the spot)
+            }
         }
         s_cnt[a] = cnt;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    {
+        const uint32_t nl = s_nlate[wv] < RC_LATE_CAP ? s_nlate[wv] : RC_LATE_CAP;
+        for (uint32_t i = (uint32_t)t & 63u; i < nl; i += 64u) {
+            const uint32_t a = s_late[wv][i];
+            const int cw = a >> 4, cs = 2 * (a & 15);
+            const uint64_t x = ((((uint64_t)s_code[cw] << 32) | s_code[cw + 1]) << cs) | (((uint64_t)s_code[cw + 2] << cs) >> 32);
+            const uint64_t canon = rc_canonical_dev(x >> (64 - 2 * k), k);
+            s_cnt[a] = rc_table_lookup_o<EXT>(A.T, canon, canon, nullptr, 1);
+        }
     }
     }
     __syncthreads();

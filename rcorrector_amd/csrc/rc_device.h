@@ -34,8 +34,12 @@ __device__ inline int rc_packed_overflow_count(const rc_table_view &T, uint64_t 
 // search node's four extensions), for the "core" filter of rc_common.h; callers without such neighbours pass canon
 // disp0 (PACKED, rc_table_lookup_quad's straggler path): the walk starts at the disp0-th bucket behind the home bucket -- the ones
 // in front of it have been looked at, and so has the filter
+// more (PACKED): only ONE bucket is looked at; where the walk would go on to the next one -- the k-mer not found, the bucket full and
+// flagged -- *more is set and 0 returned: the caller finishes those k-mers later, gathered into full wavefronts (disp0 = 1), instead
+// of sending the whole wavefront round the loop again for a lane or two (round 6, the fused probe kernel)
 template <bool EXT = true, bool SEARCH = false>
-__device__ __forceinline__ int rc_table_lookup_o(const rc_table_view &T, uint64_t canon, uint64_t orient, uint32_t *n_req = nullptr, uint32_t disp0 = 0)
+__device__ __forceinline__ int rc_table_lookup_o(const rc_table_view &T, uint64_t canon, uint64_t orient, uint32_t *n_req = nullptr, uint32_t disp0 = 0,
+                                                 bool *more = nullptr)
 {
     // The slots are compared as 64-bit words, from the last slot to the first, so that the first slot in
     // probe order is assigned last and wins without a test (two instructions per slot: the probe
@@ -124,6 +128,10 @@ __device__ __forceinline__ int rc_table_lookup_o(const rc_table_view &T, uint64_
             if (r != 0 || !(last >> 31) || disp == RC_PACKED_MAX_DISP) {
                 if (r == (int)cmask) return rc_packed_overflow_count(T, canon);
                 return r;
+            }
+            if (more) {
+                *more = true;
+                return 0;
             }
         }
     }
@@ -218,7 +226,7 @@ __device__ __forceinline__ int rc_table_lookup_quad(const rc_table_view &T, uint
     uint32_t mine = 0, more = 0;
     auto round = [&](uint32_t bb, uint32_t rr, uint32_t ww, bool me) {
         uint4 v = make_uint4(0, RC_PACKED_EMPTY_WORD, 0, RC_PACKED_EMPTY_WORD);
-        if (!(ww >> 31)) v = reinterpret_cast<const uint4 *>(T.buckets + (size_t)bb * RC_BUCKET_DWORDS)[ql];
+        if (!(ww >> 31) && ql < RC_BUCKET_DWORDS / 4) v = reinterpret_cast<const uint4 *>(T.buckets + (size_t)bb * RC_BUCKET_DWORDS)[ql];
         const uint32_t t0 = __builtin_amdgcn_bitop3_b32(__builtin_amdgcn_bitop3_b32(v.y, ww, mhi, 0x28), v.x, rr, 0xF6);
         const uint32_t t1 = __builtin_amdgcn_bitop3_b32(__builtin_amdgcn_bitop3_b32(v.w, ww, mhi, 0x28), v.z, rr, 0xF6);
         uint32_t x = t1 == 0 ? v.w : 0u;
@@ -227,7 +235,7 @@ __device__ __forceinline__ int rc_table_lookup_quad(const rc_table_view &T, uint
         const uint32_t p01 = (ql & 1) ? (y ? y : x) : (x ? x : y);
         const uint32_t z = rc_dpp_u32<0x4E>(p01);    // quad_perm [2,3,0,1]
         const uint32_t r = (ql & 2) ? (z ? z : p01) : (p01 ? p01 : z);  // the first match in slot order, in every lane of the quad
-        const uint32_t cont = rc_dpp_u32<0xFF>(v.w) >> 31;  // the bucket's last slot (lane 3 of the quad) carries the continue flag
+        const uint32_t cont = rc_dpp_u32<(RC_BUCKET_DWORDS / 4 - 1) * 0x55>(v.w) >> 31;  // the bucket's last slot (the quad's lane 3 with 64-byte buckets) carries the continue flag
         mine = me ? r : mine;
         more = me ? cont : more;
     };

@@ -48,7 +48,14 @@ def test_table_lookup_matches_store(gpu_ctx_factory, k):
     got = ctx.lookup(absent)
     assert (got[~present] == 0).all()
     st = ctx.table_stats()
-    assert st["entries"] == len(can) and st["bytes"] in (st["buckets"] * 64, st["buckets"] * 128)
+    assert st["entries"] == len(can) and st["bytes"] in (st["buckets"] * _bucket_bytes(), st["buckets"] * 2 * _bucket_bytes())
+
+
+def _bucket_bytes():
+    """bytes of a table bucket as the library is built (rc_common.h: RC_BUCKET_DWORDS; PACKED: 8 bytes a slot)"""
+    import re
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rcorrector_amd", "csrc", "rc_common.h")).read()
+    return 4 * int(re.search(r"#ifndef RC_BUCKET_DWORDS\n#define RC_BUCKET_DWORDS (\d+)", src).group(1))
 
 
 def test_table_later_duplicate_wins(gpu_ctx_factory):
@@ -658,7 +665,7 @@ def test_table_packed_and_wide_layouts_hold_the_same_table(k, n, monkeypatch):
     fwd = rng.integers(0, 1 << 63, size=n, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=n, dtype=np.uint64)
     fwd &= mask
     can = np.unique(np.minimum(fwd, _revcomp_codes(fwd, k)))
-    buckets = int((len(can) + 1000) / (8 * 0.4)) + 1   # the build's choice for a small table: entries / (8 slots * load 0.4)
+    buckets = int((len(can) + 1000) / (_bucket_bytes() // 8 * 0.4)) + 1   # the build's choice for a small table: entries / (slots per bucket * load 0.4)
     ext = 0
     while 2 * k > 32 and (buckets << ext) < (1 << (2 * k - 32)):
         ext += 1
