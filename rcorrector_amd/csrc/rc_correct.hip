@@ -138,9 +138,12 @@ int rc_launch_kmer_info(rc_ctx *ctx, const rc_device_batch_args &a);
 // eight 16-byte loads of two probes in flight -- measured on 25 M x 150 bp against a 1.26 GB table:
 // 44.1 / 42.3 / 46.2 / 47.7 ms at 5 / 6 / 7 / 8 waves (a 545 MB table, mostly cache hits, prefers
 // eight: 65.5 -> 62.1 ms).
+// Round 6, 32-byte buckets (a probe in flight holds 8 VGPRs instead of 16): 38.1 / 36.9-38.0 / 35.9 / 41.6 ms at 5 / 6 / 7 / 8 on that
+// table, 61.5 / 56.5 / 53.7 / 55.6 on the 545 MB one -- seven for both (72 VGPRs, 7 x 17.6 KB of LDS a CU).
 #ifndef RC_FUSED_SMALL_WAVES
-#define RC_FUSED_SMALL_WAVES 6
+#define RC_FUSED_SMALL_WAVES 7
 #endif
+#define RC_FUSED_EXT_WAVES 6  // (the instances for tables with remainder-extension bits -- config 4's -- keep six: 372 vs 374-398 ms at seven)
 // EC = count registers per lane of the threshold rows (rc_quarter.h): 8 for reads of up to 128 k-mers, 9 for 144 (151-base
 // reads at k = 23), 10 for every read of up to 160 bases.  A read the tier of this launch does not hold (rc_kernel_args::
 // tier_lo / tier_hi: a longer read, or the mate of one) is left out -- no bases copied, no counts, cls = 0.
@@ -637,17 +640,17 @@ int rc_launch_probe_threshold_list(rc_ctx *ctx, const rc_device_batch_args &a, s
             hipLaunchKernelGGL((k_probe_threshold_list<4096, 6, false, 8, 0>), grid, block, 0, ctx->stream, A, nbytes, list, rpb, counts, txcd);
     } else if (ec == 8) {
         if (ctx->ext)
-            RC_FUSED_LAUNCH(2816, RC_FUSED_SMALL_WAVES, true, 8);
+            RC_FUSED_LAUNCH(2816, RC_FUSED_EXT_WAVES, true, 8);
         else
             RC_FUSED_LAUNCH(2816, RC_FUSED_SMALL_WAVES, false, 8);
     } else if (ec == 9) {
         if (ctx->ext)
-            RC_FUSED_LAUNCH(2816, RC_FUSED_SMALL_WAVES, true, 9);
+            RC_FUSED_LAUNCH(2816, RC_FUSED_EXT_WAVES, true, 9);
         else
             RC_FUSED_LAUNCH(2816, RC_FUSED_SMALL_WAVES, false, 9);
     } else {
         if (ctx->ext)
-            RC_FUSED_LAUNCH(2816, RC_FUSED_SMALL_WAVES, true, 10);
+            RC_FUSED_LAUNCH(2816, RC_FUSED_EXT_WAVES, true, 10);
         else
             RC_FUSED_LAUNCH(2816, RC_FUSED_SMALL_WAVES, false, 10);
     }
