@@ -41,7 +41,8 @@
 #pragma once
 
 #ifndef RC_K2S_WAVES
-#define RC_K2S_WAVES 7  // waves per SIMD the register allocation is held to (25 M x 150 bp pairs: 12.4 / 11.4 / 11.1 / 11.4 ms at 5 / 6 / 7 / 8)
+#define RC_K2S_WAVES 8  // waves per SIMD the register allocation is held to (25 M x 150 bp pairs, round 3: 12.4 / 11.4 / 11.1 / 11.4 ms at 5 / 6 / 7 / 8;
+                        // round 6, 32-byte buckets -- a lookup holds half the registers: 11.4 / 10.5 / 10.0 at 6 / 7 / 8, config 3 19.5 / 17.6 / 16.9)
 #endif
 #ifndef RC_K2S_GRID
 #define RC_K2S_GRID 128  // workgroups per CU of the grid that walks the list (25 M x 150 bp pairs: 11.5 / 11.0 / 10.4 / 10.2 / 10.2 ms at 12 / 24 / 48 / 96 / 384: the sections by number of stretches are uneven work)
