@@ -238,7 +238,7 @@ void rc_destroy(rc_ctx *c)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     rc_dbuf *bufs[] = {&ctx->counts, &ctx->strong, &ctx->info, &ctx->stack, &ctx->work,
                        &ctx->h_seq, &ctx->h_qual, &ctx->h_off, &ctx->h_res, &ctx->trace, &ctx->cls, &ctx->worklist, &ctx->sel_tmp,
-                       &ctx->loc_a, &ctx->loc_list, &ctx->tier_flag, &ctx->tier_list, &ctx->cand, &ctx->single_list, &ctx->runs, &ctx->bs_dev};
+                       &ctx->loc_a, &ctx->loc_list, &ctx->loc_span, &ctx->tier_flag, &ctx->tier_list, &ctx->cand, &ctx->single_list, &ctx->runs, &ctx->bs_dev};
     for (rc_dbuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (ctx->slots) {

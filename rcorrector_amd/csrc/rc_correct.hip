@@ -160,7 +160,8 @@ int rc_launch_kmer_info(rc_ctx *ctx, const rc_device_batch_args &a);
 // four reads, so no wave ever waits at a barrier for another)
 template <int RC_FUSED_TILE, int WAVES, bool EXT, int EC = 8, int DEDUP = 0, bool QUAD = false, int NT = RC_PROBE_THREADS>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_probe_threshold_list(rc_kernel_args A, size_t nbytes, const uint32_t *__restrict__ list,
-                                                                           uint32_t reads_per_block, int32_t *__restrict__ counts, uint32_t tiles_per_xcd)
+                                                                           uint32_t reads_per_block, int32_t *__restrict__ counts, uint32_t tiles_per_xcd,
+                                                                           const uint2 *__restrict__ span)
 {
     constexpr int NS = DEDUP ? DEDUP : 1;
     __shared__ unsigned long long s_key[NS];
@@ -191,10 +192,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         if (t == 0) s_nown = 0;
     }
     if ((uint32_t)t < nr) {
-        const uint32_t r = list[i0 + t], g0 = A.off[r];
+        const uint32_t r = list[i0 + t];
+        const uint2 sp = span[i0 + t];  // (k_probe_order left it next to the list: no gather of the offsets behind the list's load)
         s_rid[t] = r;
-        s_gpos[t] = g0;
-        s_len1[t] = A.off[r + 1] - g0;  // bases + the NUL
+        s_gpos[t] = sp.x;
+        s_len1[t] = sp.y;  // bases + the NUL
     }
     __syncthreads();
     if (A.tier_hi != RC_TIER_ALL) {  // (uniform) the list keeps mates adjacent and nr is even in paired / interleaved batches
@@ -618,7 +620,7 @@ int rc_launch_probe_threshold_list(rc_ctx *ctx, const rc_device_batch_args &a, s
         const uint32_t nt = (a.n + rpw - 1) / rpw, tx = ctx->env_fused_xcd ? (nt + 7) / 8 : 0;
         rc_timer_begin(ctx);
         hipLaunchKernelGGL((k_probe_threshold_list<704, 6, false, 8, 0, false, 64>), dim3(tx ? tx * 8 : nt), dim3(64), 0, ctx->stream, A, nbytes,
-                           (const uint32_t *)ctx->loc_list.p, rpw, (int32_t *)ctx->counts.p, tx);
+                           (const uint32_t *)ctx->loc_list.p, rpw, (int32_t *)ctx->counts.p, tx, (const uint2 *)ctx->loc_span.p);
         rc_timer_end(ctx, RC_T_PROBE);
         RC_CHECK_HIP(ctx, hipGetLastError());
         *done = true;
@@ -627,17 +629,17 @@ int rc_launch_probe_threshold_list(rc_ctx *ctx, const rc_device_batch_args &a, s
 #define RC_FUSED_LAUNCH(TILE, WAVES, EXT, EC)                                                                                                        \
     do {                                                                                                                                             \
         if (dedup)                                                                                                                                   \
-            hipLaunchKernelGGL((k_probe_threshold_list<TILE, 5, EXT, EC, 1024>), grid, block, 0, ctx->stream, A, nbytes, list, rpb, counts, txcd);         \
+            hipLaunchKernelGGL((k_probe_threshold_list<TILE, 5, EXT, EC, 1024>), grid, block, 0, ctx->stream, A, nbytes, list, rpb, counts, txcd, (const uint2 *)ctx->loc_span.p);         \
         else if (quad)                                                                                                                               \
-            hipLaunchKernelGGL((k_probe_threshold_list<TILE, WAVES, EXT, EC, 0, true>), grid, block, 0, ctx->stream, A, nbytes, list, rpb, counts, txcd);  \
+            hipLaunchKernelGGL((k_probe_threshold_list<TILE, WAVES, EXT, EC, 0, true>), grid, block, 0, ctx->stream, A, nbytes, list, rpb, counts, txcd, (const uint2 *)ctx->loc_span.p);  \
         else                                                                                                                                         \
-            hipLaunchKernelGGL((k_probe_threshold_list<TILE, WAVES, EXT, EC, 0>), grid, block, 0, ctx->stream, A, nbytes, list, rpb, counts, txcd);        \
+            hipLaunchKernelGGL((k_probe_threshold_list<TILE, WAVES, EXT, EC, 0>), grid, block, 0, ctx->stream, A, nbytes, list, rpb, counts, txcd, (const uint2 *)ctx->loc_span.p);        \
     } while (0)
     if (large) {  // (reads of up to 119 bases: at most 116 k-mers; 32 reads a tile: their k-mers would want a set of 2 048 slots -- not built)
         if (ctx->ext)
-            hipLaunchKernelGGL((k_probe_threshold_list<4096, 6, true, 8, 0>), grid, block, 0, ctx->stream, A, nbytes, list, rpb, counts, txcd);
+            hipLaunchKernelGGL((k_probe_threshold_list<4096, 6, true, 8, 0>), grid, block, 0, ctx->stream, A, nbytes, list, rpb, counts, txcd, (const uint2 *)ctx->loc_span.p);
         else
-            hipLaunchKernelGGL((k_probe_threshold_list<4096, 6, false, 8, 0>), grid, block, 0, ctx->stream, A, nbytes, list, rpb, counts, txcd);
+            hipLaunchKernelGGL((k_probe_threshold_list<4096, 6, false, 8, 0>), grid, block, 0, ctx->stream, A, nbytes, list, rpb, counts, txcd, (const uint2 *)ctx->loc_span.p);
     } else if (ec == 8) {
         if (ctx->ext)
             RC_FUSED_LAUNCH(2816, RC_FUSED_EXT_WAVES, true, 8);

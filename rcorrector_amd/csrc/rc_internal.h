@@ -133,7 +133,7 @@ struct rc_ctx {
     bool cand_ready = false;
     rc_dbuf worklist; // RC_WORK_CLASSES sections of work_stride uint32 each: the reads with cls == 4, 3, 2, 1, ascending within a section
     rc_dbuf sel_tmp;  // rocPRIM scratch of the compaction
-    rc_dbuf loc_a, loc_list;  // locality order of a batch (rc_launch_locality_order)
+    rc_dbuf loc_a, loc_list, loc_span;  // locality order of a batch (rc_launch_locality_order): the reads, and where each lies in the arena
     rc_dbuf tier_flag, tier_list;  // mixed-length batches: the reads of the middle / long tier in locality order (rc_launch_tier_lists)
     size_t tier_stride = 0;        // uint32 entries between the two sections of tier_list
     bool env_fused_xcd = false;  // RC_FUSED_XCD=1 (dev): the fused probe kernel's tiles in XCD-contiguous order

@@ -828,16 +828,23 @@ __global__ __launch_bounds__(256) void k_unit_key(const uint8_t *__restrict__ se
 }
 
 // list[i] = the reads in the order k_probe_list takes them: sorted units, the mates of a pair together
-__global__ void k_probe_order(const uint32_t *__restrict__ unit_sorted, uint32_t n, int mode, uint32_t *__restrict__ list)
+// span[i] (round 6) = where read list[i] lies in the arena -- {first byte, bytes with the NUL}: the fused probe kernel's workgroups
+// then find their reads with two coalesced loads side by side instead of a load of the list and, behind it, a gather of the offsets
+__global__ void k_probe_order(const uint32_t *__restrict__ unit_sorted, uint32_t n, int mode, uint32_t *__restrict__ list,
+                              const uint32_t *__restrict__ off, uint2 *__restrict__ span)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    uint32_t r;
     if (mode == 1)
-        list[i] = unit_sorted[i >> 1] + ((i & 1u) ? (n >> 1) : 0u);
+        r = unit_sorted[i >> 1] + ((i & 1u) ? (n >> 1) : 0u);
     else if (mode == 2)
-        list[i] = 2u * unit_sorted[i >> 1] + (i & 1u);
+        r = 2u * unit_sorted[i >> 1] + (i & 1u);
     else
-        list[i] = unit_sorted[i];
+        r = unit_sorted[i];
+    list[i] = r;
+    const uint32_t g0 = off[r];
+    span[i] = make_uint2(g0, off[r + 1] - g0);
 }
 
 int rc_launch_locality_order(rc_ctx *ctx, const rc_device_batch_args &a, size_t nbytes)
@@ -846,6 +853,7 @@ int rc_launch_locality_order(rc_ctx *ctx, const rc_device_batch_args &a, size_t 
     int rc;
     if ((rc = rc_dbuf_reserve(ctx, &ctx->loc_a, (size_t)n_units * 16 + 256))) return rc;  // keys, keys', idx, idx'
     if ((rc = rc_dbuf_reserve(ctx, &ctx->loc_list, (size_t)n * 4 + 256))) return rc;
+    if ((rc = rc_dbuf_reserve(ctx, &ctx->loc_span, (size_t)n * 8 + 256))) return rc;
     uint32_t *keys = (uint32_t *)ctx->loc_a.p, *keys2 = keys + n_units, *idx = keys2 + n_units, *idx2 = idx + n_units;
     uint32_t upb = (uint32_t)(RC_KEY_TILE / ((size_t)(a.max_len + 1) * (a.mode == 2 ? 2 : 1)));
     if (upb > 256) upb = 256;
@@ -855,7 +863,8 @@ int rc_launch_locality_order(rc_ctx *ctx, const rc_device_batch_args &a, size_t 
     RC_CHECK_HIP(ctx, rocprim::radix_sort_pairs(nullptr, t1, keys, keys2, idx, idx2, (size_t)n_units, 0, 32, ctx->stream));
     if ((rc = rc_dbuf_reserve(ctx, &ctx->sel_tmp, t1))) return rc;
     RC_CHECK_HIP(ctx, rocprim::radix_sort_pairs(ctx->sel_tmp.p, t1, keys, keys2, idx, idx2, (size_t)n_units, 0, 32, ctx->stream));
-    hipLaunchKernelGGL(k_probe_order, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, idx2, n, a.mode, (uint32_t *)ctx->loc_list.p);
+    hipLaunchKernelGGL(k_probe_order, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, idx2, n, a.mode, (uint32_t *)ctx->loc_list.p, a.off,
+                       (uint2 *)ctx->loc_span.p);
     RC_CHECK_HIP(ctx, hipGetLastError());
     return RC_OK;
 }
