@@ -176,6 +176,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
     // letter masks of the arena, bit p % 32 of word p / 32 = arena byte p (rc_pack16m): not one of ACGT / an A / a T
     __shared__ __attribute__((aligned(4))) uint16_t s_bad[RC_FUSED_TILE / 16 + 20], s_am[RC_FUSED_TILE / 16 + 20], s_tm[RC_FUSED_TILE / 16 + 20];
     __shared__ uint32_t s_lpos[RC_PLIST_MAX_READS + 1], s_gpos[RC_PLIST_MAX_READS], s_len1[RC_PLIST_MAX_READS], s_rid[RC_PLIST_MAX_READS];
+    __shared__ uint32_t s_vpos[RC_PLIST_MAX_READS + 1];
+    __shared__ uint32_t s_kuni;
     __shared__ __attribute__((aligned(16))) int32_t s_cnt[RC_FUSED_TILE + 64];
     __shared__ uint8_t s_cls[RC_PLIST_MAX_READS];
     const int t = threadIdx.x, k = A.P.k;  // (an instance compiled for k = 23 was measured and dropped: 46.0 vs 41.9 ms)
@@ -216,18 +218,33 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
     // local start of each read: same alignment modulo 4 as in memory, a NUL in front.  Read j starts at base_j + (gpos_j & 3) with
     // base_0 = 4 and base_{j+1} = base_j + (((gpos_j & 3) + len1_j + 3) & ~3): a prefix sum, done by the first wave (round 6: one
     // thread used to walk the reads while 255 waited at the barrier)
+    // ... and s_vpos[j] = the k-mers of the reads in front of read j (the same scan: bytes in the low half of the word, k-mers in the
+    // high half -- 64 reads of 160 bases stay below 2^16 either way): the probe loop walks k-mers, not arena positions
     if (t < 64) {
         const bool in = (uint32_t)t < nr;
         const uint32_t sj = in ? (s_gpos[t] & 3u) + s_len1[t] : 0u;
-        uint32_t inc = (sj + 3u) & ~3u;  // inclusive scan over the wave
+        const uint32_t kc = in && s_len1[t] > (uint32_t)k ? s_len1[t] - (uint32_t)k : 0u;  // (len1 counts the NUL: kcnt = len - k + 1)
+        const uint32_t own = ((sj + 3u) & ~3u) | (kc << 16);
+        uint32_t inc = own;  // inclusive scan over the wave
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t up = __shfl_up(inc, o, 64);
             inc += t >= o ? up : 0u;
         }
-        const uint32_t base = 4u + inc - ((sj + 3u) & ~3u);
-        if (in) s_lpos[t] = base + (s_gpos[t] & 3u);
-        if ((uint32_t)t + 1 == nr) s_lpos[nr] = base + sj;  // the end of the last read
+        const uint32_t base = 4u + ((inc - own) & 0xFFFFu);
+        if (in) {
+            s_lpos[t] = base + (s_gpos[t] & 3u);
+            s_vpos[t] = (inc - own) >> 16;
+        }
+        if ((uint32_t)t + 1 == nr) {
+            s_lpos[nr] = base + sj;  // the end of the last read
+            s_vpos[nr] = inc >> 16;
+        }
+        // every read of the tile with the same number of k-mers (untrimmed reads of one length: the usual batch)?  Then k-mer v is
+        // k-mer v % K of read v / K, and the probe loop walks the tile's k-mers instead of its arena positions
+        const uint32_t kc0 = __shfl(kc, 0, 64);
+        const bool same = __ballot(in && kc != kc0) == 0;
+        if (t == 0) s_kuni = same ? kc0 : 0u;
     }
     __syncthreads();
 #define RC_FUSED_CUT(n, v)                                                       \
@@ -349,9 +366,27 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
     const int wv = t >> 6;
     if ((t & 63) == 0) s_nlate[wv] = 0;
     __builtin_amdgcn_wave_barrier();
+    // A sixth of a tile's arena positions start no k-mer -- the last k - 1 of every read, its NUL, the padding -- and walking them
+    // costs two of the loop's ten iterations with their loads.  Where every read of the tile has the same number K of k-mers
+    // (s_kuni: untrimmed reads of one length) the loop walks the K-MERS instead: k-mer v = k-mer v % K of read v / K (one
+    // multiply-high by 2^32 / K, exact below 2^14 k-mers a tile).  A ragged tile walks its positions as before.  [Mapping v to its
+    // read by binary search over the reads' k-mer prefix sums -- any tile -- was measured first: six dependent LDS reads an
+    // iteration, 35.5 -> 36.9 ms; -DRC_PROBE_BY_POSITION keeps every tile on the position walk.]
+#ifdef RC_PROBE_BY_POSITION
+    const uint32_t kuni = 0;
+#else
+    const uint32_t kuni = s_kuni;
+#endif
+    const uint32_t krcp = kuni ? (uint32_t)(0x100000000ull / kuni) + 1u : 0u;   // ceil(2^32 / K) (K > 1; K = 1: the position walk)
+    const uint32_t n_it = kuni > 1 ? s_vpos[nr] : (total >= (uint32_t)k + 4u ? total - (uint32_t)k - 4u + 1u : 0u);  // k-mers, or positions 4 .. total - k
 #pragma unroll RC_PROBE_UNROLL
-    for (uint32_t a = 4 + (uint32_t)t; a + (uint32_t)k <= total; a += NT) {
-        // a window with a letter outside ACGT -- the NUL behind a read included: a position that is no k-mer of any read -- counts 0
+    for (uint32_t v = (uint32_t)t; v < n_it; v += NT) {
+        uint32_t a = 4u + v;
+        if (kuni > 1) {  // (uniform)
+            const uint32_t jr = __umulhi(v, krcp);
+            a = s_lpos[jr] + (v - jr * kuni);
+        }
+        // a window with a letter outside ACGT counts 0 (walking positions: the NUL behind a read included -- a position that is no k-mer)
         const int mw = a >> 5;
         int cnt = 0;
         if (!(__builtin_amdgcn_alignbit(m_bad[mw + 1], m_bad[mw], (uint32_t)a & 31u) & kmask)) {
