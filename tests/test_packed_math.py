@@ -37,3 +37,14 @@ def test_pack16m_swar_equals_its_definition(tmp_path):
     p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
     out = p.stdout.decode()
     assert p.returncode == 0 and out.startswith("ok "), out
+
+
+def test_kmer_walk_reciprocal_is_exact():
+    """The fused probe kernel's k-mer walk (rc_correct.hip: tiles whose reads all have K k-mers) maps k-mer v to read v / K by one
+    multiply-high with floor(2^32 / K) + 1: exact for every K a read of up to 160 bases can have and every v a tile can hold
+    (64 reads x 160 k-mers < 2^14), which is what lets the loop skip the positions that start no k-mer."""
+    import numpy as np
+    v = np.arange(1 << 14, dtype=np.uint64)
+    for K in range(2, 161):
+        rcp = np.uint64((1 << 32) // K + 1)
+        assert np.array_equal((v * rcp) >> np.uint64(32), v // np.uint64(K)), K
